@@ -1,0 +1,210 @@
+"""ctypes binding of the CPU oracle (oracle/ivx_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg, never by the product path.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "_build", "libivx_oracle.so")
+_REF = os.path.join(_HERE, "_ref", "libref_superintervals.so")
+
+NULL_IDX = 0xFFFFFFFF
+
+_u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+_i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
+
+
+def build(force=False):
+    """Compile the C restatement (and, where /root/reference exists, the
+    reference-built superintervals checker)."""
+    if force or not os.path.exists(_LIB) or os.path.getmtime(_LIB) < os.path.getmtime(
+            os.path.join(_HERE, "ivx_oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "all"])
+    if os.path.isdir("/root/reference") and (force or not os.path.exists(_REF)):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "ref"])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB)
+        _lib.orc_join_brute.restype = C.c_uint64
+        _lib.orc_join_tree.restype = C.c_uint64
+        _lib.orc_nearest.restype = C.c_uint64
+        _lib.orc_merge.restype = C.c_uint64
+        _lib.orc_subtract.restype = C.c_uint64
+        _lib.orc_merge_intervals_i32.restype = C.c_uint64
+        _lib.orc_check_i32.restype = C.c_int64
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _k(a):
+    return np.ascontiguousarray(a, dtype=np.uint32)
+
+
+def _c32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _c64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _side32(key, s, e):
+    key, s, e = _k(key), _c32(s), _c32(e)
+    assert len(key) == len(s) == len(e)
+    return key, s, e, C.c_uint64(len(key))
+
+
+def join(bkey, bs, be, pkey, ps, pe, brute=False, threads=1, per_row=False):
+    """-> (build_rows u32[], probe_rows u32[]) [, per_row u64[]]"""
+    L = lib()
+    bk, bs_, be_, nb = _side32(bkey, bs, be)
+    pk, ps_, pe_, npr = _side32(pkey, ps, pe)
+    if brute:
+        n = L.orc_join_brute(_p(bk), _p(bs_), _p(be_), nb, _p(pk), _p(ps_), _p(pe_), npr, None, None, C.c_uint64(0))
+        ob = np.empty(n, np.uint32); op = np.empty(n, np.uint32)
+        L.orc_join_brute(_p(bk), _p(bs_), _p(be_), nb, _p(pk), _p(ps_), _p(pe_), npr, _p(ob), _p(op), C.c_uint64(n))
+        return ob, op
+    cnt = np.zeros(len(pk), np.uint64)
+    n = L.orc_join_tree(_p(bk), _p(bs_), _p(be_), nb, _p(pk), _p(ps_), _p(pe_), npr, None, None, C.c_uint64(0),
+                        _p(cnt), C.c_int(threads))
+    ob = np.empty(n, np.uint32); op = np.empty(n, np.uint32)
+    L.orc_join_tree(_p(bk), _p(bs_), _p(be_), nb, _p(pk), _p(ps_), _p(pe_), npr, _p(ob), _p(op), C.c_uint64(n),
+                    _p(cnt), C.c_int(threads))
+    return (ob, op, cnt) if per_row else (ob, op)
+
+
+def join_count(bkey, bs, be, pkey, ps, pe, threads=1):
+    """Total pairs + per-row counts, nothing materialised."""
+    L = lib()
+    bk, bs_, be_, nb = _side32(bkey, bs, be)
+    pk, ps_, pe_, npr = _side32(pkey, ps, pe)
+    cnt = np.zeros(len(pk), np.uint64)
+    n = L.orc_join_tree(_p(bk), _p(bs_), _p(be_), nb, _p(pk), _p(ps_), _p(pe_), npr, None, None, C.c_uint64(0),
+                        _p(cnt), C.c_int(threads))
+    return int(n), cnt
+
+
+def join_exists(bkey, bs, be, pkey, ps, pe):
+    L = lib()
+    bk, bs_, be_, nb = _side32(bkey, bs, be)
+    pk, ps_, pe_, npr = _side32(pkey, ps, pe)
+    out = np.zeros(len(pk), np.uint8)
+    L.orc_join_exists(_p(bk), _p(bs_), _p(be_), nb, _p(pk), _p(ps_), _p(pe_), npr, _p(out))
+    return out
+
+
+def count_overlaps(bkey, bs, be, pkey, ps, pe, strict=False):
+    L = lib()
+    bk, bs_, be_, nb = _side32(bkey, bs, be)
+    pk, ps_, pe_, npr = _side32(pkey, ps, pe)
+    out = np.zeros(len(pk), np.int64)
+    L.orc_count_overlaps(_p(bk), _p(bs_), _p(be_), nb, _p(pk), _p(ps_), _p(pe_), npr, C.c_int(int(strict)), _p(out))
+    return out
+
+
+def coverage(bkey, bs, be, pkey, ps, pe, strict=False):
+    L = lib()
+    bk, bs_, be_, nb = _side32(bkey, bs, be)
+    pk, ps_, pe_, npr = _side32(pkey, ps, pe)
+    out = np.zeros(len(pk), np.int64)
+    L.orc_coverage(_p(bk), _p(bs_), _p(be_), nb, _p(pk), _p(ps_), _p(pe_), npr, C.c_int(int(strict)), _p(out))
+    return out
+
+
+def merge_intervals(s, e):
+    s = _c32(s).copy(); e = _c32(e).copy()
+    m = lib().orc_merge_intervals_i32(_p(s), _p(e), C.c_uint64(len(s)))
+    return s[:m], e[:m]
+
+
+def nearest(bkey, bs, be, pkey, ps, pe, k=1, overlap=True, strict=False):
+    """-> (build_rows u32 (NULL_IDX = null), probe_rows u32, distance i64 (-1 = null))"""
+    L = lib()
+    bk, bs_, be_, nb = _side32(bkey, bs, be)
+    pk, ps_, pe_, npr = _side32(pkey, ps, pe)
+    cap = len(pk) * max(int(k), 1)
+    ob = np.empty(cap, np.uint32); op = np.empty(cap, np.uint32); od = np.empty(cap, np.int64)
+    n = L.orc_nearest(_p(bk), _p(bs_), _p(be_), nb, _p(pk), _p(ps_), _p(pe_), npr, C.c_int(int(strict)),
+                      C.c_uint32(int(k)), C.c_int(int(overlap)), _p(ob), _p(op), _p(od), C.c_uint64(cap))
+    return ob[:n], op[:n], od[:n]
+
+
+def merge(key, s, e, min_dist=0, strict=False):
+    """-> (key u32, start i64, end i64, n_intervals i64), keys ascending."""
+    L = lib()
+    key, s, e = _k(key), _c64(s), _c64(e)
+    n = len(key)
+    ok = np.empty(n, np.uint32); os_ = np.empty(n, np.int64); oe = np.empty(n, np.int64); on = np.empty(n, np.int64)
+    m = L.orc_merge(_p(key), _p(s), _p(e), C.c_uint64(n), C.c_int64(int(min_dist)), C.c_int(int(strict)),
+                    _p(ok), _p(os_), _p(oe), _p(on), C.c_uint64(n))
+    return ok[:m], os_[:m], oe[:m], on[:m]
+
+
+def subtract(lkey, ls, le, rkey, rs, re, strict=False):
+    """-> (key u32, start i64, end i64, left_row u32)"""
+    L = lib()
+    lkey, ls, le = _k(lkey), _c64(ls), _c64(le)
+    rkey, rs, re = _k(rkey), _c64(rs), _c64(re)
+    args = (_p(lkey), _p(ls), _p(le), C.c_uint64(len(lkey)), _p(rkey), _p(rs), _p(re), C.c_uint64(len(rkey)),
+            C.c_int(int(strict)))
+    m = L.orc_subtract(*args, None, None, None, None, C.c_uint64(0))
+    ok = np.empty(m, np.uint32); os_ = np.empty(m, np.int64); oe = np.empty(m, np.int64); orow = np.empty(m, np.uint32)
+    L.orc_subtract(*args, _p(ok), _p(os_), _p(oe), _p(orow), C.c_uint64(m))
+    return ok, os_, oe, orow
+
+
+def check_i32(v):
+    v = _c64(v)
+    return int(lib().orc_check_i32(_p(v), C.c_uint64(len(v))))
+
+
+# ---- the reference's own vendored structure, compiled from /root/reference ----
+
+_ref = None
+
+
+def ref_available():
+    return os.path.exists(_REF)
+
+
+def ref():
+    global _ref
+    if _ref is None:
+        _ref = C.CDLL(_REF)
+        _ref.ref_si_join.restype = C.c_uint64
+    return _ref
+
+
+def ref_join(bkey, bs, be, pkey, ps, pe):
+    R = ref()
+    bk, bs_, be_, nb = _side32(bkey, bs, be)
+    pk, ps_, pe_, npr = _side32(pkey, ps, pe)
+    n = R.ref_si_join(_p(bk), _p(bs_), _p(be_), nb, _p(pk), _p(ps_), _p(pe_), npr, None, None, C.c_uint64(0))
+    ob = np.empty(n, np.uint32); op = np.empty(n, np.uint32)
+    R.ref_si_join(_p(bk), _p(bs_), _p(be_), nb, _p(pk), _p(ps_), _p(pe_), npr, _p(ob), _p(op), C.c_uint64(n))
+    return ob, op
+
+
+def ref_count(bkey, bs, be, pkey, ps, pe):
+    R = ref()
+    bk, bs_, be_, nb = _side32(bkey, bs, be)
+    pk, ps_, pe_, npr = _side32(pkey, ps, pe)
+    out = np.zeros(len(pk), np.int64)
+    R.ref_si_count(_p(bk), _p(bs_), _p(be_), nb, _p(pk), _p(ps_), _p(pe_), npr, _p(out))
+    return out
