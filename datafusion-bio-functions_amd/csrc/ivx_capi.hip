@@ -1,0 +1,290 @@
+// ivx_capi.hip -- extern "C" entry points of libivx_hip.so (see include/ivx.h).
+// Host-side plumbing only: argument checks, staging of host buffers, stream and
+// scratch management.  All arithmetic happens in the HIP kernels.
+#include "ivx_internal.hpp"
+#include <cstring>
+#include <new>
+
+// ------------------------------------------------------------- ctx helpers
+
+ivx_status ivx_ctx::get_scratch(int slot, size_t bytes, void **out)
+{
+    ivx_buf &b = scratch[slot];
+    if (bytes < 256) bytes = 256;
+    if (b.cap < bytes) {
+        if (b.p) { (void)hipStreamSynchronize(stream); (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+        size_t want = bytes + bytes / 8;
+        hipError_t e = hipMalloc(&b.p, want);
+        if (e != hipSuccess) { want = bytes; e = hipMalloc(&b.p, want); }
+        if (e != hipSuccess) { b.p = nullptr; return fail_hip("hipMalloc(scratch)", e); }
+        b.cap = want;
+    }
+    *out = b.p;
+    return IVX_OK;
+}
+
+ivx_status ivx_ctx::get_pinned(int slot, size_t bytes, void **out)
+{
+    ivx_buf &b = pinned[slot];
+    if (bytes < 256) bytes = 256;
+    if (b.cap < bytes) {
+        if (b.p) { (void)hipStreamSynchronize(stream); (void)hipHostFree(b.p); b.p = nullptr; b.cap = 0; }
+        hipError_t e = hipHostMalloc(&b.p, bytes, hipHostMallocDefault);
+        if (e != hipSuccess) { b.p = nullptr; return fail_hip("hipHostMalloc", e); }
+        b.cap = bytes;
+    }
+    *out = b.p;
+    return IVX_OK;
+}
+
+ivx_status ivx_index_alloc(ivx_ctx *ctx, ivx_index *ix, size_t bytes, void **out)
+{
+    if (bytes < 256) bytes = 256;
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return ctx->fail_hip("hipMalloc(index)", e);
+    ix->allocs.push_back(p);
+    ix->bytes += bytes;
+    *out = p;
+    return IVX_OK;
+}
+
+namespace {
+
+// stage one input column: host -> device scratch, or pass the device pointer through
+template <typename T>
+ivx_status stage_in(ivx_ctx *ctx, int mem, int slot, const T *src, u64 n, const T **dev)
+{
+    if (src == nullptr) { *dev = nullptr; return IVX_OK; }
+    if (mem == IVX_MEM_DEVICE) { *dev = src; return IVX_OK; }
+    T *d;
+    IVX_TRY(ctx->get_scratch(slot, (size_t)n * sizeof(T), (void **)&d));
+    if (n) IVX_HIP(ctx, hipMemcpyAsync(d, src, (size_t)n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    *dev = d;
+    return IVX_OK;
+}
+
+// output column: device scratch (host mode) or the caller's device pointer
+template <typename T>
+ivx_status stage_out(ivx_ctx *ctx, int mem, int slot, T *dst, u64 n, T **dev)
+{
+    if (dst == nullptr) { *dev = nullptr; return IVX_OK; }
+    if (mem == IVX_MEM_DEVICE) { *dev = dst; return IVX_OK; }
+    T *d;
+    IVX_TRY(ctx->get_scratch(slot, (size_t)n * sizeof(T), (void **)&d));
+    *dev = d;
+    return IVX_OK;
+}
+
+template <typename T>
+ivx_status copy_out(ivx_ctx *ctx, int mem, T *dst, const T *dev, u64 n)
+{
+    if (mem == IVX_MEM_DEVICE || dst == nullptr || n == 0) return IVX_OK;
+    IVX_HIP(ctx, hipMemcpyAsync(dst, dev, (size_t)n * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+    return IVX_OK;
+}
+
+ivx_status read_scalar(ivx_ctx *ctx, int word, u64 *out)
+{
+    IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + word, ctx->d_scalars + word, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+    IVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *out = ctx->h_scalars[word];
+    return IVX_OK;
+}
+
+ivx_status check_probe_args(ivx_ctx *ctx, const ivx_index *ix, int kind, int mem, const void *s, const void *e, u64 n)
+{
+    if (!ctx) return IVX_ERR_INVALID;
+    if (!ix) return ctx->fail(IVX_ERR_INVALID, "null index");
+    if (ix->kind != kind) return ctx->fail(IVX_ERR_UNSUPPORTED, "index kind does not match this probe");
+    if (ix->device != ctx->device) return ctx->fail(IVX_ERR_INVALID, "index lives on another device");
+    if (mem != IVX_MEM_HOST && mem != IVX_MEM_DEVICE) return ctx->fail(IVX_ERR_INVALID, "bad mem");
+    if (n && (!s || !e)) return ctx->fail(IVX_ERR_INVALID, "null coordinate column");
+    if (n > 0xFFFFFFFFull) return ctx->fail(IVX_ERR_INVALID, "probe batch exceeds UInt32 index capacity");
+    IVX_HIP(ctx, hipSetDevice(ctx->device));
+    return IVX_OK;
+}
+
+struct KernelTimer {
+    ivx_ctx *c;
+    explicit KernelTimer(ivx_ctx *ctx) : c(ctx) { (void)hipEventRecord(c->ev0, c->stream); c->last_ms = -1.0; }
+    ~KernelTimer() { (void)hipEventRecord(c->ev1, c->stream); }
+};
+
+}  // namespace
+
+// ------------------------------------------------------------------ ctx
+
+extern "C" const char *ivx_version(void) { return "ivx-hip 0.1 (gfx950)"; }
+
+extern "C" ivx_status ivx_ctx_create(int device_ordinal, ivx_ctx **out)
+{
+    if (!out) return IVX_ERR_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return IVX_ERR_NO_DEVICE;   // no CPU fallback
+    if (device_ordinal < 0 || device_ordinal >= ndev) return IVX_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_ordinal) != hipSuccess) return IVX_ERR_NO_DEVICE;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return IVX_ERR_NO_DEVICE;       // code objects are gfx950 only
+    ivx_ctx *c = new (std::nothrow) ivx_ctx();
+    if (!c) return IVX_ERR_OOM;
+    c->device = device_ordinal;
+    bool ok = hipSetDevice(device_ordinal) == hipSuccess &&
+              hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
+              hipMalloc((void **)&c->d_scalars, 64 * sizeof(u64)) == hipSuccess &&
+              hipHostMalloc((void **)&c->h_scalars, 64 * sizeof(u64), hipHostMallocDefault) == hipSuccess;
+    if (!ok) { ivx_ctx_free(c); return IVX_ERR_HIP; }
+    c->stream = c->own_stream;
+    *out = c;
+    return IVX_OK;
+}
+
+extern "C" void ivx_ctx_free(ivx_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto &b : c->scratch) if (b.p) (void)hipFree(b.p);
+    for (auto &b : c->pinned) if (b.p) (void)hipHostFree(b.p);
+    if (c->d_scalars) (void)hipFree(c->d_scalars);
+    if (c->h_scalars) (void)hipHostFree(c->h_scalars);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+extern "C" const char *ivx_last_error(const ivx_ctx *c) { return c ? c->err.c_str() : "null ctx"; }
+
+extern "C" ivx_status ivx_ctx_set_stream(ivx_ctx *c, void *hip_stream)
+{
+    if (!c) return IVX_ERR_INVALID;
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return IVX_OK;
+}
+
+extern "C" ivx_status ivx_ctx_synchronize(ivx_ctx *c)
+{
+    if (!c) return IVX_ERR_INVALID;
+    IVX_HIP(c, hipStreamSynchronize(c->stream));
+    return IVX_OK;
+}
+
+extern "C" double ivx_ctx_last_kernel_ms(const ivx_ctx *cc)
+{
+    ivx_ctx *c = const_cast<ivx_ctx *>(cc);
+    if (!c) return -1.0;
+    if (c->last_ms < 0.0) {
+        float ms = 0.f;
+        if (hipEventSynchronize(c->ev1) == hipSuccess && hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->last_ms = ms;
+    }
+    return c->last_ms;
+}
+
+// ---------------------------------------------------------------- index
+
+ivx_status ivx_count_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32 *s, const i32 *e, u64 n);
+ivx_status ivx_coverage_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32 *s, const i32 *e, u64 n);
+ivx_status ivx_nearest_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32 *s, const i32 *e, u64 n);
+
+extern "C" ivx_status ivx_index_build(ivx_ctx *ctx, int kind, int mem, const uint32_t *key, const int32_t *start,
+                                      const int32_t *end, uint64_t n, uint32_t n_keys, ivx_index **out)
+{
+    if (!ctx) return IVX_ERR_INVALID;
+    if (!out) return ctx->fail(IVX_ERR_INVALID, "null out");
+    *out = nullptr;
+    if (kind < IVX_KIND_OVERLAP || kind > IVX_KIND_NEAREST) return ctx->fail(IVX_ERR_INVALID, "bad index kind");
+    if (mem != IVX_MEM_HOST && mem != IVX_MEM_DEVICE) return ctx->fail(IVX_ERR_INVALID, "bad mem");
+    if (n && (!start || !end)) return ctx->fail(IVX_ERR_INVALID, "null coordinate column");
+    if (n > 0xFFFFFFFEull) return ctx->fail(IVX_ERR_INVALID, "build side exceeds UInt32 index capacity");   // interval_join.rs:759
+    if (n_keys == 0) n_keys = 1;
+    if (!key) n_keys = 1;
+    IVX_HIP(ctx, hipSetDevice(ctx->device));
+    ivx_index *ix = new (std::nothrow) ivx_index();
+    if (!ix) return ctx->fail(IVX_ERR_OOM, "host allocation failed");
+    ix->kind = kind; ix->device = ctx->device; ix->n = n; ix->nkeys = n_keys;
+    const u32 *dk; const i32 *ds, *de;
+    ivx_status st = stage_in(ctx, mem, WS_IN_KEY, key, n, &dk);
+    if (st == IVX_OK) st = stage_in(ctx, mem, WS_IN_START, start, n, &ds);
+    if (st == IVX_OK) st = stage_in(ctx, mem, WS_IN_END, end, n, &de);
+    if (st == IVX_OK) {
+        KernelTimer t(ctx);
+        switch (kind) {
+        case IVX_KIND_OVERLAP: st = ivx_join_build(ctx, ix, dk, ds, de, n); break;
+        case IVX_KIND_COUNT: st = ivx_count_build(ctx, ix, dk, ds, de, n); break;
+        case IVX_KIND_COVERAGE: st = ivx_coverage_build(ctx, ix, dk, ds, de, n); break;
+        default: st = ivx_nearest_build(ctx, ix, dk, ds, de, n); break;
+        }
+    }
+    if (st == IVX_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = ctx->fail(IVX_ERR_HIP, "index build failed on device");
+    if (st != IVX_OK) { ivx_index_free(ix); return st; }
+    *out = ix;
+    return IVX_OK;
+}
+
+extern "C" void ivx_index_free(ivx_index *ix)
+{
+    if (!ix) return;
+    (void)hipSetDevice(ix->device);
+    for (void *p : ix->allocs) (void)hipFree(p);
+    delete ix;
+}
+
+extern "C" uint64_t ivx_index_rows(const ivx_index *ix) { return ix ? ix->n : 0; }
+extern "C" uint64_t ivx_index_device_bytes(const ivx_index *ix) { return ix ? ix->bytes : 0; }
+
+// ---------------------------------------------------------------- a3 probes
+
+static ivx_status overlap_common(ivx_ctx *ctx, const ivx_index *ix, int mem, int mode,
+                                 const u32 *key, const i32 *start, const i32 *end, u64 n,
+                                 u32 *per_row, u8 *exists, u32 *bidx, u32 *pidx, u64 cap, u64 *total)
+{
+    IVX_TRY(check_probe_args(ctx, ix, IVX_KIND_OVERLAP, mem, start, end, n));
+    const u32 *dk; const i32 *ds, *de;
+    IVX_TRY(stage_in(ctx, mem, WS_IN_KEY, key, n, &dk));
+    IVX_TRY(stage_in(ctx, mem, WS_IN_START, start, n, &ds));
+    IVX_TRY(stage_in(ctx, mem, WS_IN_END, end, n, &de));
+    u32 *d_row = nullptr, *d_b = nullptr, *d_p = nullptr; u8 *d_ex = nullptr;
+    IVX_TRY(stage_out(ctx, mem, WS_OUT_A, per_row, n, &d_row));
+    IVX_TRY(stage_out(ctx, mem, WS_OUT_B, exists, n, &d_ex));
+    IVX_TRY(stage_out(ctx, mem, WS_OUT_C, bidx, cap, &d_b));
+    IVX_TRY(stage_out(ctx, mem, WS_OUT_D, pidx, cap, &d_p));
+    IVX_HIP(ctx, hipMemsetAsync(ctx->d_scalars, 0, sizeof(u64), ctx->stream));
+    {
+        KernelTimer t(ctx);
+        IVX_TRY(ivx_join_probe(ctx, ix->jv, mode, dk, ds, de, n, d_row, d_ex, d_b, d_p, cap, ctx->d_scalars));
+    }
+    u64 tot = 0;
+    if (mode != JP_EXISTS) IVX_TRY(read_scalar(ctx, 0, &tot));
+    if (total) *total = tot;
+    if (mode == JP_FILL && tot > cap) return ctx->fail(IVX_ERR_CAPACITY, "pair buffers too small");
+    IVX_TRY(copy_out(ctx, mem, per_row, d_row, n));
+    IVX_TRY(copy_out(ctx, mem, exists, d_ex, n));
+    if (mode == JP_FILL) { IVX_TRY(copy_out(ctx, mem, bidx, d_b, tot)); IVX_TRY(copy_out(ctx, mem, pidx, d_p, tot)); }
+    if (mem == IVX_MEM_HOST) IVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return IVX_OK;
+}
+
+extern "C" ivx_status ivx_probe_overlap_count(ivx_ctx *ctx, const ivx_index *ix, int mem, const uint32_t *key,
+                                              const int32_t *start, const int32_t *end, uint64_t n,
+                                              uint32_t *per_row, uint64_t *total)
+{
+    return overlap_common(ctx, ix, mem, per_row ? JP_PER_ROW : JP_COUNT, key, start, end, n, per_row, nullptr, nullptr, nullptr, 0, total);
+}
+
+extern "C" ivx_status ivx_probe_overlap_fill(ivx_ctx *ctx, const ivx_index *ix, int mem, const uint32_t *key,
+                                             const int32_t *start, const int32_t *end, uint64_t n,
+                                             uint32_t *build_idx, uint32_t *probe_idx, uint64_t cap, uint64_t *written)
+{
+    if (ctx && cap && (!build_idx || !probe_idx)) return ctx->fail(IVX_ERR_INVALID, "null pair buffers");
+    return overlap_common(ctx, ix, mem, JP_FILL, key, start, end, n, nullptr, nullptr, build_idx, probe_idx, cap, written);
+}
+
+extern "C" ivx_status ivx_probe_exists(ivx_ctx *ctx, const ivx_index *ix, int mem, const uint32_t *key,
+                                       const int32_t *start, const int32_t *end, uint64_t n, uint8_t *exists)
+{
+    if (ctx && n && !exists) return ctx->fail(IVX_ERR_INVALID, "null exists buffer");
+    return overlap_common(ctx, ix, mem, JP_EXISTS, key, start, end, n, nullptr, exists, nullptr, nullptr, 0, nullptr);
+}

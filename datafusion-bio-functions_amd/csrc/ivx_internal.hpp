@@ -1,0 +1,140 @@
+// ivx_internal.hpp -- shared host/device definitions of libivx_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/ivx.h"
+
+typedef uint8_t u8;
+typedef uint32_t u32;
+typedef int32_t i32;
+typedef uint64_t u64;
+typedef int64_t i64;
+
+#define IVX_WAVE 64
+
+// ---------------------------------------------------------------- context
+struct ivx_buf { void *p = nullptr; size_t cap = 0; };
+
+enum { IVX_NSCRATCH = 24, IVX_NPIN = 4 };
+
+struct ivx_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double last_ms = 0.0;
+    std::string err;
+    ivx_buf scratch[IVX_NSCRATCH];      // grow-only device scratch, one slot per use
+    ivx_buf pinned[IVX_NPIN];           // grow-only pinned host staging
+    u64 *d_scalars = nullptr;           // 64 device words for counters / totals
+    u64 *h_scalars = nullptr;           // pinned mirror
+
+    ivx_status fail(ivx_status st, const std::string &msg) { err = msg; return st; }
+    ivx_status fail_hip(const char *what, hipError_t e)
+    {
+        err = std::string(what) + ": " + hipGetErrorString(e);
+        return e == hipErrorOutOfMemory ? IVX_ERR_OOM : IVX_ERR_HIP;
+    }
+    // device scratch of at least `bytes` in slot `slot` (contents undefined)
+    ivx_status get_scratch(int slot, size_t bytes, void **out);
+    ivx_status get_pinned(int slot, size_t bytes, void **out);
+};
+
+#define IVX_HIP(ctx, call)                                              \
+    do {                                                                \
+        hipError_t e__ = (call);                                        \
+        if (e__ != hipSuccess) return (ctx)->fail_hip(#call, e__);      \
+    } while (0)
+
+#define IVX_TRY(call)                                                   \
+    do {                                                                \
+        ivx_status s__ = (call);                                        \
+        if (s__ != IVX_OK) return s__;                                  \
+    } while (0)
+
+// scratch slot ids (one per concurrent use inside a call)
+enum {
+    WS_IN_KEY = 0, WS_IN_START, WS_IN_END, WS_IN2_KEY, WS_IN2_START, WS_IN2_END,
+    WS_OUT_A, WS_OUT_B, WS_OUT_C, WS_OUT_D,
+    WS_SCAN0, WS_SCAN1, WS_SCAN2,
+    WS_TMP0, WS_TMP1, WS_TMP2, WS_TMP3, WS_TMP4, WS_TMP5, WS_TMP6, WS_TMP7
+};
+
+// ---------------------------------------------------------------- indexes
+#define IVX_MAXL 8        // length-class levels of the binned overlap index
+#define IVX_LSTEP 4       // bin width grows 16x per level
+#define IVX_SH_MIN 4
+
+struct ivx_ent { i32 s, e; u32 row; };          // 12-byte AoS entry of the overlap index
+
+// header words written by the layout kernel (device resident, read by probes)
+enum { HDR_SH0 = 0, HDR_NLEV = 1, HDR_NBINS = 2, HDR_LEVCNT = 4 /* .. +IVX_MAXL */, HDR_WORDS = 16 };
+
+struct JoinIndexView {
+    const i32 *origin;      // [nkeys] smallest start of the key
+    const u32 *span;        // [nkeys] largest start - smallest start
+    const u32 *kcnt;        // [nkeys] build rows of the key
+    const u32 *lbase;       // [IVX_MAXL*nkeys] first bin of (level,key)
+    const u32 *binstart;    // [nbins+1] CSR offsets into ent
+    const ivx_ent *ent;     // [n] entries grouped by bin
+    const u32 *hdr;         // [HDR_WORDS]
+    u32 nkeys;
+};
+
+// sorted-rank grid over one int32 column grouped by key (count_overlaps,
+// coverage, nearest): rank(x) = cum[bin(x)] + #{v in bin : v <= x}
+struct RankGridView {
+    const i32 *origin;      // [nkeys] smallest value of the key
+    const u32 *span;        // [nkeys]
+    const u32 *kcnt;        // [nkeys]
+    const u32 *koff;        // [nkeys+1] rows before the key
+    const u32 *kbase;       // [nkeys] first bin of the key
+    const u32 *binstart;    // [nbins+1]
+    const i32 *val;         // [n] values grouped by (key,bin); sorted if `sorted`
+    const u32 *hdr;         // [0] = shift
+    u32 nkeys;
+};
+
+struct CoverageView {
+    RankGridView first, last;   // over merged nodes' first / last (both ascending per key)
+    const i64 *pw;              // [m+1] prefix sums of max(1, last-first)
+    const i32 *nfirst, *nlast;  // [m] merged nodes in order
+};
+
+struct NearestView {
+    RankGridView by_start, by_end, pmax;   // rank grids over start / end / prefix-max-end orders
+    const i32 *s_start, *s_end; const u32 *s_row;   // by_start order (start,end,row)
+    const i32 *e_start, *e_end; const u32 *e_row;   // by_end order (end,start,row)
+    const i32 *pmaxv;                               // prefix max of end in by_start order
+    JoinIndexView ov;                               // overlap index for k>1 include_overlaps
+};
+
+struct ivx_index {
+    int kind = 0;
+    int device = 0;
+    u64 n = 0;
+    u32 nkeys = 0;
+    size_t bytes = 0;
+    std::vector<void *> allocs;
+    JoinIndexView jv{};
+    RankGridView gs{}, ge{};
+    CoverageView cv{};
+    NearestView nv{};
+    int flags = 0;
+};
+
+// ---------------------------------------------------------------- internal API
+// scan.hip
+ivx_status ivx_scan_exclusive_u32(ivx_ctx *ctx, u32 *data, u64 n);      // in place, uses WS_SCAN*
+ivx_status ivx_scan_exclusive_u64(ivx_ctx *ctx, u64 *data, u64 n);
+
+// join.hip
+ivx_status ivx_join_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32 *s, const i32 *e, u64 n);
+ivx_status ivx_join_probe(ivx_ctx *ctx, const JoinIndexView &jv, int mode,
+                          const u32 *key, const i32 *s, const i32 *e, u64 n,
+                          u32 *per_row, u8 *exists, u32 *ob, u32 *op, u64 cap, u64 *d_cursor);
+enum { JP_COUNT = 0, JP_PER_ROW = 1, JP_EXISTS = 2, JP_FILL = 3 };
+
+ivx_status ivx_index_alloc(ivx_ctx *ctx, ivx_index *ix, size_t bytes, void **out);

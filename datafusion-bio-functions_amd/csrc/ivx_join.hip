@@ -1,0 +1,344 @@
+// ivx_join.hip -- binned overlap index (build) and the overlap-pairs probe.
+//
+// Replaces, for Algorithm::Coitrees, the reference's
+//   build : update_hashmap + COITree::new per key   (interval_join.rs:745-763, :903-931)
+//   probe : IntervalJoinAlgorithm::get + RLE expand (interval_join.rs:849-862, :1614-1653)
+//
+// Index layout in HBM (all integer/index work, HBM/L2-latency bound, no MFMA):
+//   Build rows are classed by length into levels l = 0..L-1; level l holds the
+//   rows with (end-start) < 2^(sh0 + 4l) and is cut into bins 2^(sh0+4l) wide
+//   per key, so a row starts at most one bin before the bin its end falls in.
+//   All (level,key,bin) cells are laid out in one CSR: binstart[] -> ent[]
+//   (12-byte {start,end,row} entries grouped by cell by a counting sort with
+//   atomics; order inside a cell is arbitrary -- the reference pins only the
+//   pair multiset).  A probe row [qs,qe] reads, per non-empty level, the two
+//   binstart words bracketing cells [bin(qs - 2^sh + 1) .. bin(qe)] and tests
+//   the entries between them with the literal predicate
+//   start <= qe && end >= qs.
+//   sh0 is picked on the device from the per-key coordinate spans so that the
+//   finest level has at most ~2 cells per build row.
+#include "ivx_device.hpp"
+
+namespace {
+
+constexpr int BT = 256;              // build kernels
+constexpr u32 KEYS_IN_LDS = 2048;    // per-key min/max privatised in LDS up to this many keys
+
+// ------------------------------------------------------------------ build
+
+__global__ void k_init_keystats(i32 *kmin, i32 *kmax, u32 *kcnt, u32 nkeys, u32 *hdr)
+{
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nkeys) { kmin[i] = INT32_MAX; kmax[i] = INT32_MIN; kcnt[i] = 0; }
+    if (i < HDR_WORDS) hdr[i] = 0;
+}
+
+// per-key min / max of `v` and row counts; key ids >= nkeys set the error flag
+__global__ __launch_bounds__(BT) void k_keystats(const u32 *__restrict__ key, const i32 *__restrict__ v, u64 n,
+                                                 u32 nkeys, i32 *kmin, i32 *kmax, u32 *kcnt, u32 *errflag)
+{
+    extern __shared__ i32 sh[];
+    const bool priv = nkeys <= KEYS_IN_LDS;
+    i32 *smin = sh, *smax = sh + nkeys;
+    u32 *scnt = (u32 *)(sh + 2 * nkeys);
+    if (priv) {
+        for (u32 k = threadIdx.x; k < nkeys; k += BT) { smin[k] = INT32_MAX; smax[k] = INT32_MIN; scnt[k] = 0; }
+        __syncthreads();
+    }
+    for (u64 i = (u64)blockIdx.x * BT + threadIdx.x; i < n; i += (u64)gridDim.x * BT) {
+        u32 k = key ? key[i] : 0u;
+        if (k >= nkeys) { *errflag = 1; continue; }
+        i32 x = v[i];
+        if (priv) { atomicMin(&smin[k], x); atomicMax(&smax[k], x); atomicAdd(&scnt[k], 1u); }
+        else { atomicMin(&kmin[k], x); atomicMax(&kmax[k], x); atomicAdd(&kcnt[k], 1u); }
+    }
+    if (priv) {
+        __syncthreads();
+        for (u32 k = threadIdx.x; k < nkeys; k += BT)
+            if (scnt[k]) { atomicMin(&kmin[k], smin[k]); atomicMax(&kmax[k], smax[k]); atomicAdd(&kcnt[k], scnt[k]); }
+    }
+}
+
+__device__ __forceinline__ u32 cells_of(u32 cnt, u32 span, u32 sh) { return cnt ? (sh >= 32 ? 1u : (span >> sh) + 1u) : 0u; }
+
+// One workgroup: turn per-key (min,max,count) into origin/span, pick sh0 and
+// lay out the (level,key) cell ranges.  hdr: sh0, #levels, #cells.
+__global__ __launch_bounds__(1024) void k_join_layout(const i32 *kmin, const i32 *kmax, const u32 *kcnt, u32 nkeys, u64 n,
+                                                      i32 *origin, u32 *span, u32 *lbase, u32 *hdr, u64 maxcells)
+{
+    __shared__ u64 red[1024 / IVX_WAVE + 1];
+    __shared__ u32 s_sh0;
+    const u32 t = threadIdx.x;
+    for (u32 k = t; k < nkeys; k += 1024) {
+        u32 c = kcnt[k];
+        origin[k] = c ? kmin[k] : 0;
+        span[k] = c ? (u32)((i64)kmax[k] - (i64)kmin[k]) : 0u;
+    }
+    __syncthreads();
+    // smallest shift whose finest level fits the budget (monotone in sh)
+    const u64 budget0 = 2 * n + nkeys;
+    u32 lo = IVX_SH_MIN, hi = 31;
+    while (lo < hi) {
+        u32 mid = (lo + hi) / 2;
+        u64 s = 0;
+        for (u32 k = t; k < nkeys; k += 1024) s += cells_of(kcnt[k], span[k], mid);
+        u64 tot = block_sum<u64, 1024>(s, red);
+        if (tot <= budget0) hi = mid; else lo = mid + 1;
+    }
+    if (t == 0) s_sh0 = lo;
+    __syncthreads();
+    const u32 sh0 = s_sh0;
+    u32 nlev = 0;
+    for (u32 l = 0; l < IVX_MAXL; l++) { nlev = l + 1; if (sh0 + IVX_LSTEP * l >= 32) break; }
+    // exclusive prefix over (level, key) cells
+    u64 run = 0;
+    for (u32 l = 0; l < nlev; l++) {
+        const u32 sh = sh0 + IVX_LSTEP * l;
+        for (u32 k0 = 0; k0 < nkeys; k0 += 1024) {
+            u32 k = k0 + t;
+            u64 c = k < nkeys ? cells_of(kcnt[k], span[k], sh) : 0u;
+            u64 tot;
+            u64 ex = block_excl_scan<u64, 1024>(c, red, &tot);
+            if (k < nkeys) lbase[(u64)l * nkeys + k] = (u32)(run + ex);
+            run += tot;
+        }
+    }
+    if (t == 0) {
+        hdr[HDR_SH0] = sh0;
+        hdr[HDR_NLEV] = nlev;
+        hdr[HDR_NBINS] = (u32)(run <= maxcells ? run : maxcells);   // never exceeds the budget by construction
+    }
+}
+
+__device__ __forceinline__ u32 level_of(i32 s, i32 e, u32 sh0, u32 nlev)
+{
+    i64 len = (i64)e - (i64)s;
+    if (len <= 0) return 0;
+    u32 bits = 64 - __clzll((u64)len);                 // len < 2^bits
+    u32 l = bits <= sh0 ? 0 : (bits - sh0 + IVX_LSTEP - 1) / IVX_LSTEP;
+    return l < nlev ? l : nlev - 1;                    // top level has sh >= 32 >= bits
+}
+
+__device__ __forceinline__ u32 cell_of(const i32 *origin, const u32 *lbase, u32 nkeys, u32 k, i32 s, u32 l, u32 sh0)
+{
+    const u32 sh = sh0 + IVX_LSTEP * l;
+    const u32 off = (u32)((i64)s - (i64)origin[k]);
+    return lbase[(u64)l * nkeys + k] + (sh >= 32 ? 0u : off >> sh);
+}
+
+__global__ __launch_bounds__(BT) void k_join_count(const u32 *__restrict__ key, const i32 *__restrict__ s,
+                                                   const i32 *__restrict__ e, u64 n, u32 nkeys,
+                                                   const i32 *origin, const u32 *lbase, u32 *hdr, u32 *bincnt)
+{
+    __shared__ u32 levcnt[IVX_MAXL];
+    if (threadIdx.x < IVX_MAXL) levcnt[threadIdx.x] = 0;
+    __syncthreads();
+    const u32 sh0 = hdr[HDR_SH0], nlev = hdr[HDR_NLEV];
+    for (u64 i = (u64)blockIdx.x * BT + threadIdx.x; i < n; i += (u64)gridDim.x * BT) {
+        u32 k = key ? key[i] : 0u;
+        if (k >= nkeys) continue;
+        i32 si = s[i], ei = e[i];
+        u32 l = level_of(si, ei, sh0, nlev);
+        atomicAdd(&bincnt[cell_of(origin, lbase, nkeys, k, si, l, sh0)], 1u);
+        atomicAdd(&levcnt[l], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < IVX_MAXL && levcnt[threadIdx.x]) atomicAdd(&hdr[HDR_LEVCNT + threadIdx.x], levcnt[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(BT) void k_join_scatter(const u32 *__restrict__ key, const i32 *__restrict__ s,
+                                                     const i32 *__restrict__ e, u64 n, u32 nkeys,
+                                                     const i32 *origin, const u32 *lbase, const u32 *hdr,
+                                                     const u32 *binstart, u32 *cursor, ivx_ent *ent)
+{
+    const u32 sh0 = hdr[HDR_SH0], nlev = hdr[HDR_NLEV];
+    for (u64 i = (u64)blockIdx.x * BT + threadIdx.x; i < n; i += (u64)gridDim.x * BT) {
+        u32 k = key ? key[i] : 0u;
+        if (k >= nkeys) continue;
+        i32 si = s[i], ei = e[i];
+        u32 l = level_of(si, ei, sh0, nlev);
+        u32 c = cell_of(origin, lbase, nkeys, k, si, l, sh0);
+        u32 at = binstart[c] + atomicAdd(&cursor[c], 1u);
+        ivx_ent x; x.s = si; x.e = ei; x.row = (u32)i;
+        ent[at] = x;
+    }
+}
+
+// ------------------------------------------------------------------ probe
+
+constexpr int PT = 256;     // probe workgroup
+constexpr int PI = 4;       // probe rows per thread per tile
+constexpr int PTILE = PT * PI;
+
+// visit every build row of key k overlapping [qs,qe]
+template <class F>
+__device__ __forceinline__ void walk(const JoinIndexView &ix, u32 sh0, u32 nlev, u32 k, i32 qs, i32 qe, F &&f)
+{
+    if (k >= ix.nkeys) return;
+    if (ix.kcnt[k] == 0) return;
+    const i32 origin = ix.origin[k];
+    const u32 span = ix.span[k];
+    const i64 hi64 = (i64)qe - (i64)origin;
+    if (hi64 < 0) return;                                 // every start of this key is > qe
+    for (u32 l = 0; l < nlev; l++) {
+        if (ix.hdr[HDR_LEVCNT + l] == 0) continue;        // wave-uniform
+        const u32 sh = sh0 + IVX_LSTEP * l;
+        u32 blo = 0, bhi = 0;
+        if (sh < 32) {
+            const u32 ncell = (span >> sh) + 1u;
+            const i64 lo64 = (i64)qs - ((i64)1 << sh) + 1 - (i64)origin;   // starts below this cannot reach qs
+            const i64 bl = lo64 <= 0 ? 0 : (lo64 >> sh);
+            const i64 bh = hi64 >> sh;
+            if (bl >= (i64)ncell) continue;
+            blo = (u32)bl;
+            bhi = bh >= (i64)ncell ? ncell - 1u : (u32)bh;
+            if (blo > bhi) continue;
+        }
+        const u32 base = ix.lbase[(u64)l * ix.nkeys + k];
+        const u32 a = ix.binstart[base + blo], b = ix.binstart[base + bhi + 1];
+        for (u32 j = a; j < b; j++) {
+            const ivx_ent x = ix.ent[j];
+            if (x.s <= qe && x.e >= qs) f(x.row);
+        }
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(PT) void k_probe_overlap(JoinIndexView ix, const u32 *__restrict__ pkey,
+                                                      const i32 *__restrict__ ps, const i32 *__restrict__ pe, u64 n,
+                                                      u32 *__restrict__ per_row, u8 *__restrict__ exists,
+                                                      u32 *__restrict__ ob, u32 *__restrict__ op, u64 cap,
+                                                      unsigned long long *cursor)
+{
+    __shared__ u32 lds[PT / IVX_WAVE + 1];
+    __shared__ unsigned long long s_base;
+    const u32 sh0 = ix.hdr[HDR_SH0], nlev = ix.hdr[HDR_NLEV];
+    const u64 ntiles = (n + PTILE - 1) / PTILE;
+    u64 acc = 0;                                           // MODE COUNT / PER_ROW: pairs seen by this thread
+    for (u64 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        u32 cnt[PI], st0[PI], st1[PI];
+        u32 tsum = 0;
+#pragma unroll
+        for (int it = 0; it < PI; it++) {
+            const u64 i = tile * PTILE + (u64)it * PT + threadIdx.x;
+            u32 m = 0, a0 = 0, a1 = 0;
+            if (i < n) {
+                const u32 k = pkey ? pkey[i] : 0u;
+                const i32 qs = ps[i], qe = pe[i];
+                walk(ix, sh0, nlev, k, qs, qe, [&](u32 row) {
+                    if (m == 0) a0 = row; else if (m == 1) a1 = row;
+                    m++;
+                });
+                if (MODE == JP_PER_ROW) per_row[i] = m;
+                if (MODE == JP_EXISTS) exists[i] = m != 0;
+            }
+            cnt[it] = m; st0[it] = a0; st1[it] = a1;
+            tsum += m;
+        }
+        if (MODE != JP_FILL) { acc += tsum; continue; }
+        // ---- wavefront + workgroup prefix sum -> one cursor bump per tile
+        u32 total;
+        const u32 ex = block_excl_scan<u32, PT>(tsum, lds, &total);
+        if (threadIdx.x == 0) s_base = total ? atomicAdd(cursor, (unsigned long long)total) : 0ull;
+        __syncthreads();
+        const u64 base = s_base;
+        if (total && base + total <= cap) {
+            u64 at = base + ex;
+#pragma unroll
+            for (int it = 0; it < PI; it++) {
+                const u32 m = cnt[it];
+                if (m == 0) continue;
+                const u64 i = tile * PTILE + (u64)it * PT + threadIdx.x;
+                if (m <= 2) {
+                    ob[at] = st0[it]; op[at] = (u32)i;
+                    if (m == 2) { ob[at + 1] = st1[it]; op[at + 1] = (u32)i; }
+                    at += m;
+                } else {
+                    const u32 k = pkey ? pkey[i] : 0u;
+                    walk(ix, sh0, nlev, k, ps[i], pe[i], [&](u32 row) { ob[at] = row; op[at] = (u32)i; at++; });
+                }
+            }
+        }
+        __syncthreads();                                   // s_base is rewritten next tile
+    }
+    if (MODE == JP_COUNT || MODE == JP_PER_ROW) {
+        __shared__ u64 lds64[PT / IVX_WAVE];
+        u64 tot = block_sum<u64, PT>(acc, lds64);
+        if (threadIdx.x == 0 && tot) atomicAdd(cursor, (unsigned long long)tot);
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+
+ivx_status ivx_join_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32 *s, const i32 *e, u64 n)
+{
+    const u32 nkeys = ix->nkeys;
+    hipStream_t st = ctx->stream;
+    const u64 maxcells = 2 * n + n / 4 + (u64)IVX_MAXL * nkeys + 64;
+    if (maxcells + 1 >= 0xFFFFFFFFull) return ctx->fail(IVX_ERR_INVALID, "build side too large for 32-bit cell ids");
+
+    i32 *origin; u32 *span, *kcnt, *lbase, *binstart, *hdr; ivx_ent *ent;
+    IVX_TRY(ivx_index_alloc(ctx, ix, nkeys * sizeof(i32), (void **)&origin));
+    IVX_TRY(ivx_index_alloc(ctx, ix, nkeys * sizeof(u32), (void **)&span));
+    IVX_TRY(ivx_index_alloc(ctx, ix, nkeys * sizeof(u32), (void **)&kcnt));
+    IVX_TRY(ivx_index_alloc(ctx, ix, (size_t)IVX_MAXL * nkeys * sizeof(u32), (void **)&lbase));
+    IVX_TRY(ivx_index_alloc(ctx, ix, (maxcells + 1) * sizeof(u32), (void **)&binstart));
+    IVX_TRY(ivx_index_alloc(ctx, ix, HDR_WORDS * sizeof(u32), (void **)&hdr));
+    IVX_TRY(ivx_index_alloc(ctx, ix, (n ? n : 1) * sizeof(ivx_ent), (void **)&ent));
+
+    i32 *kmin, *kmax; u32 *cursor, *errflag;
+    IVX_TRY(ctx->get_scratch(WS_TMP0, nkeys * sizeof(i32), (void **)&kmin));
+    IVX_TRY(ctx->get_scratch(WS_TMP1, nkeys * sizeof(i32), (void **)&kmax));
+    IVX_TRY(ctx->get_scratch(WS_TMP2, (maxcells + 1) * sizeof(u32), (void **)&cursor));
+    errflag = (u32 *)(ctx->d_scalars + 8);
+
+    IVX_HIP(ctx, hipMemsetAsync(errflag, 0, sizeof(u32), st));
+    IVX_HIP(ctx, hipMemsetAsync(binstart, 0, (maxcells + 1) * sizeof(u32), st));
+    IVX_HIP(ctx, hipMemsetAsync(cursor, 0, (maxcells + 1) * sizeof(u32), st));
+    const u32 ginit = ((nkeys > HDR_WORDS ? nkeys : HDR_WORDS) + BT - 1) / BT;
+    hipLaunchKernelGGL(k_init_keystats, dim3(ginit), dim3(BT), 0, st, kmin, kmax, kcnt, nkeys, hdr);
+    const u32 grid = ivx_stream_grid(n, BT * 8, 1024);
+    const size_t shm = nkeys <= KEYS_IN_LDS ? (size_t)nkeys * 12 : 0;
+    hipLaunchKernelGGL(k_keystats, dim3(grid), dim3(BT), shm, st, key, s, n, nkeys, kmin, kmax, kcnt, errflag);
+    hipLaunchKernelGGL(k_join_layout, dim3(1), dim3(1024), 0, st, kmin, kmax, kcnt, nkeys, n, origin, span, lbase, hdr, maxcells);
+    hipLaunchKernelGGL(k_join_count, dim3(grid), dim3(BT), 0, st, key, s, e, n, nkeys, origin, lbase, hdr, binstart);
+    IVX_TRY(ivx_scan_exclusive_u32(ctx, binstart, maxcells + 1));
+    hipLaunchKernelGGL(k_join_scatter, dim3(grid), dim3(BT), 0, st, key, s, e, n, nkeys, origin, lbase, hdr, binstart, cursor, ent);
+    IVX_HIP(ctx, hipGetLastError());
+
+    // key ids are validated on the device; surface the flag (one small D2H)
+    IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 8, errflag, sizeof(u32), hipMemcpyDeviceToHost, st));
+    IVX_HIP(ctx, hipStreamSynchronize(st));
+    if (*(u32 *)(ctx->h_scalars + 8)) return ctx->fail(IVX_ERR_INVALID, "build key id >= n_keys");
+
+    ix->jv.origin = origin; ix->jv.span = span; ix->jv.kcnt = kcnt; ix->jv.lbase = lbase;
+    ix->jv.binstart = binstart; ix->jv.ent = ent; ix->jv.hdr = hdr; ix->jv.nkeys = nkeys;
+    return IVX_OK;
+}
+
+ivx_status ivx_join_probe(ivx_ctx *ctx, const JoinIndexView &jv, int mode,
+                          const u32 *key, const i32 *s, const i32 *e, u64 n,
+                          u32 *per_row, u8 *exists, u32 *ob, u32 *op, u64 cap, u64 *d_cursor)
+{
+    if (n == 0) return IVX_OK;
+    const u32 grid = ivx_stream_grid(n, PTILE, 256 * 8);
+    unsigned long long *cur = (unsigned long long *)d_cursor;
+    switch (mode) {
+    case JP_COUNT:
+        hipLaunchKernelGGL(k_probe_overlap<JP_COUNT>, dim3(grid), dim3(PT), 0, ctx->stream, jv, key, s, e, n, per_row, exists, ob, op, cap, cur);
+        break;
+    case JP_PER_ROW:
+        hipLaunchKernelGGL(k_probe_overlap<JP_PER_ROW>, dim3(grid), dim3(PT), 0, ctx->stream, jv, key, s, e, n, per_row, exists, ob, op, cap, cur);
+        break;
+    case JP_EXISTS:
+        hipLaunchKernelGGL(k_probe_overlap<JP_EXISTS>, dim3(grid), dim3(PT), 0, ctx->stream, jv, key, s, e, n, per_row, exists, ob, op, cap, cur);
+        break;
+    default:
+        hipLaunchKernelGGL(k_probe_overlap<JP_FILL>, dim3(grid), dim3(PT), 0, ctx->stream, jv, key, s, e, n, per_row, exists, ob, op, cap, cur);
+        break;
+    }
+    IVX_HIP(ctx, hipGetLastError());
+    return IVX_OK;
+}

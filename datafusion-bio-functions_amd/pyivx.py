@@ -1,0 +1,298 @@
+"""ctypes binding of libivx_hip.so (include/ivx.h) for tests and bench.py.
+
+Plumbing only: numpy arrays go through the IVX_MEM_HOST entry points, torch CUDA
+tensors through IVX_MEM_DEVICE with their data_ptr().  There is no fallback of
+any kind: if the HIP library is missing or no gfx950 device is usable this
+module raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libivx_hip.so")
+
+MEM_HOST, MEM_DEVICE = 0, 1
+KIND_OVERLAP, KIND_COUNT, KIND_COVERAGE, KIND_NEAREST = 0, 1, 2, 3
+OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_CAPACITY, ERR_UNSUPPORTED = range(7)
+NULL_IDX = 0xFFFFFFFF
+
+# every symbol include/ivx.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "ivx_ctx_create", "ivx_ctx_free", "ivx_last_error", "ivx_ctx_set_stream", "ivx_ctx_synchronize",
+    "ivx_ctx_last_kernel_ms", "ivx_version", "ivx_index_build", "ivx_index_free", "ivx_index_rows",
+    "ivx_index_device_bytes", "ivx_probe_overlap_count", "ivx_probe_overlap_fill", "ivx_probe_exists",
+    "ivx_probe_count", "ivx_probe_coverage", "ivx_probe_nearest", "ivx_merge", "ivx_subtract",
+]
+
+
+class IvxError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"ivx status {status}: {msg}")
+        self.status = status
+
+
+_lib = None
+
+
+def _preload_hip_runtime():
+    """PyTorch-ROCm bundles its own libamdhip64.so (same SONAME as /opt/rocm's).  Two HIP
+    runtimes in one process do not share device state, so when torch is installed make its
+    copy the one that is resident before libivx_hip.so binds to libamdhip64.so.7."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec and spec.origin:
+        p = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(p):
+            C.CDLL(p, mode=C.RTLD_GLOBAL)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise IvxError(ERR_NO_DEVICE, f"{LIB_PATH} is missing: run __graft_entry__.build() (no CPU fallback exists)")
+        _preload_hip_runtime()
+        L = C.CDLL(LIB_PATH)
+        L.ivx_last_error.restype = C.c_char_p
+        L.ivx_version.restype = C.c_char_p
+        L.ivx_ctx_last_kernel_ms.restype = C.c_double
+        L.ivx_index_rows.restype = C.c_uint64
+        L.ivx_index_device_bytes.restype = C.c_uint64
+        _lib = L
+    return _lib
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    if _is_torch(x):
+        return C.c_void_p(x.data_ptr())
+    return x.ctypes.data_as(C.c_void_p)
+
+
+def _mem_of(*arrs):
+    kinds = {_is_torch(a) for a in arrs if a is not None}
+    if len(kinds) > 1:
+        raise ValueError("mix of host and device buffers in one call")
+    return MEM_DEVICE if kinds == {True} else MEM_HOST
+
+
+def _np(a, dt):
+    return None if a is None else np.ascontiguousarray(a, dtype=dt)
+
+
+def _cols(key, s, e, dt):
+    """normalise one (key,start,end) side; returns (key,start,end,n,mem)"""
+    if _is_torch(s):
+        assert s.is_contiguous() and e.is_contiguous() and (key is None or key.is_contiguous())
+        return key, s, e, int(s.numel()), MEM_DEVICE
+    key, s, e = _np(key, np.uint32), _np(s, dt), _np(e, dt)
+    return key, s, e, len(s), MEM_HOST
+
+
+class Index:
+    def __init__(self, ctx, handle, kind):
+        self.ctx, self.h, self.kind = ctx, handle, kind
+
+    @property
+    def rows(self):
+        return lib().ivx_index_rows(self.h)
+
+    @property
+    def device_bytes(self):
+        return lib().ivx_index_device_bytes(self.h)
+
+    def free(self):
+        if self.h:
+            lib().ivx_index_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Ctx:
+    def __init__(self, device=0):
+        self.h = C.c_void_p()
+        st = lib().ivx_ctx_create(C.c_int(device), C.byref(self.h))
+        if st != OK:
+            self.h = None
+            raise IvxError(st, "ivx_ctx_create failed (no usable gfx950 device; there is no CPU fallback)")
+
+    def close(self):
+        if self.h:
+            lib().ivx_ctx_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, st):
+        if st != OK:
+            raise IvxError(st, lib().ivx_last_error(self.h).decode())
+
+    def set_stream(self, stream_ptr):
+        self._chk(lib().ivx_ctx_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def synchronize(self):
+        self._chk(lib().ivx_ctx_synchronize(self.h))
+
+    def last_kernel_ms(self):
+        return lib().ivx_ctx_last_kernel_ms(self.h)
+
+    # ---- index ----
+    def build(self, kind, key, start, end, n_keys=None):
+        key, s, e, n, mem = _cols(key, start, end, np.int32)
+        if n_keys is None:
+            n_keys = 1 if key is None else (int(key.max()) + 1 if n else 1)
+        h = C.c_void_p()
+        self._chk(lib().ivx_index_build(self.h, C.c_int(kind), C.c_int(mem), _ptr(key), _ptr(s), _ptr(e),
+                                         C.c_uint64(n), C.c_uint32(n_keys), C.byref(h)))
+        return Index(self, h, kind)
+
+    # ---- a3 ----
+    def overlap_count(self, ix, key, start, end, per_row=False):
+        key, s, e, n, mem = _cols(key, start, end, np.int32)
+        total = C.c_uint64(0)
+        pr = None
+        if per_row:
+            if mem == MEM_DEVICE:
+                import torch
+                pr = torch.empty(n, dtype=torch.int32, device=s.device)
+            else:
+                pr = np.empty(n, np.uint32)
+        self._chk(lib().ivx_probe_overlap_count(self.h, ix.h, C.c_int(mem), _ptr(key), _ptr(s), _ptr(e),
+                                                 C.c_uint64(n), _ptr(pr), C.byref(total)))
+        return (total.value, pr) if per_row else total.value
+
+    def overlap_fill(self, ix, key, start, end, cap=None, out=None):
+        """-> (build_idx, probe_idx) of length `written`.  Host arrays: cap defaults to a count pass."""
+        key, s, e, n, mem = _cols(key, start, end, np.int32)
+        if out is not None:
+            ob, op = out
+            cap = int(ob.numel()) if _is_torch(ob) else len(ob)
+        else:
+            if cap is None:
+                cap = self.overlap_count(ix, key, s, e)
+            if mem == MEM_DEVICE:
+                import torch
+                ob = torch.empty(max(cap, 1), dtype=torch.int32, device=s.device)
+                op = torch.empty(max(cap, 1), dtype=torch.int32, device=s.device)
+            else:
+                ob = np.empty(max(cap, 1), np.uint32); op = np.empty(max(cap, 1), np.uint32)
+        written = C.c_uint64(0)
+        st = lib().ivx_probe_overlap_fill(self.h, ix.h, C.c_int(mem), _ptr(key), _ptr(s), _ptr(e), C.c_uint64(n),
+                                          _ptr(ob), _ptr(op), C.c_uint64(cap), C.byref(written))
+        if st == ERR_CAPACITY:
+            raise IvxError(st, f"need {written.value} pairs, cap {cap}")
+        self._chk(st)
+        w = written.value
+        return ob[:w], op[:w]
+
+    def exists(self, ix, key, start, end):
+        key, s, e, n, mem = _cols(key, start, end, np.int32)
+        if mem == MEM_DEVICE:
+            import torch
+            out = torch.empty(n, dtype=torch.uint8, device=s.device)
+        else:
+            out = np.empty(n, np.uint8)
+        self._chk(lib().ivx_probe_exists(self.h, ix.h, C.c_int(mem), _ptr(key), _ptr(s), _ptr(e), C.c_uint64(n), _ptr(out)))
+        return out
+
+    # ---- a4 / a5 ----
+    def _per_row_i64(self, fn, ix, key, start, end, strict):
+        key, s, e, n, mem = _cols(key, start, end, np.int32)
+        if mem == MEM_DEVICE:
+            import torch
+            out = torch.empty(n, dtype=torch.int64, device=s.device)
+        else:
+            out = np.empty(n, np.int64)
+        self._chk(fn(self.h, ix.h, C.c_int(mem), _ptr(key), _ptr(s), _ptr(e), C.c_uint64(n), C.c_int(int(strict)), _ptr(out)))
+        return out
+
+    def count_overlaps(self, ix, key, start, end, strict=False):
+        return self._per_row_i64(lib().ivx_probe_count, ix, key, start, end, strict)
+
+    def coverage(self, ix, key, start, end, strict=False):
+        return self._per_row_i64(lib().ivx_probe_coverage, ix, key, start, end, strict)
+
+    # ---- a6 ----
+    def nearest(self, ix, key, start, end, k=1, overlap=True, strict=False, distance=True):
+        key, s, e, n, mem = _cols(key, start, end, np.int32)
+        cap = n * max(int(k), 1)
+        if mem == MEM_DEVICE:
+            import torch
+            ob = torch.empty(max(cap, 1), dtype=torch.int32, device=s.device)
+            op = torch.empty(max(cap, 1), dtype=torch.int32, device=s.device)
+            od = torch.empty(max(cap, 1), dtype=torch.int64, device=s.device) if distance else None
+        else:
+            ob = np.empty(max(cap, 1), np.uint32); op = np.empty(max(cap, 1), np.uint32)
+            od = np.empty(max(cap, 1), np.int64) if distance else None
+        rows = C.c_uint64(0)
+        self._chk(lib().ivx_probe_nearest(self.h, ix.h, C.c_int(mem), _ptr(key), _ptr(s), _ptr(e), C.c_uint64(n),
+                                           C.c_int(int(strict)), C.c_uint32(int(k)), C.c_int(int(overlap)),
+                                           _ptr(ob), _ptr(op), _ptr(od), C.c_uint64(cap), C.byref(rows)))
+        r = rows.value
+        return ob[:r], op[:r], (od[:r] if distance else None)
+
+    # ---- a7..a9 ----
+    def merge(self, key, start, end, n_keys=None, min_dist=0, strict=False):
+        key, s, e, n, mem = _cols(key, start, end, np.int64)
+        if n_keys is None:
+            n_keys = 1 if key is None else (int(key.max()) + 1 if n else 1)
+        cap = max(n, 1)
+        if mem == MEM_DEVICE:
+            import torch
+            dev = s.device
+            ok = torch.empty(cap, dtype=torch.int32, device=dev); os_ = torch.empty(cap, dtype=torch.int64, device=dev)
+            oe = torch.empty(cap, dtype=torch.int64, device=dev); on = torch.empty(cap, dtype=torch.int64, device=dev)
+        else:
+            ok = np.empty(cap, np.uint32); os_ = np.empty(cap, np.int64); oe = np.empty(cap, np.int64); on = np.empty(cap, np.int64)
+        m = C.c_uint64(0)
+        self._chk(lib().ivx_merge(self.h, C.c_int(mem), _ptr(key), _ptr(s), _ptr(e), C.c_uint64(n), C.c_uint32(n_keys),
+                                   C.c_int64(int(min_dist)), C.c_int(int(strict)), _ptr(ok), _ptr(os_), _ptr(oe), _ptr(on),
+                                   C.c_uint64(cap), C.byref(m)))
+        m = m.value
+        return ok[:m], os_[:m], oe[:m], on[:m]
+
+    def subtract(self, lkey, ls, le, rkey, rs, re, n_keys=None, strict=False):
+        lkey, ls, le, nl, mem = _cols(lkey, ls, le, np.int64)
+        rkey, rs, re, nr, mem2 = _cols(rkey, rs, re, np.int64)
+        assert mem == mem2
+        if n_keys is None:
+            mk = 0
+            for k_, n_ in ((lkey, nl), (rkey, nr)):
+                if k_ is not None and n_:
+                    mk = max(mk, int(k_.max()))
+            n_keys = mk + 1
+        args = (C.c_int(mem), _ptr(lkey), _ptr(ls), _ptr(le), C.c_uint64(nl), _ptr(rkey), _ptr(rs), _ptr(re),
+                C.c_uint64(nr), C.c_uint32(n_keys), C.c_int(int(strict)))
+        m = C.c_uint64(0)
+        self._chk(lib().ivx_subtract(self.h, *args, None, None, None, None, C.c_uint64(0), C.byref(m)))
+        cap = max(m.value, 1)
+        if mem == MEM_DEVICE:
+            import torch
+            dev = ls.device
+            ok = torch.empty(cap, dtype=torch.int32, device=dev); os_ = torch.empty(cap, dtype=torch.int64, device=dev)
+            oe = torch.empty(cap, dtype=torch.int64, device=dev); orow = torch.empty(cap, dtype=torch.int32, device=dev)
+        else:
+            ok = np.empty(cap, np.uint32); os_ = np.empty(cap, np.int64); oe = np.empty(cap, np.int64); orow = np.empty(cap, np.uint32)
+        m2 = C.c_uint64(0)
+        self._chk(lib().ivx_subtract(self.h, *args, _ptr(ok), _ptr(os_), _ptr(oe), _ptr(orow), C.c_uint64(cap), C.byref(m2)))
+        m2 = m2.value
+        return ok[:m2], os_[:m2], oe[:m2], orow[:m2]

@@ -1,0 +1,178 @@
+/*
+ * ivx.h -- C ABI of the MI355X-native interval build-and-probe library
+ *          (libivx_hip.so, hand-written HIP for gfx950).
+ *
+ * This is the drop-in boundary for ONE path of
+ * biodatageeks/datafusion-bio-functions: the interval index build + probe
+ * behind `datafusion-bio-function-ranges` (IntervalJoinExec and the
+ * overlap / count_overlaps / coverage / nearest / merge / subtract table
+ * functions).  The reference has no FFI of its own (no extern "C" anywhere);
+ * each entry point below names the reference Rust function whose inner loop
+ * it replaces -- the call a maintainer would swap for an `unsafe extern "C"`
+ * call in the stream implementation (see INTEGRATION.md for the Rust stub).
+ * R/ = datafusion/bio-function-ranges/ in the reference tree.
+ *
+ * Conventions
+ *  - Plain pointers and sizes only.  No Arrow, torch or C++ types.
+ *  - `mem` says where EVERY data pointer of that call lives:
+ *      IVX_MEM_HOST   host memory (Arrow buffers); the library stages them
+ *                     through pinned memory with hipMemcpyAsync;
+ *      IVX_MEM_DEVICE device memory of the ctx's GPU (e.g. buffers the caller
+ *                     already keeps in HBM); no copies, kernels run on the
+ *                     ctx stream.
+ *    Scalar out-parameters (`uint64_t *total`, `*n_out`, ...) are always host
+ *    pointers; writing them synchronises the ctx stream.
+ *  - Keys never cross the boundary as strings: the host maps the equi-key
+ *    column(s) (contig, or contig+strand, ...) to dense ids 0..n_keys-1.  The
+ *    reference groups rows by a 64-bit hash of the key columns and never
+ *    compares key values (interval_join.rs:857, :922-928); dense ids differ
+ *    from that only under a hash collision (documented divergence).
+ *    `key == NULL` means "one key" (range-only join: interval_join.rs on
+ *    [(lit 1, lit 1)], bio_physical_planner.rs:125-146).
+ *  - Join/count/coverage/nearest coordinates are int32, closed [start,end]
+ *    (array_utils.rs:66-135 `resolve()`); merge/subtract are int64
+ *    (`resolve_i64()`, :137-172).  Range checks and null checks stay in the
+ *    host layer, with the reference's wording.
+ *  - "build" is the reference's left / collected side, "probe" the streamed
+ *    right side.  Row indices are uint32 (interval_join.rs:759-760, :1616).
+ *  - `strict` for count/coverage/nearest shrinks the QUERY (qs+1, qe-1) as the
+ *    UDTFs do (interval_tree.rs:185-188, :253-256; nearest.rs:341-344).  The
+ *    SQL join path instead rewrites `<`/`>` into `end-1` on both sides
+ *    (intervals.rs:85-115); callers of ivx_probe_overlap_* pass already
+ *    adjusted columns, exactly as IntervalJoinExec evaluates them.
+ *  - Every function returns an ivx_status; ivx_last_error(ctx) holds the text
+ *    (maps to DataFusionError::Execution).
+ *  - An ivx_index is immutable after build and may be probed concurrently
+ *    from several host threads, each with its OWN ivx_ctx on the same device
+ *    (the reference shares Arc<JoinLeftData> across partitions,
+ *    interval_join.rs:466-480).
+ *  - There is NO CPU fallback: without a usable gfx950 device
+ *    ivx_ctx_create fails with IVX_ERR_NO_DEVICE.
+ */
+#ifndef IVX_H
+#define IVX_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ivx_ctx ivx_ctx;
+typedef struct ivx_index ivx_index;
+typedef int32_t ivx_status;
+
+enum {
+    IVX_OK = 0,
+    IVX_ERR_INVALID = 1,      /* bad argument (null pointer, key id >= n_keys, min_dist < 0 ...) */
+    IVX_ERR_NO_DEVICE = 2,    /* no HIP device / not gfx950 */
+    IVX_ERR_HIP = 3,          /* a HIP runtime call failed; text in ivx_last_error */
+    IVX_ERR_OOM = 4,          /* device or pinned allocation failed (ResourcesExhausted) */
+    IVX_ERR_CAPACITY = 5,     /* caller's output buffers too small; the needed size is returned */
+    IVX_ERR_UNSUPPORTED = 6   /* e.g. wrong index kind for this probe */
+};
+
+enum { IVX_MEM_HOST = 0, IVX_MEM_DEVICE = 1 };
+
+/* which reference structure the index replaces */
+enum {
+    IVX_KIND_OVERLAP = 0,   /* COITree per key            interval_join.rs:745-763 (a1+a2)        */
+    IVX_KIND_COUNT = 1,     /* CountOverlapIndex          interval_tree.rs:20-39, :113-143        */
+    IVX_KIND_COVERAGE = 2,  /* merged COITree             interval_tree.rs:52-111 (coverage=true) */
+    IVX_KIND_NEAREST = 3    /* NearestIntervalIndex       nearest_index.rs:44-71                  */
+};
+
+#define IVX_NULL_IDX 0xFFFFFFFFu   /* NULL build row (interval_join.rs:1233 u32::MAX marker) */
+
+/* ---- context ----------------------------------------------------------- */
+ivx_status ivx_ctx_create(int device_ordinal, ivx_ctx **out);
+void       ivx_ctx_free(ivx_ctx *ctx);
+const char *ivx_last_error(const ivx_ctx *ctx);
+/* run on a caller-owned hipStream_t (e.g. torch's current stream); NULL = the
+ * ctx's own stream */
+ivx_status ivx_ctx_set_stream(ivx_ctx *ctx, void *hip_stream);
+ivx_status ivx_ctx_synchronize(ivx_ctx *ctx);
+/* device time (ms, hipEvent) of the kernels of the last call on this ctx */
+double     ivx_ctx_last_kernel_ms(const ivx_ctx *ctx);
+const char *ivx_version(void);
+
+/* ---- index build: replaces collect_left_input's update_hashmap +
+ *      IntervalJoinAlgorithm::new (interval_join.rs:584-668, :745-847, :903-931),
+ *      build_count_index_from_batches / build_coitree_from_batches
+ *      (interval_tree.rs:75-143) and build_nearest_indexes (nearest.rs:498-547) */
+ivx_status ivx_index_build(ivx_ctx *ctx, int kind, int mem,
+                           const uint32_t *key /* nullable */, const int32_t *start, const int32_t *end,
+                           uint64_t n, uint32_t n_keys, ivx_index **out);
+void       ivx_index_free(ivx_index *ix);
+uint64_t   ivx_index_rows(const ivx_index *ix);
+uint64_t   ivx_index_device_bytes(const ivx_index *ix);
+
+/* ---- a3: IntervalJoinAlgorithm::get + probe loop
+ *      (interval_join.rs:849-900, :1614-1653).  Index kind OVERLAP. ---------
+ * count: total pairs and, if per_row != NULL, the reference's rle_right
+ *        (matches per probe row, uint32). */
+ivx_status ivx_probe_overlap_count(ivx_ctx *ctx, const ivx_index *ix, int mem,
+                                   const uint32_t *key, const int32_t *start, const int32_t *end, uint64_t n,
+                                   uint32_t *per_row /* nullable */, uint64_t *total);
+/* fill: the (build_idx, probe_idx) pairs = the reference's (left_indexes,
+ *       index_right) before compute::take.  Pair ORDER is unspecified (the
+ *       reference pins only the row multiset).  If more than cap pairs exist
+ *       nothing useful is written, *written = pairs needed and the call
+ *       returns IVX_ERR_CAPACITY. */
+ivx_status ivx_probe_overlap_fill(ivx_ctx *ctx, const ivx_index *ix, int mem,
+                                  const uint32_t *key, const int32_t *start, const int32_t *end, uint64_t n,
+                                  uint32_t *build_idx, uint32_t *probe_idx, uint64_t cap, uint64_t *written);
+/* a3': RightSemi / RightAnti (interval_join.rs:1014-1024, :1433-1447):
+ *      exists[i] = 1 iff probe row i has a match. */
+ivx_status ivx_probe_exists(ivx_ctx *ctx, const ivx_index *ix, int mem,
+                            const uint32_t *key, const int32_t *start, const int32_t *end, uint64_t n,
+                            uint8_t *exists);
+
+/* ---- a4: CountOverlapIndex::query_count in get_count_stream
+ *      (interval_tree.rs:41-49, :249-267).  Index kind COUNT. */
+ivx_status ivx_probe_count(ivx_ctx *ctx, const ivx_index *ix, int mem,
+                           const uint32_t *key, const int32_t *start, const int32_t *end, uint64_t n,
+                           int strict, int64_t *out);
+/* ---- a5: get_coverage in get_stream (interval_tree.rs:145-152, :181-208).
+ *      Index kind COVERAGE. */
+ivx_status ivx_probe_coverage(ivx_ctx *ctx, const ivx_index *ix, int mem,
+                              const uint32_t *key, const int32_t *start, const int32_t *end, uint64_t n,
+                              int strict, int64_t *out);
+
+/* ---- a6: NearestIntervalIndex::nearest_one / nearest_k in get_nearest_stream
+ *      (nearest_index.rs:91-235, nearest.rs:330-456) and Algorithm::CoitreesNearest
+ *      (interval_join.rs:864-870).  Index kind NEAREST.
+ *      Every probe row yields max(1, found) output rows, in probe order:
+ *      build_idx (IVX_NULL_IDX = NULL left columns), probe_idx, and if
+ *      distance != NULL candidate_distance on the RAW probe coordinates
+ *      (-1 = NULL).  cap >= n*max(k,1) always suffices. */
+ivx_status ivx_probe_nearest(ivx_ctx *ctx, const ivx_index *ix, int mem,
+                             const uint32_t *key, const int32_t *start, const int32_t *end, uint64_t n,
+                             int strict, uint32_t k, int include_overlaps,
+                             uint32_t *build_idx, uint32_t *probe_idx, int64_t *distance /* nullable */,
+                             uint64_t cap, uint64_t *rows);
+
+/* ---- a7+a8: StreamCollector sort + MergeStream sweep
+ *      (grouped_stream.rs:50-113, merge.rs:282-350).
+ *      Output rows ordered by (key id, start); give key ids in the byte order
+ *      of the contig names to reproduce the reference's group order.
+ *      cap >= n always suffices. */
+ivx_status ivx_merge(ivx_ctx *ctx, int mem,
+                     const uint32_t *key /* nullable */, const int64_t *start, const int64_t *end, uint64_t n,
+                     uint32_t n_keys, int64_t min_dist, int strict,
+                     uint32_t *out_key, int64_t *out_start, int64_t *out_end, int64_t *out_n,
+                     uint64_t cap, uint64_t *n_out);
+
+/* ---- a7+a9: SubtractStream / SubtractStreamExtra sweep
+ *      (subtract.rs:390-462, :575-655).  out_row (nullable) = the left input row
+ *      of each fragment (for the extra-columns `take`).  Passing cap = 0 with
+ *      NULL outputs only counts. */
+ivx_status ivx_subtract(ivx_ctx *ctx, int mem,
+                        const uint32_t *lkey, const int64_t *lstart, const int64_t *lend, uint64_t nl,
+                        const uint32_t *rkey, const int64_t *rstart, const int64_t *rend, uint64_t nr,
+                        uint32_t n_keys, int strict,
+                        uint32_t *out_key, int64_t *out_start, int64_t *out_end, uint32_t *out_row,
+                        uint64_t cap, uint64_t *n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

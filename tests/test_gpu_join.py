@@ -1,0 +1,134 @@
+"""-m gpu: the HIP overlap join through the C ABI vs the CPU oracle (bit-exact pair multisets)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, encode_keys, pair_set, synth
+from oracle import oracle as orc
+
+sys.path.insert(0, os.path.join(ROOT, "datafusion-bio-functions_amd"))
+import pyivx  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = pyivx.Ctx(0)
+    yield c
+    c.close()
+
+
+def _check_join(ctx, bk, bs, be, pk, ps, pe, nkeys):
+    ix = ctx.build(pyivx.KIND_OVERLAP, bk, bs, be, n_keys=nkeys)
+    want_b, want_p, want_cnt = orc.join(bk, bs, be, pk, ps, pe, per_row=True, threads=4)
+    total, per_row = ctx.overlap_count(ix, pk, ps, pe, per_row=True)
+    assert total == len(want_b)
+    assert (per_row.astype(np.uint64) == want_cnt).all()
+    assert ctx.overlap_count(ix, pk, ps, pe) == total
+    ob, op = ctx.overlap_fill(ix, pk, ps, pe, cap=total)
+    assert len(ob) == total
+    assert (pair_set(ob, op) == pair_set(want_b, want_p)).all()
+    ex = ctx.exists(ix, pk, ps, pe)
+    assert (ex == (want_cnt > 0)).all()
+    ix.free()
+
+
+def test_join_golden_tables(ctx, golden):
+    for case in golden.cases("join"):
+        b, p = golden.rows(case["build"]), golden.rows(case["probe"])
+        names, ((bk, bs, be), (pk, ps, pe)) = encode_keys(b, p)
+        bs, be, ps, pe = (x.astype(np.int32) for x in (bs, be, ps, pe))
+        if case["strict"]:
+            be = be - 1; pe = pe - 1
+        ix = ctx.build(pyivx.KIND_OVERLAP, bk, bs, be, n_keys=len(names))
+        ob, op = ctx.overlap_fill(ix, pk, ps, pe)
+        got = sorted([[b[i], p[j]] for i, j in zip(ob, op)], key=repr)
+        assert got == sorted(case["expect"], key=repr), case["name"]
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_join_random_vs_oracle(ctx, seed):
+    nk = [1, 3, 24, 200][seed % 4]
+    mean = [1000, 50, 20000, 300][(seed // 2) % 4]
+    bk, bs, be = synth(20_000, 1000 + seed, nkeys=nk, mean_len=mean, span=3_000_000)
+    pk, ps, pe = synth(100_000, 2000 + seed, nkeys=nk + (seed % 2), mean_len=150, span=3_000_000)
+    _check_join(ctx, bk, bs, be, pk, ps, pe, nk + 1)
+
+
+def test_join_edge_cases(ctx):
+    # empty probe, empty build, single rows, probe keys without build rows
+    bk, bs, be = synth(1000, 1, nkeys=2, span=10_000)
+    ix = ctx.build(pyivx.KIND_OVERLAP, bk, bs, be, n_keys=4)
+    e = np.empty(0, np.int32)
+    assert ctx.overlap_count(ix, np.empty(0, np.uint32), e, e) == 0
+    assert ctx.overlap_count(ix, np.array([3, 3], np.uint32), np.array([0, 5], np.int32), np.array([10_000, 9], np.int32)) == 0
+    ix0 = ctx.build(pyivx.KIND_OVERLAP, np.empty(0, np.uint32), e, e, n_keys=1)
+    assert ctx.overlap_count(ix0, np.zeros(5, np.uint32), np.zeros(5, np.int32), np.ones(5, np.int32)) == 0
+    # key == NULL (range-only join)
+    ixn = ctx.build(pyivx.KIND_OVERLAP, None, bs, be)
+    want = orc.join(np.zeros_like(bk), bs, be, np.zeros(50, np.uint32), bs[:50], be[:50])
+    got = ctx.overlap_fill(ixn, None, bs[:50], be[:50])
+    assert (pair_set(*got) == pair_set(*want)).all()
+
+
+def test_join_extremes_and_inverted(ctx):
+    rng = np.random.default_rng(5)
+    lo, hi = np.iinfo(np.int32).min, np.iinfo(np.int32).max
+    bs = np.concatenate([rng.integers(lo, hi, 3000), [lo, lo, hi - 5, 0, -10]]).astype(np.int64)
+    bl = np.concatenate([rng.integers(0, 1 << 20, 3000), [0, 2**32 - 2, 5, 2**31 - 1, 20]]).astype(np.int64)
+    be = np.minimum(bs + bl, hi)
+    bs, be = bs.astype(np.int32), be.astype(np.int32)
+    be[::37] = bs[::37] - rng.integers(1, 100, len(bs[::37])).astype(np.int32)      # inverted build rows
+    qs = rng.integers(lo, hi, 20000).astype(np.int64)
+    qe = np.minimum(qs + rng.integers(0, 1 << 22, 20000), hi)
+    qs, qe = qs.astype(np.int32), qe.astype(np.int32)
+    qe[::11] = qs[::11] - 7                                                           # inverted queries
+    bk = rng.integers(0, 3, len(bs)).astype(np.uint32); pk = rng.integers(0, 3, len(qs)).astype(np.uint32)
+    _check_join(ctx, bk, bs, be, pk, qs, qe, 3)
+
+
+def test_join_skew_deep_pileup(ctx):
+    # one hot region: every probe overlaps thousands of build rows, plus one chromosome-long row
+    rng = np.random.default_rng(9)
+    bs = np.concatenate([rng.integers(1_000_000, 1_001_000, 5000), [0]]).astype(np.int32)
+    be = np.concatenate([bs[:-1] + rng.integers(100, 2000, 5000), [200_000_000]]).astype(np.int32)
+    ps = rng.integers(999_000, 1_003_000, 3000).astype(np.int32)
+    pe = ps + 150
+    z = np.zeros
+    _check_join(ctx, z(len(bs), np.uint32), bs, be, z(len(ps), np.uint32), ps, pe, 1)
+
+
+def test_capacity_error(ctx):
+    bk, bs, be = synth(5000, 3, span=100_000)
+    ix = ctx.build(pyivx.KIND_OVERLAP, bk, bs, be, n_keys=1)
+    total = ctx.overlap_count(ix, bk, bs, be)
+    assert total > 10
+    with pytest.raises(pyivx.IvxError) as ei:
+        ctx.overlap_fill(ix, bk, bs, be, cap=total - 1)
+    assert ei.value.status == pyivx.ERR_CAPACITY
+
+
+def test_bad_key_rejected(ctx):
+    with pytest.raises(pyivx.IvxError) as ei:
+        ctx.build(pyivx.KIND_OVERLAP, np.array([0, 5], np.uint32), np.array([1, 2], np.int32), np.array([3, 4], np.int32), n_keys=2)
+    assert ei.value.status == pyivx.ERR_INVALID
+
+
+def test_device_pointers_match_host(ctx):
+    import torch
+    bk, bs, be = synth(50_000, 11, nkeys=24, mean_len=1000, span=5_000_000)
+    pk, ps, pe = synth(400_000, 12, nkeys=24, mean_len=150, span=5_000_000)
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(a.view(np.int32) if a.dtype == np.uint32 else a).to(dev)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ix = ctx.build(pyivx.KIND_OVERLAP, t(bk), t(bs), t(be), n_keys=24)
+    total = ctx.overlap_count(ix, t(pk), t(ps), t(pe))
+    ob, op = ctx.overlap_fill(ix, t(pk), t(ps), t(pe), cap=total)
+    torch.cuda.synchronize()
+    want = orc.join(bk, bs, be, pk, ps, pe, threads=4)
+    got = (ob.cpu().numpy().view(np.uint32), op.cpu().numpy().view(np.uint32))
+    assert (pair_set(*got) == pair_set(*want)).all()
+    ctx.set_stream(None)
