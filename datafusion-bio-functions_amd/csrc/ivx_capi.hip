@@ -145,7 +145,7 @@ extern "C" void ivx_ctx_free(ivx_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->stream);
     for (auto &b : c->scratch) if (b.p) (void)hipFree(b.p);
     for (auto &b : c->pinned) if (b.p) (void)hipHostFree(b.p);
     if (c->d_scalars) (void)hipFree(c->d_scalars);
@@ -161,7 +161,14 @@ extern "C" const char *ivx_last_error(const ivx_ctx *c) { return c ? c->err.c_st
 extern "C" ivx_status ivx_ctx_set_stream(ivx_ctx *c, void *hip_stream)
 {
     if (!c) return IVX_ERR_INVALID;
-    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    c->stream = (hipStream_t)hip_stream;
+    return IVX_OK;
+}
+
+extern "C" ivx_status ivx_ctx_use_own_stream(ivx_ctx *c)
+{
+    if (!c) return IVX_ERR_INVALID;
+    c->stream = c->own_stream;
     return IVX_OK;
 }
 

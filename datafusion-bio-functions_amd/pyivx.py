@@ -20,7 +20,8 @@ NULL_IDX = 0xFFFFFFFF
 
 # every symbol include/ivx.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "ivx_ctx_create", "ivx_ctx_free", "ivx_last_error", "ivx_ctx_set_stream", "ivx_ctx_synchronize",
+    "ivx_ctx_create", "ivx_ctx_free", "ivx_last_error", "ivx_ctx_set_stream", "ivx_ctx_use_own_stream",
+    "ivx_ctx_synchronize",
     "ivx_ctx_last_kernel_ms", "ivx_version", "ivx_index_build", "ivx_index_free", "ivx_index_rows",
     "ivx_index_device_bytes", "ivx_probe_overlap_count", "ivx_probe_overlap_fill", "ivx_probe_exists",
     "ivx_probe_count", "ivx_probe_coverage", "ivx_probe_nearest", "ivx_merge", "ivx_subtract",
@@ -147,7 +148,11 @@ class Ctx:
             raise IvxError(st, lib().ivx_last_error(self.h).decode())
 
     def set_stream(self, stream_ptr):
-        self._chk(lib().ivx_ctx_set_stream(self.h, C.c_void_p(stream_ptr)))
+        """use this hipStream_t verbatim (0/None = HIP's default stream)"""
+        self._chk(lib().ivx_ctx_set_stream(self.h, C.c_void_p(stream_ptr or 0)))
+
+    def use_own_stream(self):
+        self._chk(lib().ivx_ctx_use_own_stream(self.h))
 
     def synchronize(self):
         self._chk(lib().ivx_ctx_synchronize(self.h))

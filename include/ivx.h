@@ -86,9 +86,12 @@ enum {
 ivx_status ivx_ctx_create(int device_ordinal, ivx_ctx **out);
 void       ivx_ctx_free(ivx_ctx *ctx);
 const char *ivx_last_error(const ivx_ctx *ctx);
-/* run on a caller-owned hipStream_t (e.g. torch's current stream); NULL = the
- * ctx's own stream */
+/* run on a caller-owned hipStream_t, used verbatim (e.g. torch's current
+ * stream; NULL is HIP's default stream, which orders against the caller's
+ * other default-stream work).  A fresh ctx runs on its own non-blocking
+ * stream; ivx_ctx_use_own_stream switches back to it. */
 ivx_status ivx_ctx_set_stream(ivx_ctx *ctx, void *hip_stream);
+ivx_status ivx_ctx_use_own_stream(ivx_ctx *ctx);
 ivx_status ivx_ctx_synchronize(ivx_ctx *ctx);
 /* device time (ms, hipEvent) of the kernels of the last call on this ctx */
 double     ivx_ctx_last_kernel_ms(const ivx_ctx *ctx);

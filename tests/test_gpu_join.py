@@ -131,4 +131,4 @@ def test_device_pointers_match_host(ctx):
     want = orc.join(bk, bs, be, pk, ps, pe, threads=4)
     got = (ob.cpu().numpy().view(np.uint32), op.cpu().numpy().view(np.uint32))
     assert (pair_set(*got) == pair_set(*want)).all()
-    ctx.set_stream(None)
+    ctx.use_own_stream()
