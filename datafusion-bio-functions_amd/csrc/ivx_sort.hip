@@ -1,0 +1,256 @@
+// ivx_sort.hip -- stable LSD radix sort of multi-word records (hand-written;
+// rocPRIM/hipCUB are not used).  Replaces the reference's per-contig
+// comparison sorts: `sort_unstable` on (start,end[,row]) tuples
+// (grouped_stream.rs:93-95, :213-215), by_start / by_end ordering
+// (nearest_index.rs:50-55, :77-82), merge_intervals' stable sort by first
+// (interval_tree.rs:57).
+//
+// A record is NW 64-bit words held as NW separate arrays (SoA).  One pass
+// sorts by an 8-bit digit of one word:
+//   k_hist    per-workgroup digit histograms (wave ballot "match" + LDS counters)
+//   scan      exclusive prefix over [digit][workgroup]
+//   k_scatter stable local ranking per wavefront (ballot + popcount), records
+//             re-ordered through LDS so that global writes are contiguous runs
+// HBM-bound: per pass 8 B/row read for the histogram + 8*NW B/row read and
+// written by the scatter.  Digits whose bits are constant over the whole input
+// are skipped (one OR-reduction up front).
+#include "ivx_device.hpp"
+#include "ivx_sort.hpp"
+
+namespace {
+
+constexpr int RS_T = 256;
+constexpr int RS_I = 8;                         // records per thread per tile
+constexpr int RS_TILE = RS_T * RS_I;            // 2048
+constexpr int RS_WAVES = RS_T / IVX_WAVE;       // 4
+constexpr int RS_WTILE = RS_TILE / RS_WAVES;    // 512 consecutive records per wavefront
+constexpr int RS_TPB = 8;                       // tiles per workgroup
+constexpr u64 RS_CHUNK = (u64)RS_TILE * RS_TPB; // 16384 records per workgroup
+
+template <int NW> struct Ptrs { u64 *w[NW]; };
+template <int NW> struct CPtrs { const u64 *w[NW]; };
+
+// word `word` of a record held in registers, without a runtime-indexed array
+// (a runtime index would send the record to scratch memory)
+template <int NW>
+__device__ __forceinline__ u64 pick_word(const u64 (&x)[NW], int word)
+{
+    u64 v = x[0];
+    if (NW > 1 && word == 1) v = x[NW > 1 ? 1 : 0];
+    if (NW > 2 && word == 2) v = x[NW > 2 ? 2 : 0];
+    return v;
+}
+
+// lanes of the wave holding the same 8-bit digit (valid lanes only)
+__device__ __forceinline__ u64 match_digit(u32 d, bool valid)
+{
+    u64 peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        const bool bit = (d >> b) & 1u;
+        const u64 bal = __ballot(bit);
+        peers &= bit ? bal : ~bal;
+    }
+    return peers;
+}
+
+__global__ __launch_bounds__(RS_T) void k_varbits(const u64 *__restrict__ w, u64 n, unsigned long long *out)
+{
+    __shared__ u64 lds[RS_T / IVX_WAVE];
+    const u64 x0 = n ? w[0] : 0;
+    u64 acc = 0;
+    for (u64 i = (u64)blockIdx.x * RS_T + threadIdx.x; i < n; i += (u64)gridDim.x * RS_T) acc |= w[i] ^ x0;
+#pragma unroll
+    for (int d = IVX_WAVE / 2; d > 0; d >>= 1) acc |= __shfl_xor(acc, d, IVX_WAVE);
+    if (lane_id() == 0) lds[threadIdx.x / IVX_WAVE] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 a = 0;
+        for (int i = 0; i < RS_T / IVX_WAVE; i++) a |= lds[i];
+        if (a) atomicOr(out, (unsigned long long)a);
+    }
+}
+
+__global__ __launch_bounds__(RS_T) void k_hist(const u64 *__restrict__ w, u64 n, int shift, u32 nblk, u32 *__restrict__ hist)
+{
+    __shared__ u32 cnt[RS_WAVES][256];
+    for (int i = threadIdx.x; i < RS_WAVES * 256; i += RS_T) (&cnt[0][0])[i] = 0;
+    __syncthreads();
+    const u64 lo = (u64)blockIdx.x * RS_CHUNK;
+    const u64 hi = lo + RS_CHUNK < n ? lo + RS_CHUNK : n;
+    const u32 wv = threadIdx.x / IVX_WAVE;
+    for (u64 i0 = lo; i0 < hi; i0 += RS_T) {
+        const u64 i = i0 + threadIdx.x;
+        const bool valid = i < hi;
+        const u32 d = valid ? (u32)((w[i] >> shift) & 0xFF) : 0u;
+        const u64 peers = match_digit(d, valid);
+        if (valid && mask_rank(peers) == 0) cnt[wv][d] += (u32)__popcll(peers);   // one lane per distinct digit
+    }
+    __syncthreads();
+    {
+        const u32 d = threadIdx.x;
+        u32 s = 0;
+#pragma unroll
+        for (int k = 0; k < RS_WAVES; k++) s += cnt[k][d];
+        hist[(u64)d * nblk + blockIdx.x] = s;
+    }
+}
+
+template <int NW>
+__global__ __launch_bounds__(RS_T) void k_scatter(CPtrs<NW> in, Ptrs<NW> out, u64 n, int word, int shift, u32 nblk,
+                                                 const u32 *__restrict__ offs)
+{
+    __shared__ u64 rec[NW][RS_TILE];
+    __shared__ u32 wcnt[RS_WAVES][256];          // per-wave digit counts -> exclusive offsets across waves
+    __shared__ u32 dstart[256];                  // first local slot of the digit in this tile
+    __shared__ u32 tcnt[256];                    // records of the digit in this tile
+    __shared__ u32 gbase[256];                   // next global slot of the digit for this workgroup
+    __shared__ u32 scan_lds[RS_T / IVX_WAVE + 1];
+
+    const u32 tid = threadIdx.x, wv = tid / IVX_WAVE, ln = lane_id();
+    gbase[tid] = offs[(u64)tid * nblk + blockIdx.x];
+    const u64 lo = (u64)blockIdx.x * RS_CHUNK;
+    const u64 hi = lo + RS_CHUNK < n ? lo + RS_CHUNK : n;
+
+    for (u64 t0 = lo; t0 < hi; t0 += RS_TILE) {
+        for (int i = tid; i < RS_WAVES * 256; i += RS_T) (&wcnt[0][0])[i] = 0;
+        __syncthreads();
+        const u32 tile_n = (u32)(hi - t0 < RS_TILE ? hi - t0 : RS_TILE);
+        u64 r[RS_I][NW];
+        u32 dig[RS_I], lrank[RS_I];
+        // ---- stable rank inside the wave's 512-record slice (index order = round, lane)
+#pragma unroll
+        for (int k = 0; k < RS_I; k++) {
+            const u32 j = wv * RS_WTILE + k * IVX_WAVE + ln;        // slot in tile
+            const bool valid = j < tile_n;
+            u32 d = 0;
+            if (valid) {
+#pragma unroll
+                for (int q = 0; q < NW; q++) r[k][q] = in.w[q][t0 + j];
+                d = (u32)((pick_word<NW>(r[k], word) >> shift) & 0xFF);
+            }
+            const u64 peers = match_digit(d, valid);
+            u32 base = 0;
+            if (valid) base = wcnt[wv][d];
+            const u32 rk = mask_rank(peers);
+            if (valid && rk == 0) wcnt[wv][d] = base + (u32)__popcll(peers);
+            dig[k] = valid ? d : 0xFFFFFFFFu;
+            lrank[k] = base + rk;
+        }
+        __syncthreads();
+        // ---- digit totals, offsets of each wave inside the digit, digit starts
+        {
+            const u32 d = tid;
+            u32 run = 0;
+#pragma unroll
+            for (int k = 0; k < RS_WAVES; k++) { const u32 c = wcnt[k][d]; wcnt[k][d] = run; run += c; }
+            tcnt[d] = run;
+            u32 tot;
+            dstart[d] = block_excl_scan<u32, RS_T>(run, scan_lds, &tot);
+        }
+        __syncthreads();
+        // ---- local reorder through LDS
+#pragma unroll
+        for (int k = 0; k < RS_I; k++) {
+            if (dig[k] != 0xFFFFFFFFu) {
+                const u32 pos = dstart[dig[k]] + wcnt[wv][dig[k]] + lrank[k];
+#pragma unroll
+                for (int q = 0; q < NW; q++) rec[q][pos] = r[k][q];
+            }
+        }
+        __syncthreads();
+        // ---- contiguous runs to global
+#pragma unroll
+        for (int k = 0; k < RS_I; k++) {
+            const u32 j = k * RS_T + tid;
+            if (j < tile_n) {
+                u64 x[NW];
+#pragma unroll
+                for (int q = 0; q < NW; q++) x[q] = rec[q][j];
+                const u32 d = (u32)((pick_word<NW>(x, word) >> shift) & 0xFF);
+                const u64 g = (u64)gbase[d] + (j - dstart[d]);
+#pragma unroll
+                for (int q = 0; q < NW; q++) out.w[q][g] = x[q];
+            }
+        }
+        __syncthreads();
+        gbase[tid] += tcnt[tid];
+        __syncthreads();
+    }
+}
+
+template <int NW>
+ivx_status sort_impl(ivx_ctx *ctx, u64 *const *a, u64 *const *b, u64 n, const ivx_sort_field *fields, int nfields, int *in_b)
+{
+    *in_b = 0;
+    if (n <= 1) return IVX_OK;
+    if (n >= 0xFFFFFFFFull) return ctx->fail(IVX_ERR_INVALID, "sort: more than 2^32-1 records");
+    hipStream_t st = ctx->stream;
+    // which bits vary at all (per sorted word)
+    unsigned long long *d_var = (unsigned long long *)(ctx->d_scalars + 16);
+    IVX_HIP(ctx, hipMemsetAsync(d_var, 0, 8 * sizeof(u64), st));
+    for (int f = 0; f < nfields; f++)
+        hipLaunchKernelGGL(k_varbits, dim3(ivx_stream_grid(n, RS_T * 16, 1024)), dim3(RS_T), 0, st, (const u64 *)a[fields[f].word], n, d_var + f);
+    IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 16, d_var, 8 * sizeof(u64), hipMemcpyDeviceToHost, st));
+    IVX_HIP(ctx, hipStreamSynchronize(st));
+
+    const u32 nblk = (u32)((n + RS_CHUNK - 1) / RS_CHUNK);
+    u32 *hist;
+    IVX_TRY(ctx->get_scratch(WS_TMP7, (size_t)256 * nblk * sizeof(u32), (void **)&hist));
+    int cur = 0;
+    for (int f = 0; f < nfields; f++) {
+        const u64 var = ctx->h_scalars[16 + f];
+        for (int sh = fields[f].lo; sh < fields[f].hi; sh += 8) {
+            const u64 window = (sh + 8 >= 64 ? ~0ull : ((1ull << (sh + 8)) - 1)) & ~((1ull << sh) - 1);
+            u64 fieldmask = fields[f].hi >= 64 ? ~0ull : ((1ull << fields[f].hi) - 1);
+            if (((var & window) & fieldmask) == 0) continue;          // digit constant over the input
+            u64 *const *src = cur ? b : a;
+            u64 *const *dst = cur ? a : b;
+            CPtrs<NW> ci; Ptrs<NW> po;
+            for (int q = 0; q < NW; q++) { ci.w[q] = src[q]; po.w[q] = dst[q]; }
+            hipLaunchKernelGGL(k_hist, dim3(nblk), dim3(RS_T), 0, st, (const u64 *)src[fields[f].word], n, sh, nblk, hist);
+            IVX_TRY(ivx_scan_exclusive_u32(ctx, hist, (u64)256 * nblk));
+            hipLaunchKernelGGL((k_scatter<NW>), dim3(nblk), dim3(RS_T), 0, st, ci, po, n, fields[f].word, sh, nblk, (const u32 *)hist);
+            cur ^= 1;
+        }
+    }
+    IVX_HIP(ctx, hipGetLastError());
+    *in_b = cur;
+    return IVX_OK;
+}
+
+}  // namespace
+
+ivx_status ivx_radix_sort(ivx_ctx *ctx, int nw, u64 *const *a, u64 *const *b, u64 n,
+                          const ivx_sort_field *fields, int nfields, int *in_b)
+{
+    switch (nw) {
+    case 1: return sort_impl<1>(ctx, a, b, n, fields, nfields, in_b);
+    case 2: return sort_impl<2>(ctx, a, b, n, fields, nfields, in_b);
+    case 3: return sort_impl<3>(ctx, a, b, n, fields, nfields, in_b);
+    default: return ctx->fail(IVX_ERR_INVALID, "sort: unsupported record width");
+    }
+}
+
+// test hook (not part of include/ivx.h): sort (w0[,w1]) device or host arrays by the given fields
+extern "C" ivx_status ivx_debug_sort(ivx_ctx *ctx, int nw, u64 *w0, u64 *w1, u64 *w2, u64 n,
+                                     const int *field_words, const int *field_lo, const int *field_hi, int nfields)
+{
+    if (!ctx || nw < 1 || nw > 3 || nfields > 8) return IVX_ERR_INVALID;
+    IVX_HIP(ctx, hipSetDevice(ctx->device));
+    u64 *host[3] = {w0, w1, w2};
+    u64 *a[3], *b[3];
+    for (int q = 0; q < nw; q++) {
+        IVX_TRY(ctx->get_scratch(WS_TMP0 + q, n * sizeof(u64), (void **)&a[q]));
+        IVX_TRY(ctx->get_scratch(WS_TMP3 + q, n * sizeof(u64), (void **)&b[q]));
+        IVX_HIP(ctx, hipMemcpyAsync(a[q], host[q], n * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+    }
+    ivx_sort_field f[8];
+    for (int i = 0; i < nfields; i++) { f[i].word = field_words[i]; f[i].lo = field_lo[i]; f[i].hi = field_hi[i]; }
+    int in_b = 0;
+    IVX_TRY(ivx_radix_sort(ctx, nw, a, b, n, f, nfields, &in_b));
+    for (int q = 0; q < nw; q++)
+        IVX_HIP(ctx, hipMemcpyAsync(host[q], in_b ? b[q] : a[q], n * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+    IVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return IVX_OK;
+}

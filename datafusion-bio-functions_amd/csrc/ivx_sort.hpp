@@ -1,0 +1,12 @@
+// ivx_sort.hpp -- stable LSD radix sort of SoA multi-word records (see ivx_sort.hip).
+#pragma once
+#include "ivx_internal.hpp"
+
+// sort by bits [lo,hi) of word `word`; lo and hi byte aligned.  Fields are given
+// from the LEAST significant sort criterion to the most significant one.
+struct ivx_sort_field { int word, lo, hi; };
+
+// a[0..nw) hold the input arrays, b[0..nw) same-sized scratch; *in_b tells where
+// the sorted records ended up (1 = in b).  Uses scratch WS_TMP7 and WS_SCAN*.
+ivx_status ivx_radix_sort(ivx_ctx *ctx, int nw, u64 *const *a, u64 *const *b, u64 n,
+                          const ivx_sort_field *fields, int nfields, int *in_b);
