@@ -208,6 +208,7 @@ extern "C" ivx_status ivx_index_build(ivx_ctx *ctx, int kind, int mem, const uin
     if (n > 0xFFFFFFFEull) return ctx->fail(IVX_ERR_INVALID, "build side exceeds UInt32 index capacity");   // interval_join.rs:759
     if (n_keys == 0) n_keys = 1;
     if (!key) n_keys = 1;
+    if (kind == IVX_KIND_NEAREST && n >= 0x80000000ull) return ctx->fail(IVX_ERR_INVALID, "nearest index: more than 2^31-1 rows");
     IVX_HIP(ctx, hipSetDevice(ctx->device));
     ivx_index *ix = new (std::nothrow) ivx_index();
     if (!ix) return ctx->fail(IVX_ERR_OOM, "host allocation failed");
@@ -294,4 +295,160 @@ extern "C" ivx_status ivx_probe_exists(ivx_ctx *ctx, const ivx_index *ix, int me
 {
     if (ctx && n && !exists) return ctx->fail(IVX_ERR_INVALID, "null exists buffer");
     return overlap_common(ctx, ix, mem, JP_EXISTS, key, start, end, n, nullptr, exists, nullptr, nullptr, 0, nullptr);
+}
+
+// ---------------------------------------------------------------- a4 / a5 / a6 probes
+
+ivx_status ivx_count_probe(ivx_ctx *ctx, const ivx_index *ix, const u32 *key, const i32 *s, const i32 *e, u64 n, int strict, i64 *out);
+ivx_status ivx_coverage_probe(ivx_ctx *ctx, const ivx_index *ix, const u32 *key, const i32 *s, const i32 *e, u64 n, int strict, i64 *out);
+ivx_status ivx_nearest_probe(ivx_ctx *ctx, const ivx_index *ix, const u32 *key, const i32 *s, const i32 *e, u64 n,
+                             int strict, u32 k, int include_overlaps, u32 *ob, u32 *op, i64 *od, u64 cap, u64 *rows);
+ivx_status ivx_merge_device(ivx_ctx *ctx, const u32 *key, const i64 *s, const i64 *e, u64 n, u32 nkeys,
+                            i64 min_dist, int strict, u32 *ok, i64 *os, i64 *oe, i64 *on, u64 *m);
+ivx_status ivx_subtract_device(ivx_ctx *ctx, const u32 *lkey, const i64 *ls, const i64 *le, u64 nl,
+                               const u32 *rkey, const i64 *rs, const i64 *re, u64 nr, u32 nkeys, int strict,
+                               u32 *ok, i64 *os, i64 *oe, u32 *orow, u64 cap, u64 *n_out);
+
+static ivx_status per_row_i64(ivx_ctx *ctx, const ivx_index *ix, int kind, int mem, const u32 *key, const i32 *start,
+                              const i32 *end, u64 n, int strict, i64 *out)
+{
+    IVX_TRY(check_probe_args(ctx, ix, kind, mem, start, end, n));
+    if (n && !out) return ctx->fail(IVX_ERR_INVALID, "null output column");
+    const u32 *dk; const i32 *ds, *de; i64 *dout;
+    IVX_TRY(stage_in(ctx, mem, WS_IN_KEY, key, n, &dk));
+    IVX_TRY(stage_in(ctx, mem, WS_IN_START, start, n, &ds));
+    IVX_TRY(stage_in(ctx, mem, WS_IN_END, end, n, &de));
+    IVX_TRY(stage_out(ctx, mem, WS_OUT_A, out, n, &dout));
+    {
+        KernelTimer t(ctx);
+        if (kind == IVX_KIND_COUNT) IVX_TRY(ivx_count_probe(ctx, ix, dk, ds, de, n, strict, dout));
+        else IVX_TRY(ivx_coverage_probe(ctx, ix, dk, ds, de, n, strict, dout));
+    }
+    IVX_TRY(copy_out(ctx, mem, out, dout, n));
+    if (mem == IVX_MEM_HOST) IVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return IVX_OK;
+}
+
+extern "C" ivx_status ivx_probe_count(ivx_ctx *ctx, const ivx_index *ix, int mem, const uint32_t *key, const int32_t *start,
+                                      const int32_t *end, uint64_t n, int strict, int64_t *out)
+{
+    return per_row_i64(ctx, ix, IVX_KIND_COUNT, mem, key, start, end, n, strict, out);
+}
+
+extern "C" ivx_status ivx_probe_coverage(ivx_ctx *ctx, const ivx_index *ix, int mem, const uint32_t *key, const int32_t *start,
+                                         const int32_t *end, uint64_t n, int strict, int64_t *out)
+{
+    return per_row_i64(ctx, ix, IVX_KIND_COVERAGE, mem, key, start, end, n, strict, out);
+}
+
+extern "C" ivx_status ivx_probe_nearest(ivx_ctx *ctx, const ivx_index *ix, int mem, const uint32_t *key, const int32_t *start,
+                                        const int32_t *end, uint64_t n, int strict, uint32_t k, int include_overlaps,
+                                        uint32_t *build_idx, uint32_t *probe_idx, int64_t *distance, uint64_t cap, uint64_t *rows)
+{
+    IVX_TRY(check_probe_args(ctx, ix, IVX_KIND_NEAREST, mem, start, end, n));
+    if (!rows) return ctx->fail(IVX_ERR_INVALID, "null rows");
+    if (n && (!build_idx || !probe_idx)) return ctx->fail(IVX_ERR_INVALID, "null output column");
+    if ((u64)k * n > 0xFFFFFFFFFFull) return ctx->fail(IVX_ERR_INVALID, "nearest: k * rows too large");
+    const u32 *dk; const i32 *ds, *de; u32 *db, *dp; i64 *dd;
+    IVX_TRY(stage_in(ctx, mem, WS_IN_KEY, key, n, &dk));
+    IVX_TRY(stage_in(ctx, mem, WS_IN_START, start, n, &ds));
+    IVX_TRY(stage_in(ctx, mem, WS_IN_END, end, n, &de));
+    IVX_TRY(stage_out(ctx, mem, WS_OUT_A, build_idx, cap, &db));
+    IVX_TRY(stage_out(ctx, mem, WS_OUT_B, probe_idx, cap, &dp));
+    IVX_TRY(stage_out(ctx, mem, WS_OUT_C, distance, cap, &dd));
+    u64 r = 0;
+    {
+        KernelTimer t(ctx);
+        ivx_status st = ivx_nearest_probe(ctx, ix, dk, ds, de, n, strict, k, include_overlaps, db, dp, dd, cap, &r);
+        *rows = r;
+        if (st != IVX_OK) return st;
+    }
+    IVX_TRY(copy_out(ctx, mem, build_idx, db, r));
+    IVX_TRY(copy_out(ctx, mem, probe_idx, dp, r));
+    IVX_TRY(copy_out(ctx, mem, distance, dd, r));
+    if (mem == IVX_MEM_HOST) IVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return IVX_OK;
+}
+
+// ---------------------------------------------------------------- a7..a9
+
+extern "C" ivx_status ivx_merge(ivx_ctx *ctx, int mem, const uint32_t *key, const int64_t *start, const int64_t *end, uint64_t n,
+                                uint32_t n_keys, int64_t min_dist, int strict,
+                                uint32_t *out_key, int64_t *out_start, int64_t *out_end, int64_t *out_n,
+                                uint64_t cap, uint64_t *n_out)
+{
+    if (!ctx) return IVX_ERR_INVALID;
+    if (!n_out) return ctx->fail(IVX_ERR_INVALID, "null n_out");
+    *n_out = 0;
+    if (mem != IVX_MEM_HOST && mem != IVX_MEM_DEVICE) return ctx->fail(IVX_ERR_INVALID, "bad mem");
+    if (n && (!start || !end)) return ctx->fail(IVX_ERR_INVALID, "null coordinate column");
+    if (min_dist < 0) return ctx->fail(IVX_ERR_INVALID, "merge() min_dist must be >= 0, got " + std::to_string(min_dist));   // table_function.rs:237
+    if (cap < n) return ctx->fail(IVX_ERR_CAPACITY, "merge: output buffers need capacity n");
+    if (n >= 0xFFFFFFFFull) return ctx->fail(IVX_ERR_INVALID, "merge: more than 2^32-1 rows in one call");
+    if (!key || n_keys == 0) n_keys = 1;
+    IVX_HIP(ctx, hipSetDevice(ctx->device));
+    const u32 *dk; const i64 *ds, *de; u32 *ok; i64 *os, *oe, *on;
+    IVX_TRY(stage_in(ctx, mem, WS_IN_KEY, key, n, &dk));
+    IVX_TRY(stage_in(ctx, mem, WS_IN_START, start, n, &ds));
+    IVX_TRY(stage_in(ctx, mem, WS_IN_END, end, n, &de));
+    IVX_TRY(stage_out(ctx, mem, WS_OUT_A, out_key, n, &ok));
+    IVX_TRY(stage_out(ctx, mem, WS_OUT_B, out_start, n, &os));
+    IVX_TRY(stage_out(ctx, mem, WS_OUT_C, out_end, n, &oe));
+    IVX_TRY(stage_out(ctx, mem, WS_OUT_D, out_n, n, &on));
+    u64 m = 0;
+    {
+        KernelTimer t(ctx);
+        IVX_TRY(ivx_merge_device(ctx, dk, ds, de, n, n_keys, min_dist, strict, ok, os, oe, on, &m));
+    }
+    *n_out = m;
+    IVX_TRY(copy_out(ctx, mem, out_key, ok, m));
+    IVX_TRY(copy_out(ctx, mem, out_start, os, m));
+    IVX_TRY(copy_out(ctx, mem, out_end, oe, m));
+    IVX_TRY(copy_out(ctx, mem, out_n, on, m));
+    if (mem == IVX_MEM_HOST) IVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return IVX_OK;
+}
+
+extern "C" ivx_status ivx_subtract(ivx_ctx *ctx, int mem,
+                                   const uint32_t *lkey, const int64_t *lstart, const int64_t *lend, uint64_t nl,
+                                   const uint32_t *rkey, const int64_t *rstart, const int64_t *rend, uint64_t nr,
+                                   uint32_t n_keys, int strict,
+                                   uint32_t *out_key, int64_t *out_start, int64_t *out_end, uint32_t *out_row,
+                                   uint64_t cap, uint64_t *n_out)
+{
+    if (!ctx) return IVX_ERR_INVALID;
+    if (!n_out) return ctx->fail(IVX_ERR_INVALID, "null n_out");
+    *n_out = 0;
+    if (mem != IVX_MEM_HOST && mem != IVX_MEM_DEVICE) return ctx->fail(IVX_ERR_INVALID, "bad mem");
+    if ((nl && (!lstart || !lend)) || (nr && (!rstart || !rend))) return ctx->fail(IVX_ERR_INVALID, "null coordinate column");
+    if (nl >= 0xFFFFFFFFull || nr >= 0xFFFFFFFFull) return ctx->fail(IVX_ERR_INVALID, "subtract: more than 2^32-1 rows in one call");
+    if ((lkey == nullptr) != (rkey == nullptr) && nl && nr) return ctx->fail(IVX_ERR_INVALID, "subtract: key given for one side only");
+    if (n_keys == 0 || (!lkey && !rkey)) n_keys = 1;
+    IVX_HIP(ctx, hipSetDevice(ctx->device));
+    const u32 *dlk, *drk; const i64 *dls, *dle, *drs, *dre; u32 *ok, *orow; i64 *os, *oe;
+    IVX_TRY(stage_in(ctx, mem, WS_IN_KEY, lkey, nl, &dlk));
+    IVX_TRY(stage_in(ctx, mem, WS_IN_START, lstart, nl, &dls));
+    IVX_TRY(stage_in(ctx, mem, WS_IN_END, lend, nl, &dle));
+    IVX_TRY(stage_in(ctx, mem, WS_IN2_KEY, rkey, nr, &drk));
+    IVX_TRY(stage_in(ctx, mem, WS_IN2_START, rstart, nr, &drs));
+    IVX_TRY(stage_in(ctx, mem, WS_IN2_END, rend, nr, &dre));
+    IVX_TRY(stage_out(ctx, mem, WS_OUT_A, out_key, cap, &ok));
+    IVX_TRY(stage_out(ctx, mem, WS_OUT_B, out_start, cap, &os));
+    IVX_TRY(stage_out(ctx, mem, WS_OUT_C, out_end, cap, &oe));
+    IVX_TRY(stage_out(ctx, mem, WS_OUT_D, out_row, cap, &orow));
+    u64 m = 0;
+    {
+        KernelTimer t(ctx);
+        ivx_status st = ivx_subtract_device(ctx, dlk, dls, dle, nl, drk, drs, dre, nr, n_keys, strict, ok, os, oe, orow, cap, &m);
+        *n_out = m;
+        if (st != IVX_OK) return st;
+    }
+    if (cap) {
+        IVX_TRY(copy_out(ctx, mem, out_key, ok, m));
+        IVX_TRY(copy_out(ctx, mem, out_start, os, m));
+        IVX_TRY(copy_out(ctx, mem, out_end, oe, m));
+        IVX_TRY(copy_out(ctx, mem, out_row, orow, m));
+    }
+    if (mem == IVX_MEM_HOST) IVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return IVX_OK;
 }

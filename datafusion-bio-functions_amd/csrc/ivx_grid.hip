@@ -1,0 +1,158 @@
+// ivx_grid.hip -- per-key statistics and the rank-grid build (see ivx_grid.hpp).
+// Counting sort with atomics: histogram of cells, exclusive scan, scatter.
+#include "ivx_grid.hpp"
+
+namespace {
+
+constexpr int GT = 256;
+constexpr u32 KEYS_IN_LDS = 2048;
+
+__global__ void k_init_keystats(i32 *kmin, i32 *kmax, u32 *kcnt, u32 nkeys)
+{
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nkeys) { kmin[i] = INT32_MAX; kmax[i] = INT32_MIN; kcnt[i] = 0; }
+}
+
+// per-key min / max of v and row counts, privatised in LDS; key ids >= nkeys raise *errflag
+__global__ __launch_bounds__(GT) void k_keystats(const u32 *__restrict__ key, const i32 *__restrict__ v, u64 n,
+                                                 u32 nkeys, i32 *kmin, i32 *kmax, u32 *kcnt, u32 *errflag)
+{
+    extern __shared__ i32 sh[];
+    const bool priv = nkeys <= KEYS_IN_LDS;
+    i32 *smin = sh, *smax = sh + nkeys;
+    u32 *scnt = (u32 *)(sh + 2 * nkeys);
+    if (priv) {
+        for (u32 k = threadIdx.x; k < nkeys; k += GT) { smin[k] = INT32_MAX; smax[k] = INT32_MIN; scnt[k] = 0; }
+        __syncthreads();
+    }
+    for (u64 i = (u64)blockIdx.x * GT + threadIdx.x; i < n; i += (u64)gridDim.x * GT) {
+        const u32 k = key ? key[i] : 0u;
+        if (k >= nkeys) { *errflag = 1; continue; }
+        const i32 x = v[i];
+        if (priv) { atomicMin(&smin[k], x); atomicMax(&smax[k], x); atomicAdd(&scnt[k], 1u); }
+        else { atomicMin(&kmin[k], x); atomicMax(&kmax[k], x); atomicAdd(&kcnt[k], 1u); }
+    }
+    if (priv) {
+        __syncthreads();
+        for (u32 k = threadIdx.x; k < nkeys; k += GT)
+            if (scnt[k]) { atomicMin(&kmin[k], smin[k]); atomicMax(&kmax[k], smax[k]); atomicAdd(&kcnt[k], scnt[k]); }
+    }
+}
+
+__device__ __forceinline__ u32 gcells(u32 cnt, u32 span, u32 sh) { return cnt ? (span >> sh) + 1u : 0u; }
+
+// one workgroup: origin/span, row offsets per key, cell width, first cell per key
+__global__ __launch_bounds__(1024) void k_grid_layout(const i32 *kmin, const i32 *kmax, const u32 *kcnt, u32 nkeys, u64 n,
+                                                      i32 *origin, u32 *span, u32 *koff, u32 *kbase, u32 *hdr)
+{
+    __shared__ u64 red[1024 / IVX_WAVE + 1];
+    __shared__ u32 s_sh;
+    const u32 t = threadIdx.x;
+    for (u32 k = t; k < nkeys; k += 1024) {
+        const u32 c = kcnt[k];
+        origin[k] = c ? kmin[k] : 0;
+        span[k] = c ? (u32)((i64)kmax[k] - (i64)kmin[k]) : 0u;
+    }
+    __syncthreads();
+    const u64 budget = 2 * n + nkeys;
+    u32 lo = 0, hi = 31;
+    while (lo < hi) {
+        const u32 mid = (lo + hi) / 2;
+        u64 s = 0;
+        for (u32 k = t; k < nkeys; k += 1024) s += gcells(kcnt[k], span[k], mid);
+        const u64 tot = block_sum<u64, 1024>(s, red);
+        if (tot <= budget) hi = mid; else lo = mid + 1;
+    }
+    if (t == 0) s_sh = lo;
+    __syncthreads();
+    const u32 sh = s_sh;
+    u64 run_c = 0, run_r = 0;
+    for (u32 k0 = 0; k0 < nkeys; k0 += 1024) {
+        const u32 k = k0 + t;
+        const u64 c = k < nkeys ? gcells(kcnt[k], span[k], sh) : 0u;
+        const u64 r = k < nkeys ? kcnt[k] : 0u;
+        u64 totc, totr;
+        const u64 exc = block_excl_scan<u64, 1024>(c, red, &totc);
+        const u64 exr = block_excl_scan<u64, 1024>(r, red, &totr);
+        if (k < nkeys) { kbase[k] = (u32)(run_c + exc); koff[k] = (u32)(run_r + exr); }
+        run_c += totc; run_r += totr;
+    }
+    if (t == 0) { koff[nkeys] = (u32)run_r; hdr[0] = sh; hdr[1] = (u32)run_c; }
+}
+
+__global__ __launch_bounds__(GT) void k_grid_count(const u32 *__restrict__ key, const i32 *__restrict__ v, u64 n, u32 nkeys,
+                                                   const i32 *origin, const u32 *kbase, const u32 *hdr, u32 *bincnt)
+{
+    const u32 sh = hdr[0];
+    for (u64 i = (u64)blockIdx.x * GT + threadIdx.x; i < n; i += (u64)gridDim.x * GT) {
+        const u32 k = key ? key[i] : 0u;
+        if (k >= nkeys) continue;
+        const u32 c = kbase[k] + ((u32)((i64)v[i] - (i64)origin[k]) >> sh);
+        atomicAdd(&bincnt[c], 1u);
+    }
+}
+
+__global__ __launch_bounds__(GT) void k_grid_scatter(const u32 *__restrict__ key, const i32 *__restrict__ v, u64 n, u32 nkeys,
+                                                     const i32 *origin, const u32 *kbase, const u32 *hdr,
+                                                     const u32 *binstart, u32 *cursor, i32 *val)
+{
+    const u32 sh = hdr[0];
+    for (u64 i = (u64)blockIdx.x * GT + threadIdx.x; i < n; i += (u64)gridDim.x * GT) {
+        const u32 k = key ? key[i] : 0u;
+        if (k >= nkeys) continue;
+        const i32 x = v[i];
+        const u32 c = kbase[k] + ((u32)((i64)x - (i64)origin[k]) >> sh);
+        val[binstart[c] + atomicAdd(&cursor[c], 1u)] = x;
+    }
+}
+
+}  // namespace
+
+ivx_status ivx_keystats(ivx_ctx *ctx, const u32 *key, const i32 *v, u64 n, u32 nkeys,
+                        i32 *kmin, i32 *kmax, u32 *kcnt, u32 *errflag)
+{
+    hipStream_t st = ctx->stream;
+    hipLaunchKernelGGL(k_init_keystats, dim3((nkeys + GT - 1) / GT), dim3(GT), 0, st, kmin, kmax, kcnt, nkeys);
+    if (n) {
+        const u32 grid = ivx_stream_grid(n, GT * 8, 1024);
+        const size_t shm = nkeys <= KEYS_IN_LDS ? (size_t)nkeys * 12 : 0;
+        hipLaunchKernelGGL(k_keystats, dim3(grid), dim3(GT), shm, st, key, v, n, nkeys, kmin, kmax, kcnt, errflag);
+    }
+    IVX_HIP(ctx, hipGetLastError());
+    return IVX_OK;
+}
+
+ivx_status ivx_grid_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32 *v, u64 n, u32 nkeys, RankGridView *out)
+{
+    hipStream_t st = ctx->stream;
+    const u64 maxcells = 2 * n + nkeys + 64;
+    if (maxcells + 1 >= 0xFFFFFFFFull) return ctx->fail(IVX_ERR_INVALID, "column too large for 32-bit cell ids");
+    i32 *origin, *val; u32 *span, *kcnt, *koff, *kbase, *binstart, *hdr;
+    IVX_TRY(ivx_index_alloc(ctx, ix, nkeys * sizeof(i32), (void **)&origin));
+    IVX_TRY(ivx_index_alloc(ctx, ix, nkeys * sizeof(u32), (void **)&span));
+    IVX_TRY(ivx_index_alloc(ctx, ix, nkeys * sizeof(u32), (void **)&kcnt));
+    IVX_TRY(ivx_index_alloc(ctx, ix, ((size_t)nkeys + 1) * sizeof(u32), (void **)&koff));
+    IVX_TRY(ivx_index_alloc(ctx, ix, nkeys * sizeof(u32), (void **)&kbase));
+    IVX_TRY(ivx_index_alloc(ctx, ix, (maxcells + 1) * sizeof(u32), (void **)&binstart));
+    IVX_TRY(ivx_index_alloc(ctx, ix, 4 * sizeof(u32), (void **)&hdr));
+    IVX_TRY(ivx_index_alloc(ctx, ix, (n ? n : 1) * sizeof(i32), (void **)&val));
+    i32 *kmin, *kmax; u32 *cursor;
+    IVX_TRY(ctx->get_scratch(WS_GRID0, nkeys * sizeof(i32), (void **)&kmin));
+    IVX_TRY(ctx->get_scratch(WS_GRID1, nkeys * sizeof(i32), (void **)&kmax));
+    IVX_TRY(ctx->get_scratch(WS_GRID2, (maxcells + 1) * sizeof(u32), (void **)&cursor));
+    u32 *errflag = (u32 *)(ctx->d_scalars + 8);
+    IVX_HIP(ctx, hipMemsetAsync(binstart, 0, (maxcells + 1) * sizeof(u32), st));
+    IVX_HIP(ctx, hipMemsetAsync(cursor, 0, (maxcells + 1) * sizeof(u32), st));
+    IVX_TRY(ivx_keystats(ctx, key, v, n, nkeys, kmin, kmax, kcnt, errflag));
+    hipLaunchKernelGGL(k_grid_layout, dim3(1), dim3(1024), 0, st, kmin, kmax, kcnt, nkeys, n, origin, span, koff, kbase, hdr);
+    if (n) {
+        const u32 grid = ivx_stream_grid(n, GT * 8, 1024);
+        hipLaunchKernelGGL(k_grid_count, dim3(grid), dim3(GT), 0, st, key, v, n, nkeys, origin, kbase, hdr, binstart);
+        IVX_TRY(ivx_scan_exclusive_u32(ctx, binstart, maxcells + 1));
+        hipLaunchKernelGGL(k_grid_scatter, dim3(grid), dim3(GT), 0, st, key, v, n, nkeys, origin, kbase, hdr, binstart, cursor, val);
+    }
+    IVX_HIP(ctx, hipGetLastError());
+    out->origin = origin; out->span = span; out->kcnt = kcnt; out->koff = koff; out->kbase = kbase;
+    out->binstart = binstart; out->val = val; out->hdr = hdr; out->nkeys = nkeys;
+    return IVX_OK;
+}

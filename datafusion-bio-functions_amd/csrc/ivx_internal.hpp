@@ -17,7 +17,7 @@ typedef int64_t i64;
 // ---------------------------------------------------------------- context
 struct ivx_buf { void *p = nullptr; size_t cap = 0; };
 
-enum { IVX_NSCRATCH = 24, IVX_NPIN = 4 };
+enum { IVX_NSCRATCH = 48, IVX_NPIN = 4 };
 
 struct ivx_ctx {
     int device = 0;
@@ -56,10 +56,14 @@ struct ivx_ctx {
 
 // scratch slot ids (one per concurrent use inside a call)
 enum {
-    WS_IN_KEY = 0, WS_IN_START, WS_IN_END, WS_IN2_KEY, WS_IN2_START, WS_IN2_END,
-    WS_OUT_A, WS_OUT_B, WS_OUT_C, WS_OUT_D,
-    WS_SCAN0, WS_SCAN1, WS_SCAN2,
-    WS_TMP0, WS_TMP1, WS_TMP2, WS_TMP3, WS_TMP4, WS_TMP5, WS_TMP6, WS_TMP7
+    WS_IN_KEY = 0, WS_IN_START, WS_IN_END, WS_IN2_KEY, WS_IN2_START, WS_IN2_END,   // staged host inputs
+    WS_OUT_A, WS_OUT_B, WS_OUT_C, WS_OUT_D,                                         // staged host outputs
+    WS_SCAN0, WS_SCAN1, WS_SCAN2,                                                   // scan partials
+    WS_GRID0, WS_GRID1, WS_GRID2,                                                   // key stats + cell cursors
+    WS_SORTHIST,                                                                    // radix-sort histograms
+    WS_SA0, WS_SA1, WS_SA2, WS_SB0, WS_SB1, WS_SB2,                                 // sort ping/pong records
+    WS_RA0, WS_RA1, WS_RA2, WS_RB0, WS_RB1, WS_RB2,                                 // second record set (subtract's right side)
+    WS_T0, WS_T1, WS_T2, WS_T3, WS_T4, WS_T5, WS_T6, WS_T7, WS_T8, WS_T9            // per-op temporaries
 };
 
 // ---------------------------------------------------------------- indexes

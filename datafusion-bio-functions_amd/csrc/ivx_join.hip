@@ -18,46 +18,13 @@
 //   sh0 is picked on the device from the per-key coordinate spans so that the
 //   finest level has at most ~2 cells per build row.
 #include "ivx_device.hpp"
+#include "ivx_grid.hpp"
 
 namespace {
 
 constexpr int BT = 256;              // build kernels
-constexpr u32 KEYS_IN_LDS = 2048;    // per-key min/max privatised in LDS up to this many keys
 
 // ------------------------------------------------------------------ build
-
-__global__ void k_init_keystats(i32 *kmin, i32 *kmax, u32 *kcnt, u32 nkeys, u32 *hdr)
-{
-    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nkeys) { kmin[i] = INT32_MAX; kmax[i] = INT32_MIN; kcnt[i] = 0; }
-    if (i < HDR_WORDS) hdr[i] = 0;
-}
-
-// per-key min / max of `v` and row counts; key ids >= nkeys set the error flag
-__global__ __launch_bounds__(BT) void k_keystats(const u32 *__restrict__ key, const i32 *__restrict__ v, u64 n,
-                                                 u32 nkeys, i32 *kmin, i32 *kmax, u32 *kcnt, u32 *errflag)
-{
-    extern __shared__ i32 sh[];
-    const bool priv = nkeys <= KEYS_IN_LDS;
-    i32 *smin = sh, *smax = sh + nkeys;
-    u32 *scnt = (u32 *)(sh + 2 * nkeys);
-    if (priv) {
-        for (u32 k = threadIdx.x; k < nkeys; k += BT) { smin[k] = INT32_MAX; smax[k] = INT32_MIN; scnt[k] = 0; }
-        __syncthreads();
-    }
-    for (u64 i = (u64)blockIdx.x * BT + threadIdx.x; i < n; i += (u64)gridDim.x * BT) {
-        u32 k = key ? key[i] : 0u;
-        if (k >= nkeys) { *errflag = 1; continue; }
-        i32 x = v[i];
-        if (priv) { atomicMin(&smin[k], x); atomicMax(&smax[k], x); atomicAdd(&scnt[k], 1u); }
-        else { atomicMin(&kmin[k], x); atomicMax(&kmax[k], x); atomicAdd(&kcnt[k], 1u); }
-    }
-    if (priv) {
-        __syncthreads();
-        for (u32 k = threadIdx.x; k < nkeys; k += BT)
-            if (scnt[k]) { atomicMin(&kmin[k], smin[k]); atomicMax(&kmax[k], smax[k]); atomicAdd(&kcnt[k], scnt[k]); }
-    }
-}
 
 __device__ __forceinline__ u32 cells_of(u32 cnt, u32 span, u32 sh) { return cnt ? (sh >= 32 ? 1u : (span >> sh) + 1u) : 0u; }
 
@@ -289,19 +256,17 @@ ivx_status ivx_join_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32
     IVX_TRY(ivx_index_alloc(ctx, ix, (n ? n : 1) * sizeof(ivx_ent), (void **)&ent));
 
     i32 *kmin, *kmax; u32 *cursor, *errflag;
-    IVX_TRY(ctx->get_scratch(WS_TMP0, nkeys * sizeof(i32), (void **)&kmin));
-    IVX_TRY(ctx->get_scratch(WS_TMP1, nkeys * sizeof(i32), (void **)&kmax));
-    IVX_TRY(ctx->get_scratch(WS_TMP2, (maxcells + 1) * sizeof(u32), (void **)&cursor));
+    IVX_TRY(ctx->get_scratch(WS_GRID0, nkeys * sizeof(i32), (void **)&kmin));
+    IVX_TRY(ctx->get_scratch(WS_GRID1, nkeys * sizeof(i32), (void **)&kmax));
+    IVX_TRY(ctx->get_scratch(WS_GRID2, (maxcells + 1) * sizeof(u32), (void **)&cursor));
     errflag = (u32 *)(ctx->d_scalars + 8);
 
     IVX_HIP(ctx, hipMemsetAsync(errflag, 0, sizeof(u32), st));
     IVX_HIP(ctx, hipMemsetAsync(binstart, 0, (maxcells + 1) * sizeof(u32), st));
     IVX_HIP(ctx, hipMemsetAsync(cursor, 0, (maxcells + 1) * sizeof(u32), st));
-    const u32 ginit = ((nkeys > HDR_WORDS ? nkeys : HDR_WORDS) + BT - 1) / BT;
-    hipLaunchKernelGGL(k_init_keystats, dim3(ginit), dim3(BT), 0, st, kmin, kmax, kcnt, nkeys, hdr);
+    IVX_HIP(ctx, hipMemsetAsync(hdr, 0, HDR_WORDS * sizeof(u32), st));
+    IVX_TRY(ivx_keystats(ctx, key, s, n, nkeys, kmin, kmax, kcnt, errflag));
     const u32 grid = ivx_stream_grid(n, BT * 8, 1024);
-    const size_t shm = nkeys <= KEYS_IN_LDS ? (size_t)nkeys * 12 : 0;
-    hipLaunchKernelGGL(k_keystats, dim3(grid), dim3(BT), shm, st, key, s, n, nkeys, kmin, kmax, kcnt, errflag);
     hipLaunchKernelGGL(k_join_layout, dim3(1), dim3(1024), 0, st, kmin, kmax, kcnt, nkeys, n, origin, span, lbase, hdr, maxcells);
     hipLaunchKernelGGL(k_join_count, dim3(grid), dim3(BT), 0, st, key, s, e, n, nkeys, origin, lbase, hdr, binstart);
     IVX_TRY(ivx_scan_exclusive_u32(ctx, binstart, maxcells + 1));

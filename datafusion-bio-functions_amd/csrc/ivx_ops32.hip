@@ -1,0 +1,506 @@
+// ivx_ops32.hip -- count_overlaps, coverage and nearest on int32 coordinates:
+// index builds (device radix sort + scans + rank grids) and the probe kernels.
+//
+//   a4 CountOverlapIndex::new/query_count   interval_tree.rs:20-50, get_count_stream :249-267
+//   a5 merge_intervals + get_coverage       interval_tree.rs:52-73, :145-152, get_stream :181-208
+//   a6 NearestIntervalIndex                 nearest_index.rs:44-266, get_nearest_stream nearest.rs:330-456
+//
+// All kernels are integer/index work bound by random L2/HBM access latency; each
+// probe row costs a handful of dependent gathers instead of the reference's
+// O(log n) binary searches.
+#include "ivx_grid.hpp"
+#include "ivx_runs.hpp"
+#include "ivx_scan.hpp"
+#include "ivx_sort.hpp"
+
+namespace {
+
+constexpr int OT = 256;
+constexpr u32 SIGN = 0x80000000u;
+
+__device__ __forceinline__ i32 wadd(i32 a, i32 b) { return (i32)((u32)a + (u32)b); }
+__device__ __forceinline__ i32 wsub(i32 a, i32 b) { return (i32)((u32)a - (u32)b); }
+
+ivx_status check_keyflag(ivx_ctx *ctx)
+{
+    u32 *errflag = (u32 *)(ctx->d_scalars + 8);
+    IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 8, errflag, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+    IVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (*(u32 *)(ctx->h_scalars + 8)) return ctx->fail(IVX_ERR_INVALID, "build key id >= n_keys");
+    return IVX_OK;
+}
+
+// ======================================================================= a4
+
+__global__ __launch_bounds__(OT) void k_probe_count(RankGridView gs, RankGridView ge, const u32 *__restrict__ pkey,
+                                                    const i32 *__restrict__ ps, const i32 *__restrict__ pe, u64 n,
+                                                    int strict, i64 *__restrict__ out)
+{
+    const u32 shs = gs.hdr[0], she = ge.hdr[0];
+    for (u64 i = (u64)blockIdx.x * OT + threadIdx.x; i < n; i += (u64)gridDim.x * OT) {
+        const u32 k = pkey ? pkey[i] : 0u;
+        i32 qs = ps[i], qe = pe[i];
+        if (strict) { qs = wadd(qs, 1); qe = wsub(qe, 1); }              // interval_tree.rs:253-256
+        i64 c = 0;
+        if (k < gs.nkeys && gs.kcnt[k] != 0 && !(qe < qs)) {             // :42-44, unknown contig -> 0 (:265)
+            const u32 started = grid_rank_le(gs, shs, k, qe);            // starts.partition_point(|v| v <= end)
+            const u32 ended_before = grid_rank_lt(ge, she, k, qs);       // ends.partition_point(|v| v < start)
+            c = (i64)started - (i64)ended_before;
+        }
+        out[i] = c;
+    }
+}
+
+// ======================================================================= a5
+
+// pack rows for the stable sort by (key, first): w0 = first(biased)<<32 | end bits, w1 = key<<32 | row
+__global__ __launch_bounds__(OT) void k_pack_first(const u32 *__restrict__ key, const i32 *__restrict__ s, const i32 *__restrict__ e,
+                                                   u64 n, u32 nkeys, u64 *w0, u64 *w1, u32 *flags)
+{
+    const u64 i = (u64)blockIdx.x * OT + threadIdx.x;
+    if (i >= n) return;
+    const u32 k = key ? key[i] : 0u;
+    if (k >= nkeys) flags[0] = 1;
+    if (e[i] < s[i]) flags[1] = 1;
+    w0[i] = ((u64)((u32)s[i] ^ SIGN) << 32) | (u32)e[i];
+    w1[i] = ((u64)k << 32) | (u32)i;
+}
+
+__global__ __launch_bounds__(OT) void k_unpack_first(const u64 *__restrict__ w0, const u64 *__restrict__ w1, u64 n,
+                                                     u32 *ks, i64 *ss, i64 *es)
+{
+    const u64 i = (u64)blockIdx.x * OT + threadIdx.x;
+    if (i >= n) return;
+    ks[i] = (u32)(w1[i] >> 32);
+    ss[i] = (i64)(i32)((u32)(w0[i] >> 32) ^ SIGN);
+    es[i] = (i64)(i32)(u32)w0[i];
+}
+
+// merged nodes (i64 from the run sweep) -> i32 columns + per-node weight max(1, last-first) (i32 wrapping, :148)
+__global__ __launch_bounds__(OT) void k_nodes(const i64 *__restrict__ rs, const i64 *__restrict__ re, u64 m,
+                                              i32 *nfirst, i32 *nlast, u64 *w)
+{
+    const u64 j = (u64)blockIdx.x * OT + threadIdx.x;
+    if (j > m) return;
+    if (j == m) { w[j] = 0; return; }
+    const i32 f = (i32)rs[j], l = (i32)re[j];
+    nfirst[j] = f; nlast[j] = l;
+    const i32 d = wsub(l, f);
+    w[j] = (u64)(i64)(d > 1 ? d : 1);
+}
+
+__device__ __forceinline__ i32 cov_term(i32 qs, i32 qe, i32 first, i32 last)
+{   // interval_tree.rs:148  max(1, min(end + 1, node.last) - max(start - 1, node.first))
+    const i32 a = wadd(qe, 1), b = wsub(qs, 1);
+    const i32 hi = a < last ? a : last;
+    const i32 lo = b > first ? b : first;
+    const i32 d = wsub(hi, lo);
+    return d > 1 ? d : 1;
+}
+
+__global__ __launch_bounds__(OT) void k_probe_coverage(CoverageView cv, const u32 *__restrict__ pkey,
+                                                       const i32 *__restrict__ ps, const i32 *__restrict__ pe, u64 n,
+                                                       int strict, i64 *__restrict__ out)
+{
+    const u32 shf = cv.first.hdr[0], shl = cv.last.hdr[0];
+    for (u64 i = (u64)blockIdx.x * OT + threadIdx.x; i < n; i += (u64)gridDim.x * OT) {
+        const u32 k = pkey ? pkey[i] : 0u;
+        i32 qs = ps[i], qe = pe[i];
+        if (strict) { qs = wadd(qs, 1); qe = wsub(qe, 1); }              // :185-188
+        i32 cov = 0;
+        if (k < cv.first.nkeys && cv.first.kcnt[k] != 0) {
+            // merged nodes are disjoint and ascending: those with first <= qe are a prefix [..hi),
+            // those with last >= qs a suffix [lo..): the overlapping ones are [lo,hi)
+            const u32 hi = grid_rank_le(cv.first, shf, k, qe);
+            const u32 lo = grid_rank_lt(cv.last, shl, k, qs);
+            if (lo < hi) {
+                if (qs == INT32_MIN || qe == INT32_MAX || hi - lo <= 2) {
+                    for (u32 j = lo; j < hi; j++) cov = wadd(cov, cov_term(qs, qe, cv.nfirst[j], cv.nlast[j]));
+                } else {
+                    // interior nodes lie inside [qs,qe]: their term is max(1, last-first) = pw[j+1]-pw[j]
+                    const i64 inner = cv.pw[hi - 1] - cv.pw[lo + 1];
+                    cov = wadd(cov_term(qs, qe, cv.nfirst[lo], cv.nlast[lo]), cov_term(qs, qe, cv.nfirst[hi - 1], cv.nlast[hi - 1]));
+                    cov = (i32)((u32)cov + (u32)(u64)inner);
+                }
+            }
+        }
+        out[i] = (i64)cov;                                               // :207 `count as i64`
+    }
+}
+
+// ======================================================================= a6
+
+__global__ __launch_bounds__(OT) void k_pack_se(const u32 *__restrict__ key, const i32 *__restrict__ s, const i32 *__restrict__ e,
+                                                u64 n, u32 nkeys, int end_major, u64 *w0, u64 *w1, u32 *flags)
+{
+    const u64 i = (u64)blockIdx.x * OT + threadIdx.x;
+    if (i >= n) return;
+    const u32 k = key ? key[i] : 0u;
+    if (k >= nkeys) flags[0] = 1;
+    const u64 sb = (u32)s[i] ^ SIGN, eb = (u32)e[i] ^ SIGN;
+    w0[i] = end_major ? ((eb << 32) | sb) : ((sb << 32) | eb);
+    w1[i] = ((u64)k << 32) | (u32)i;
+}
+
+__global__ __launch_bounds__(OT) void k_unpack_se(const u64 *__restrict__ w0, const u64 *__restrict__ w1, u64 n, int end_major,
+                                                  u32 *ks, i32 *ss, i32 *es, u32 *rows)
+{
+    const u64 i = (u64)blockIdx.x * OT + threadIdx.x;
+    if (i >= n) return;
+    const i32 hi = (i32)((u32)(w0[i] >> 32) ^ SIGN), lo = (i32)((u32)w0[i] ^ SIGN);
+    ks[i] = (u32)(w1[i] >> 32);
+    rows[i] = (u32)w1[i];
+    ss[i] = end_major ? lo : hi;
+    es[i] = end_major ? hi : lo;
+}
+
+struct SegMax { i32 v; u32 head; };
+struct SegMaxOp {
+    using T = SegMax;
+    __host__ __device__ static T identity() { T t; t.v = INT32_MIN; t.head = 0; return t; }
+    __device__ static T combine(const T &a, const T &b)
+    {
+        T r; r.head = a.head | b.head; r.v = b.head ? b.v : (a.v > b.v ? a.v : b.v); return r;
+    }
+    __device__ static T shfl_up(const T &x, int d)
+    {
+        T r; r.v = __shfl_up(x.v, d, IVX_WAVE); r.head = __shfl_up(x.head, d, IVX_WAVE); return r;
+    }
+};
+
+__global__ __launch_bounds__(OT) void k_segmax_in(const u32 *__restrict__ ks, const i32 *__restrict__ es, u64 n, SegMax *sm)
+{
+    const u64 i = (u64)blockIdx.x * OT + threadIdx.x;
+    if (i >= n) return;
+    SegMax t; t.v = es[i]; t.head = (i == 0 || ks[i] != ks[i - 1]) ? 1u : 0u;
+    sm[i] = t;
+}
+__global__ __launch_bounds__(OT) void k_segmax_out(const SegMax *__restrict__ sm, u64 n, i32 *pmax)
+{
+    const u64 i = (u64)blockIdx.x * OT + threadIdx.x;
+    if (i < n) pmax[i] = sm[i].v;
+}
+
+struct Cand { i32 s, e; u32 row; };
+
+__device__ __forceinline__ i64 cand_dist(i32 qs, i32 qe, i32 s, i32 e)
+{   // nearest_index.rs:252-260
+    if (qe < s) return (i64)s - (i64)qe;
+    if (e < qs) return (i64)qs - (i64)e;
+    return 0;
+}
+__device__ __forceinline__ int cmp_meta(const Cand &a, const Cand &b)
+{   // :245-250
+    if (a.s != b.s) return a.s < b.s ? -1 : 1;
+    if (a.e != b.e) return a.e < b.e ? -1 : 1;
+    return a.row < b.row ? -1 : (a.row > b.row ? 1 : 0);
+}
+__device__ __forceinline__ int cmp_cand(i32 qs, i32 qe, const Cand &a, const Cand &b)
+{   // :262-266
+    const i64 ad = cand_dist(qs, qe, a.s, a.e), bd = cand_dist(qs, qe, b.s, b.e);
+    if (ad != bd) return ad < bd ? -1 : 1;
+    return cmp_meta(a, b);
+}
+
+struct NearestCtx {
+    NearestView nv; u32 sh_s, sh_e, sh_p;
+    __device__ __forceinline__ Cand by_start(u32 j) const { Cand c; c.s = nv.s_start[j]; c.e = nv.s_end[j]; c.row = nv.s_row[j]; return c; }
+    __device__ __forceinline__ Cand by_end(u32 j) const { Cand c; c.s = nv.e_start[j]; c.e = nv.e_end[j]; c.row = nv.e_row[j]; return c; }
+};
+
+// nearest_index.rs:222-234; positions are absolute (key offset included)
+__device__ __forceinline__ bool first_overlap(const NearestCtx &x, u32 k, u32 off, i32 qs, i32 qe, u32 *plen_abs, Cand *out)
+{
+    const u32 pend = grid_rank_le(x.nv.by_start, x.sh_s, k, qe);     // by_start.partition_point(first <= end)
+    *plen_abs = pend;
+    if (qe < qs) return false;
+    if (pend == off || x.nv.pmaxv[pend - 1] < qs) return false;
+    u32 idx = grid_rank_lt(x.nv.pmax, x.sh_p, k, qs);                 // prefix_max_end[..plen].partition_point(< start)
+    if (idx > pend) idx = pend;
+    *out = x.by_start(idx);
+    return true;
+}
+
+__global__ __launch_bounds__(OT) void k_probe_nearest1(NearestView nv, const u32 *__restrict__ pkey, const i32 *__restrict__ ps,
+                                                       const i32 *__restrict__ pe, u64 n, int strict, int include_overlaps,
+                                                       u32 *__restrict__ ob, u32 *__restrict__ op, i64 *__restrict__ od)
+{
+    NearestCtx x; x.nv = nv; x.sh_s = nv.by_start.hdr[0]; x.sh_e = nv.by_end.hdr[0]; x.sh_p = nv.pmax.hdr[0];
+    for (u64 i = (u64)blockIdx.x * OT + threadIdx.x; i < n; i += (u64)gridDim.x * OT) {
+        const u32 k = pkey ? pkey[i] : 0u;
+        const i32 rs = ps[i], re = pe[i];
+        i32 qs = rs, qe = re;
+        if (strict) { qs = wadd(qs, 1); qe = wsub(qe, 1); }              // nearest.rs:341-344
+        bool found = false;
+        Cand best{};
+        if (k < nv.by_start.nkeys && nv.by_start.kcnt[k] != 0) {
+            const u32 off = nv.by_start.koff[k], cnt = nv.by_start.kcnt[k];
+            u32 pend;
+            if (include_overlaps) found = first_overlap(x, k, off, qs, qe, &pend, &best);
+            else pend = grid_rank_le(nv.by_start, x.sh_s, k, qe);
+            if (!found) {                                                // nearest_non_overlap_one :192-220
+                const u32 li = grid_rank_lt(nv.by_end, x.sh_e, k, qs);   // by_end.partition_point(last < start)
+                const bool hl = li > off, hr = pend < off + cnt;
+                if (hl && hr) {
+                    const Cand l = x.by_end(li - 1), r = x.by_start(pend);
+                    best = cmp_cand(qs, qe, l, r) <= 0 ? l : r; found = true;
+                } else if (hl) { best = x.by_end(li - 1); found = true; }
+                else if (hr) { best = x.by_start(pend); found = true; }
+            }
+        }
+        ob[i] = found ? best.row : IVX_NULL_IDX;
+        op[i] = (u32)i;
+        if (od) od[i] = found ? cand_dist(rs, re, best.s, best.e) : -1;  // raw coordinates, nearest.rs:367-374
+    }
+}
+
+// k > 1: up to k candidates per probe row into tmp[i*k ..], rows-per-probe into cnt[i]
+__global__ __launch_bounds__(OT) void k_probe_nearestk(NearestView nv, const u32 *__restrict__ pkey, const i32 *__restrict__ ps,
+                                                       const i32 *__restrict__ pe, u64 n, int strict, int include_overlaps, u32 kk,
+                                                       u32 *__restrict__ tmp, u32 *__restrict__ cnt)
+{
+    NearestCtx x; x.nv = nv; x.sh_s = nv.by_start.hdr[0]; x.sh_e = nv.by_end.hdr[0]; x.sh_p = nv.pmax.hdr[0];
+    for (u64 i = (u64)blockIdx.x * OT + threadIdx.x; i < n; i += (u64)gridDim.x * OT) {
+        const u32 k = pkey ? pkey[i] : 0u;
+        i32 qs = ps[i], qe = pe[i];
+        if (strict) { qs = wadd(qs, 1); qe = wsub(qe, 1); }
+        u32 *mine = tmp + i * (u64)kk;                                   // holds indices into by_start/by_end: bit31 = by_end
+        u32 found = 0;
+        if (k < nv.by_start.nkeys && nv.by_start.kcnt[k] != 0) {
+            const u32 off = nv.by_start.koff[k], cnt_k = nv.by_start.kcnt[k];
+            const u32 pend = grid_rank_le(nv.by_start, x.sh_s, k, qe);
+            // seen-set of nearest_k (:122, :134, :186): rows already taken
+            auto seen = [&](u32 row) { for (u32 q = 0; q < found; q++) { const u32 t = mine[q]; const u32 r = (t >> 31) ? nv.e_row[t & 0x7FFFFFFFu] : nv.s_row[t]; if (r == row) return true; } return false; };
+            if (include_overlaps && pend > off && nv.pmaxv[pend - 1] >= qs) {
+                // all overlaps in (start,end,row) order = by_start order filtered by end >= qs (:125-137)
+                u32 j = grid_rank_lt(nv.pmax, x.sh_p, k, qs);
+                for (; j < pend && found < kk; j++)
+                    if (nv.s_end[j] >= qs && !seen(nv.s_row[j])) mine[found++] = j;
+            }
+            if (found < kk) {                                            // alternate the two cursors (:144-189)
+                u32 li = grid_rank_lt(nv.by_end, x.sh_e, k, qs), ri = pend;
+                while (found < kk) {
+                    const bool hl = li > off, hr = ri < off + cnt_k;
+                    if (!hl && !hr) break;
+                    bool take_left;
+                    if (hl && hr) take_left = cmp_cand(qs, qe, x.by_end(li - 1), x.by_start(ri)) <= 0;
+                    else take_left = hl;
+                    u32 tag; Cand c;
+                    if (take_left) { li--; c = x.by_end(li); tag = li | 0x80000000u; }
+                    else { c = x.by_start(ri); tag = ri; ri++; }
+                    if (!include_overlaps && cand_dist(qs, qe, c.s, c.e) == 0) continue;
+                    if (!seen(c.row)) mine[found++] = tag;
+                }
+            }
+        }
+        cnt[i] = found;
+    }
+}
+
+__global__ __launch_bounds__(OT) void k_rows_of(const u32 *__restrict__ cnt, u64 n, u64 *rows)
+{
+    const u64 i = (u64)blockIdx.x * OT + threadIdx.x;
+    if (i < n) rows[i] = cnt[i] ? cnt[i] : 1u;
+    if (i == n) rows[i] = 0;
+}
+
+__global__ __launch_bounds__(OT) void k_nearest_emit(NearestView nv, const i32 *__restrict__ ps, const i32 *__restrict__ pe, u64 n, u32 kk,
+                                                     const u32 *__restrict__ tmp, const u32 *__restrict__ cnt, const u64 *__restrict__ offs,
+                                                     u64 cap, u32 *ob, u32 *op, i64 *od)
+{
+    for (u64 i = (u64)blockIdx.x * OT + threadIdx.x; i < n; i += (u64)gridDim.x * OT) {
+        const u32 c = cnt[i];
+        u64 at = offs[i];
+        if (c == 0) {                                                    // nearest.rs:424-430
+            if (at < cap) { ob[at] = IVX_NULL_IDX; op[at] = (u32)i; if (od) od[at] = -1; }
+            continue;
+        }
+        for (u32 q = 0; q < c; q++, at++) {
+            if (at >= cap) break;
+            const u32 t = tmp[i * (u64)kk + q];
+            const u32 j = t & 0x7FFFFFFFu;
+            const bool e = t >> 31;
+            const i32 s_ = e ? nv.e_start[j] : nv.s_start[j], e_ = e ? nv.e_end[j] : nv.s_end[j];
+            ob[at] = e ? nv.e_row[j] : nv.s_row[j];
+            op[at] = (u32)i;
+            if (od) od[at] = cand_dist(ps[i], pe[i], s_, e_);
+        }
+    }
+}
+
+u32 grid1(u64 n) { return (u32)((n + OT - 1) / OT); }
+
+// sorted (key, start, end, row) columns from raw ones; end_major: order by (key,end,start,row)
+ivx_status sorted_columns(ivx_ctx *ctx, const u32 *key, const i32 *s, const i32 *e, u64 n, u32 nkeys, int end_major,
+                          u32 *ks, i32 *ss, i32 *es, u32 *rows)
+{
+    if (n == 0) return IVX_OK;
+    u64 *a[2], *b[2];
+    IVX_TRY(ctx->get_scratch(WS_SA0, n * sizeof(u64), (void **)&a[0]));
+    IVX_TRY(ctx->get_scratch(WS_SA1, n * sizeof(u64), (void **)&a[1]));
+    IVX_TRY(ctx->get_scratch(WS_SB0, n * sizeof(u64), (void **)&b[0]));
+    IVX_TRY(ctx->get_scratch(WS_SB1, n * sizeof(u64), (void **)&b[1]));
+    u32 *flags = (u32 *)(ctx->d_scalars + 8);
+    hipLaunchKernelGGL(k_pack_se, dim3(grid1(n)), dim3(OT), 0, ctx->stream, key, s, e, n, nkeys, end_major, a[0], a[1], flags);
+    const ivx_sort_field f[3] = {{0, 0, 32}, {0, 32, 64}, {1, 32, 64}};
+    int in_b = 0;
+    IVX_TRY(ivx_radix_sort(ctx, 2, a, b, n, f, 3, &in_b));
+    u64 *const *r = in_b ? b : a;
+    hipLaunchKernelGGL(k_unpack_se, dim3(grid1(n)), dim3(OT), 0, ctx->stream, (const u64 *)r[0], (const u64 *)r[1], n, end_major, ks, ss, es, rows);
+    IVX_HIP(ctx, hipGetLastError());
+    return IVX_OK;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------- builds
+
+ivx_status ivx_count_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32 *s, const i32 *e, u64 n)
+{
+    IVX_HIP(ctx, hipMemsetAsync(ctx->d_scalars + 8, 0, sizeof(u64), ctx->stream));
+    IVX_TRY(ivx_grid_build(ctx, ix, key, s, n, ix->nkeys, &ix->gs));     // starts, sorted independently (:35)
+    IVX_TRY(ivx_grid_build(ctx, ix, key, e, n, ix->nkeys, &ix->ge));     // ends (:36)
+    return check_keyflag(ctx);
+}
+
+ivx_status ivx_coverage_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32 *s, const i32 *e, u64 n)
+{
+    hipStream_t st = ctx->stream;
+    const u32 nkeys = ix->nkeys;
+    u32 *flags = (u32 *)(ctx->d_scalars + 8);
+    IVX_HIP(ctx, hipMemsetAsync(flags, 0, sizeof(u64), st));
+    u64 m = 0;
+    i64 *rs = nullptr, *re = nullptr; u32 *rk = nullptr;
+    if (n) {
+        // stable sort by (key, first): ties keep input order (interval_tree.rs:57 sort_by is stable)
+        u64 *a[2], *b[2];
+        IVX_TRY(ctx->get_scratch(WS_SA0, n * sizeof(u64), (void **)&a[0]));
+        IVX_TRY(ctx->get_scratch(WS_SA1, n * sizeof(u64), (void **)&a[1]));
+        IVX_TRY(ctx->get_scratch(WS_SB0, n * sizeof(u64), (void **)&b[0]));
+        IVX_TRY(ctx->get_scratch(WS_SB1, n * sizeof(u64), (void **)&b[1]));
+        hipLaunchKernelGGL(k_pack_first, dim3(grid1(n)), dim3(OT), 0, st, key, s, e, n, nkeys, a[0], a[1], flags);
+        const ivx_sort_field f[2] = {{0, 32, 64}, {1, 32, 64}};
+        int in_b = 0;
+        IVX_TRY(ivx_radix_sort(ctx, 2, a, b, n, f, 2, &in_b));
+        u64 *const *r = in_b ? b : a;
+        u32 *ks; i64 *ss, *es;
+        IVX_TRY(ctx->get_scratch(WS_T0, n * sizeof(u32), (void **)&ks));
+        IVX_TRY(ctx->get_scratch(WS_T1, n * sizeof(i64), (void **)&ss));
+        IVX_TRY(ctx->get_scratch(WS_T2, n * sizeof(i64), (void **)&es));
+        hipLaunchKernelGGL(k_unpack_first, dim3(grid1(n)), dim3(OT), 0, st, (const u64 *)r[0], (const u64 *)r[1], n, ks, ss, es);
+        IVX_TRY(ctx->get_scratch(WS_T3, n * sizeof(u32), (void **)&rk));
+        IVX_TRY(ctx->get_scratch(WS_T4, n * sizeof(i64), (void **)&rs));
+        IVX_TRY(ctx->get_scratch(WS_T8, n * sizeof(i64), (void **)&re));
+        ivx_runs_out ro{rk, rs, re, nullptr};
+        IVX_TRY(ivx_merge_runs(ctx, ks, ss, es, n, 0, 0, ro, &m));       // first <= current.last merges (:63)
+    }
+    IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 8, flags, sizeof(u64), hipMemcpyDeviceToHost, st));
+    IVX_HIP(ctx, hipStreamSynchronize(st));
+    const u32 *hf = (const u32 *)(ctx->h_scalars + 8);
+    if (hf[0]) return ctx->fail(IVX_ERR_INVALID, "build key id >= n_keys");
+    if (hf[1]) return ctx->fail(IVX_ERR_UNSUPPORTED, "coverage: a build interval has end < start (the reference's result for it is unspecified)");
+    i32 *nfirst, *nlast; u64 *pw;
+    IVX_TRY(ivx_index_alloc(ctx, ix, (m ? m : 1) * sizeof(i32), (void **)&nfirst));
+    IVX_TRY(ivx_index_alloc(ctx, ix, (m ? m : 1) * sizeof(i32), (void **)&nlast));
+    IVX_TRY(ivx_index_alloc(ctx, ix, (m + 1) * sizeof(u64), (void **)&pw));
+    hipLaunchKernelGGL(k_nodes, dim3(grid1(m + 1)), dim3(OT), 0, st, (const i64 *)rs, (const i64 *)re, m, nfirst, nlast, pw);
+    IVX_TRY(ivx_scan_exclusive_u64(ctx, pw, m + 1));
+    IVX_TRY(ivx_grid_build(ctx, ix, rk, nfirst, m, nkeys, &ix->cv.first));
+    IVX_TRY(ivx_grid_build(ctx, ix, rk, nlast, m, nkeys, &ix->cv.last));
+    ix->cv.nfirst = nfirst; ix->cv.nlast = nlast; ix->cv.pw = (const i64 *)pw;
+    IVX_HIP(ctx, hipGetLastError());
+    return IVX_OK;
+}
+
+ivx_status ivx_nearest_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32 *s, const i32 *e, u64 n)
+{
+    hipStream_t st = ctx->stream;
+    const u32 nkeys = ix->nkeys;
+    IVX_HIP(ctx, hipMemsetAsync(ctx->d_scalars + 8, 0, sizeof(u64), st));
+    const u64 na = n ? n : 1;
+    i32 *s_start, *s_end, *e_start, *e_end, *pmaxv; u32 *s_row, *e_row, *ks, *ke;
+    IVX_TRY(ivx_index_alloc(ctx, ix, na * 4, (void **)&s_start));
+    IVX_TRY(ivx_index_alloc(ctx, ix, na * 4, (void **)&s_end));
+    IVX_TRY(ivx_index_alloc(ctx, ix, na * 4, (void **)&s_row));
+    IVX_TRY(ivx_index_alloc(ctx, ix, na * 4, (void **)&e_start));
+    IVX_TRY(ivx_index_alloc(ctx, ix, na * 4, (void **)&e_end));
+    IVX_TRY(ivx_index_alloc(ctx, ix, na * 4, (void **)&e_row));
+    IVX_TRY(ivx_index_alloc(ctx, ix, na * 4, (void **)&pmaxv));
+    IVX_TRY(ctx->get_scratch(WS_T0, na * 4, (void **)&ks));
+    IVX_TRY(ctx->get_scratch(WS_T1, na * 4, (void **)&ke));
+    IVX_TRY(sorted_columns(ctx, key, s, e, n, nkeys, 0, ks, s_start, s_end, s_row));   // (start,end,row)  nearest_index.rs:50-55
+    IVX_TRY(sorted_columns(ctx, key, s, e, n, nkeys, 1, ke, e_start, e_end, e_row));   // (end,start,row)  :77-82
+    if (n) {
+        SegMax *sm;
+        IVX_TRY(ctx->get_scratch(WS_T2, n * sizeof(SegMax), (void **)&sm));
+        hipLaunchKernelGGL(k_segmax_in, dim3(grid1(n)), dim3(OT), 0, st, (const u32 *)ks, (const i32 *)s_end, n, sm);
+        IVX_TRY(ivxscan::inclusive<SegMaxOp>(ctx, sm, n));                               // prefix_max_end :58-63
+        hipLaunchKernelGGL(k_segmax_out, dim3(grid1(n)), dim3(OT), 0, st, (const SegMax *)sm, n, pmaxv);
+    }
+    IVX_TRY(ivx_grid_build(ctx, ix, ks, s_start, n, nkeys, &ix->nv.by_start));
+    IVX_TRY(ivx_grid_build(ctx, ix, ke, e_end, n, nkeys, &ix->nv.by_end));
+    IVX_TRY(ivx_grid_build(ctx, ix, ks, pmaxv, n, nkeys, &ix->nv.pmax));
+    ix->nv.s_start = s_start; ix->nv.s_end = s_end; ix->nv.s_row = s_row;
+    ix->nv.e_start = e_start; ix->nv.e_end = e_end; ix->nv.e_row = e_row; ix->nv.pmaxv = pmaxv;
+    IVX_HIP(ctx, hipGetLastError());
+    return check_keyflag(ctx);
+}
+
+// ---------------------------------------------------------------------------- probes (called from ivx_capi.hip)
+
+ivx_status ivx_count_probe(ivx_ctx *ctx, const ivx_index *ix, const u32 *key, const i32 *s, const i32 *e, u64 n, int strict, i64 *out)
+{
+    if (n == 0) return IVX_OK;
+    hipLaunchKernelGGL(k_probe_count, dim3(ivx_stream_grid(n, OT * 4)), dim3(OT), 0, ctx->stream, ix->gs, ix->ge, key, s, e, n, strict, out);
+    IVX_HIP(ctx, hipGetLastError());
+    return IVX_OK;
+}
+
+ivx_status ivx_coverage_probe(ivx_ctx *ctx, const ivx_index *ix, const u32 *key, const i32 *s, const i32 *e, u64 n, int strict, i64 *out)
+{
+    if (n == 0) return IVX_OK;
+    hipLaunchKernelGGL(k_probe_coverage, dim3(ivx_stream_grid(n, OT * 4)), dim3(OT), 0, ctx->stream, ix->cv, key, s, e, n, strict, out);
+    IVX_HIP(ctx, hipGetLastError());
+    return IVX_OK;
+}
+
+ivx_status ivx_nearest_probe(ivx_ctx *ctx, const ivx_index *ix, const u32 *key, const i32 *s, const i32 *e, u64 n,
+                             int strict, u32 k, int include_overlaps, u32 *ob, u32 *op, i64 *od, u64 cap, u64 *rows)
+{
+    *rows = 0;
+    if (n == 0) return IVX_OK;
+    hipStream_t st = ctx->stream;
+    if (k <= 1) {
+        // k == 0 yields no candidate, i.e. one NULL row per probe row, like k == 1 on an empty index (nearest_index.rs:111)
+        if (cap < n) { *rows = n; return ctx->fail(IVX_ERR_CAPACITY, "nearest: output buffers too small"); }
+        if (k == 1) {
+            hipLaunchKernelGGL(k_probe_nearest1, dim3(ivx_stream_grid(n, OT * 4)), dim3(OT), 0, st, ix->nv, key, s, e, n, strict, include_overlaps, ob, op, od);
+        } else {
+            u32 *cnt; u64 *offs;
+            IVX_TRY(ctx->get_scratch(WS_T3, n * sizeof(u32), (void **)&cnt));
+            IVX_TRY(ctx->get_scratch(WS_T4, (n + 1) * sizeof(u64), (void **)&offs));
+            IVX_HIP(ctx, hipMemsetAsync(cnt, 0, n * sizeof(u32), st));
+            hipLaunchKernelGGL(k_rows_of, dim3(grid1(n + 1)), dim3(OT), 0, st, (const u32 *)cnt, n, offs);
+            IVX_TRY(ivx_scan_exclusive_u64(ctx, offs, n + 1));
+            hipLaunchKernelGGL(k_nearest_emit, dim3(ivx_stream_grid(n, OT * 4)), dim3(OT), 0, st, ix->nv, s, e, n, 1u, (const u32 *)cnt, (const u32 *)cnt, (const u64 *)offs, cap, ob, op, od);
+        }
+        IVX_HIP(ctx, hipGetLastError());
+        *rows = n;
+        return IVX_OK;
+    }
+    u32 *tmp, *cnt; u64 *offs;
+    IVX_TRY(ctx->get_scratch(WS_T2, n * (u64)k * sizeof(u32), (void **)&tmp));
+    IVX_TRY(ctx->get_scratch(WS_T3, n * sizeof(u32), (void **)&cnt));
+    IVX_TRY(ctx->get_scratch(WS_T4, (n + 1) * sizeof(u64), (void **)&offs));
+    hipLaunchKernelGGL(k_probe_nearestk, dim3(ivx_stream_grid(n, OT * 2)), dim3(OT), 0, st, ix->nv, key, s, e, n, strict, include_overlaps, k, tmp, cnt);
+    hipLaunchKernelGGL(k_rows_of, dim3(grid1(n + 1)), dim3(OT), 0, st, (const u32 *)cnt, n, offs);
+    IVX_TRY(ivx_scan_exclusive_u64(ctx, offs, n + 1));
+    IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 3, offs + n, sizeof(u64), hipMemcpyDeviceToHost, st));
+    IVX_HIP(ctx, hipStreamSynchronize(st));
+    const u64 total = ctx->h_scalars[3];
+    *rows = total;
+    if (total > cap) return ctx->fail(IVX_ERR_CAPACITY, "nearest: output buffers too small");
+    hipLaunchKernelGGL(k_nearest_emit, dim3(ivx_stream_grid(n, OT * 2)), dim3(OT), 0, st, ix->nv, s, e, n, k, (const u32 *)tmp, (const u32 *)cnt, (const u64 *)offs, cap, ob, op, od);
+    IVX_HIP(ctx, hipGetLastError());
+    return IVX_OK;
+}

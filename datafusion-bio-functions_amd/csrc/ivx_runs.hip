@@ -1,0 +1,139 @@
+// ivx_runs.hip -- interval-merge sweep as two device-wide scans (see ivx_runs.hpp).
+#include "ivx_runs.hpp"
+#include "ivx_scan.hpp"
+
+namespace {
+
+constexpr int RT = 256;
+
+// cur_end transfer function:  konst ? (x -> c)  :  (x -> x < M ? c : x)
+struct MState { i64 M; i64 c; u32 konst; u32 pad; };
+
+struct MergeOp {
+    using T = MState;
+    __host__ __device__ static T identity() { T t; t.M = INT64_MIN; t.c = INT64_MIN; t.konst = 0; t.pad = 0; return t; }
+    // a covers the earlier rows: result = b o a
+    __device__ static T combine(const T &a, const T &b)
+    {
+        if (b.konst) return b;
+        T r;
+        r.pad = 0;
+        if (a.konst) { r.konst = 1; r.M = 0; r.c = a.c < b.M ? b.c : a.c; return r; }
+        r.konst = 0;
+        if (b.M > a.M) { r.M = b.M; r.c = b.c; }
+        else { r.M = a.M; r.c = a.c < b.M ? b.c : a.c; }
+        return r;
+    }
+    __device__ static T shfl_up(const T &v, int d)
+    {
+        T r;
+        r.M = __shfl_up(v.M, d, IVX_WAVE); r.c = __shfl_up(v.c, d, IVX_WAVE);
+        r.konst = __shfl_up(v.konst, d, IVX_WAVE); r.pad = 0;
+        return r;
+    }
+};
+
+struct HeadAcc { u32 heads; u32 last_head; };       // #run heads so far, index of the latest one
+struct HeadOp {
+    using T = HeadAcc;
+    __host__ __device__ static T identity() { T t; t.heads = 0; t.last_head = 0; return t; }
+    __device__ static T combine(const T &a, const T &b)
+    {
+        T r; r.heads = a.heads + b.heads; r.last_head = a.last_head > b.last_head ? a.last_head : b.last_head; return r;
+    }
+    __device__ static T shfl_up(const T &v, int d)
+    {
+        T r; r.heads = __shfl_up(v.heads, d, IVX_WAVE); r.last_head = __shfl_up(v.last_head, d, IVX_WAVE); return r;
+    }
+};
+
+__device__ __forceinline__ i64 sat_add(i64 a, i64 b)
+{
+    i64 r;
+    if (__builtin_add_overflow(a, b, &r)) return b > 0 ? INT64_MAX : INT64_MIN;
+    return r;
+}
+__device__ __forceinline__ i64 sat_sub_floor(i64 a, i64 b)     // b >= 0: only underflow is possible
+{
+    i64 r;
+    if (__builtin_sub_overflow(a, b, &r)) return INT64_MIN;
+    return r;
+}
+
+// merge.rs:291-296:  s <= cur_end (+) min_dist   (strict: <), (+) saturating
+__device__ __forceinline__ bool merges(i64 s, i64 cur_end, i64 d, int strict)
+{
+    const i64 boundary = sat_add(cur_end, d);
+    return strict ? (s < boundary) : (s <= boundary);
+}
+
+__global__ __launch_bounds__(RT) void k_states(const u32 *__restrict__ ks, const i64 *__restrict__ ss, const i64 *__restrict__ es,
+                                               u64 n, i64 d, int strict, MState *__restrict__ st)
+{
+    const u64 i = (u64)blockIdx.x * RT + threadIdx.x;
+    if (i >= n) return;
+    const bool first = i == 0 || ks[i] != ks[i - 1];
+    const i64 s = ss[i], e = es[i];
+    MState t; t.pad = 0;
+    if (first || (strict && s == INT64_MAX)) {          // strict: s < anything never holds at i64::MAX
+        t.konst = 1; t.M = 0; t.c = e;
+    } else {
+        // smallest cur_end that still merges row i
+        const i64 T = strict ? sat_sub_floor(s + 1, d) : sat_sub_floor(s, d);
+        t.konst = 0; t.M = T > e ? T : e; t.c = e;
+    }
+    st[i] = t;
+}
+
+// after the inclusive scan st[i].c is cur_end after row i (always a constant function)
+__global__ __launch_bounds__(RT) void k_heads(const u32 *__restrict__ ks, const i64 *__restrict__ ss, const MState *__restrict__ st,
+                                              u64 n, i64 d, int strict, HeadAcc *__restrict__ ha)
+{
+    const u64 i = (u64)blockIdx.x * RT + threadIdx.x;
+    if (i >= n) return;
+    const bool head = i == 0 || ks[i] != ks[i - 1] || !merges(ss[i], st[i - 1].c, d, strict);
+    HeadAcc h; h.heads = head ? 1u : 0u; h.last_head = head ? (u32)i : 0u;
+    ha[i] = h;
+}
+
+__global__ __launch_bounds__(RT) void k_emit_runs(const u32 *__restrict__ ks, const i64 *__restrict__ ss, const MState *__restrict__ st,
+                                                  const HeadAcc *__restrict__ ha, u64 n, ivx_runs_out out, u64 *m)
+{
+    const u64 i = (u64)blockIdx.x * RT + threadIdx.x;
+    if (i >= n) return;
+    const HeadAcc h = ha[i];
+    const bool last = i + 1 == n || ha[i + 1].heads != h.heads;
+    if (last) {
+        const u32 id = h.heads - 1;
+        if (out.key) out.key[id] = ks[i];
+        if (out.start) out.start[id] = ss[h.last_head];
+        if (out.end) out.end[id] = st[i].c;
+        if (out.count) out.count[id] = (i64)(i - h.last_head + 1);
+    }
+    if (i + 1 == n) *m = h.heads;
+}
+
+}  // namespace
+
+ivx_status ivx_merge_runs(ivx_ctx *ctx, const u32 *ks, const i64 *ss, const i64 *es, u64 n,
+                          i64 min_dist, int strict, const ivx_runs_out &out, u64 *m)
+{
+    *m = 0;
+    if (n == 0) return IVX_OK;
+    hipStream_t stq = ctx->stream;
+    MState *st; HeadAcc *ha;
+    IVX_TRY(ctx->get_scratch(WS_T5, n * sizeof(MState), (void **)&st));
+    IVX_TRY(ctx->get_scratch(WS_T6, n * sizeof(HeadAcc), (void **)&ha));
+    const u32 grid = (u32)((n + RT - 1) / RT);
+    hipLaunchKernelGGL(k_states, dim3(grid), dim3(RT), 0, stq, ks, ss, es, n, min_dist, strict, st);
+    IVX_TRY(ivxscan::inclusive<MergeOp>(ctx, st, n));
+    hipLaunchKernelGGL(k_heads, dim3(grid), dim3(RT), 0, stq, ks, ss, (const MState *)st, n, min_dist, strict, ha);
+    IVX_TRY(ivxscan::inclusive<HeadOp>(ctx, ha, n));
+    u64 *d_m = ctx->d_scalars + 2;
+    hipLaunchKernelGGL(k_emit_runs, dim3(grid), dim3(RT), 0, stq, ks, ss, (const MState *)st, (const HeadAcc *)ha, n, out, d_m);
+    IVX_HIP(ctx, hipGetLastError());
+    IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 2, d_m, sizeof(u64), hipMemcpyDeviceToHost, stq));
+    IVX_HIP(ctx, hipStreamSynchronize(stq));
+    *m = ctx->h_scalars[2];
+    return IVX_OK;
+}

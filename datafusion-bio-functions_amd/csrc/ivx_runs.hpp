@@ -1,0 +1,27 @@
+// ivx_runs.hpp -- the interval-merge sweep as parallel scans (shared by merge() and coverage()).
+//
+// The reference walks the sorted rows of a contig with one running state
+// (cur_start, cur_end, cur_count): merge.rs:286-311 and merge_intervals,
+// interval_tree.rs:60-70.  `cur_end` after a row is a function of `cur_end`
+// before it:
+//        f_(s,e)(x) = merges(x) ? max(x, e) : e ,  merges(x) <=> x >= T(s)
+// which always has the shape  x < M ? c : x  with c <= M (M = max(T,e), c = e);
+// the first row of a contig is the constant function e.  That family is closed
+// under composition:
+//        (M2,c2) o (M1,c1) = M2 > M1 ? (M2, c2) : (M1, c1 < M2 ? c2 : c1)
+// so an inclusive scan with this operator yields cur_end after every row
+// without any serial walk.  Run heads, run ids and run lengths follow from a
+// second (sum,max) scan.  Exact for ANY input (unsorted ends, end < start,
+// saturating cur_end + min_dist), not just well-formed intervals.
+#pragma once
+#include "ivx_internal.hpp"
+
+struct ivx_runs_out {
+    u32 *key; i64 *start; i64 *end; i64 *count;     // device buffers, capacity n (any may be nullptr)
+};
+
+// ks/ss/es: rows sorted by (key, start, end) on the device.  Writes the runs in
+// order and returns their number in *m (host; synchronises the stream).
+// Uses scratch WS_T5..WS_T7 and WS_SCAN*.
+ivx_status ivx_merge_runs(ivx_ctx *ctx, const u32 *ks, const i64 *ss, const i64 *es, u64 n,
+                          i64 min_dist, int strict, const ivx_runs_out &out, u64 *m);

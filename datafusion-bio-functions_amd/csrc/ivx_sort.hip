@@ -196,7 +196,7 @@ ivx_status sort_impl(ivx_ctx *ctx, u64 *const *a, u64 *const *b, u64 n, const iv
 
     const u32 nblk = (u32)((n + RS_CHUNK - 1) / RS_CHUNK);
     u32 *hist;
-    IVX_TRY(ctx->get_scratch(WS_TMP7, (size_t)256 * nblk * sizeof(u32), (void **)&hist));
+    IVX_TRY(ctx->get_scratch(WS_SORTHIST, (size_t)256 * nblk * sizeof(u32), (void **)&hist));
     int cur = 0;
     for (int f = 0; f < nfields; f++) {
         const u64 var = ctx->h_scalars[16 + f];
@@ -241,8 +241,8 @@ extern "C" ivx_status ivx_debug_sort(ivx_ctx *ctx, int nw, u64 *w0, u64 *w1, u64
     u64 *host[3] = {w0, w1, w2};
     u64 *a[3], *b[3];
     for (int q = 0; q < nw; q++) {
-        IVX_TRY(ctx->get_scratch(WS_TMP0 + q, n * sizeof(u64), (void **)&a[q]));
-        IVX_TRY(ctx->get_scratch(WS_TMP3 + q, n * sizeof(u64), (void **)&b[q]));
+        IVX_TRY(ctx->get_scratch(WS_SA0 + q, n * sizeof(u64), (void **)&a[q]));
+        IVX_TRY(ctx->get_scratch(WS_SB0 + q, n * sizeof(u64), (void **)&b[q]));
         IVX_HIP(ctx, hipMemcpyAsync(a[q], host[q], n * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
     }
     ivx_sort_field f[8];

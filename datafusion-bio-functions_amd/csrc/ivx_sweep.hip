@@ -1,0 +1,309 @@
+// ivx_sweep.hip -- merge() and subtract() on int64 coordinates.
+//
+//   a7 StreamCollector / FullBatchCollector: per-contig sort_unstable of (start,end[,row])
+//      (grouped_stream.rs:50-113, :163-237)      -> one device LSD radix sort by (key,start,end,row)
+//   a8 MergeStream sweep (merge.rs:282-350)       -> two scans (ivx_runs.hpp)
+//   a9 SubtractStream sweep (subtract.rs:390-462, :575-655) -> per-left-row binary searches over
+//      the right side's "gap heads" + count/scan/fill.
+//
+// subtract without the serial cursor.  For one left row [ls,le) the reference
+// walks the rights of the contig in (start,end) order with cursor = ls:
+//   a right j with rs_j > cursor emits [cursor, rs_j); cursor = max(cursor, re_j);
+//   it stops at the first rs_j > le (strict: >= le); finally [cursor, le) if cursor < le.
+// Rights skipped by the monotone right_cursor all end before ls, so they never
+// change max(ls, .): cursor before j is max(ls, PM[j-1]) with PM the running max
+// of right ends in the contig.  Hence j emits iff rs_j > PM[j-1] (a "gap head", a
+// property of the right side alone), ls < rs_j <= le and j is not behind the
+// right_cursor.  Because left starts ascend, the cursor for a left row is simply
+// the first right with re_j >= ls (strict: > ls) = the first j with PM[j] >= ls,
+// whatever came before.  The gap heads form a sorted array and each left row owns
+// a contiguous slice of it.  (For well-formed rights the cursor bound is implied
+// by rs_j > ls; it matters only when a right row has end < start.)
+#include "ivx_runs.hpp"
+#include "ivx_scan.hpp"
+#include "ivx_sort.hpp"
+
+namespace {
+
+constexpr int ST = 256;
+constexpr u64 SIGN64 = 0x8000000000000000ull;
+
+u32 grid1(u64 n) { return (u32)((n + ST - 1) / ST); }
+
+__global__ __launch_bounds__(ST) void k_pack64(const u32 *__restrict__ key, const i64 *__restrict__ s, const i64 *__restrict__ e,
+                                               u64 n, u32 nkeys, u64 *w0, u64 *w1, u64 *w2, u32 *flags)
+{
+    const u64 i = (u64)blockIdx.x * ST + threadIdx.x;
+    if (i >= n) return;
+    const u32 k = key ? key[i] : 0u;
+    if (k >= nkeys) flags[0] = 1;
+    w0[i] = (u64)e[i] ^ SIGN64;
+    w1[i] = (u64)s[i] ^ SIGN64;
+    w2[i] = ((u64)k << 32) | (u32)i;
+}
+
+__global__ __launch_bounds__(ST) void k_unpack64(const u64 *__restrict__ w0, const u64 *__restrict__ w1, const u64 *__restrict__ w2,
+                                                 u64 n, u32 *ks, i64 *ss, i64 *es, u32 *rows)
+{
+    const u64 i = (u64)blockIdx.x * ST + threadIdx.x;
+    if (i >= n) return;
+    es[i] = (i64)(w0[i] ^ SIGN64);
+    ss[i] = (i64)(w1[i] ^ SIGN64);
+    ks[i] = (u32)(w2[i] >> 32);
+    if (rows) rows[i] = (u32)w2[i];
+}
+
+// sort (key,start,end,row) ascending; rows of equal (key,start,end) keep input order = ascending row
+ivx_status sort64(ivx_ctx *ctx, int slot_a, int slot_b, const u32 *key, const i64 *s, const i64 *e, u64 n, u32 nkeys,
+                  u32 *ks, i64 *ss, i64 *es, u32 *rows)
+{
+    if (n == 0) return IVX_OK;
+    u64 *a[3], *b[3];
+    for (int q = 0; q < 3; q++) {
+        IVX_TRY(ctx->get_scratch(slot_a + q, n * sizeof(u64), (void **)&a[q]));
+        IVX_TRY(ctx->get_scratch(slot_b + q, n * sizeof(u64), (void **)&b[q]));
+    }
+    u32 *flags = (u32 *)(ctx->d_scalars + 8);
+    hipLaunchKernelGGL(k_pack64, dim3(grid1(n)), dim3(ST), 0, ctx->stream, key, s, e, n, nkeys, a[0], a[1], a[2], flags);
+    const ivx_sort_field f[3] = {{0, 0, 64}, {1, 0, 64}, {2, 32, 64}};
+    int in_b = 0;
+    IVX_TRY(ivx_radix_sort(ctx, 3, a, b, n, f, 3, &in_b));
+    u64 *const *r = in_b ? b : a;
+    hipLaunchKernelGGL(k_unpack64, dim3(grid1(n)), dim3(ST), 0, ctx->stream, (const u64 *)r[0], (const u64 *)r[1], (const u64 *)r[2], n, ks, ss, es, rows);
+    IVX_HIP(ctx, hipGetLastError());
+    return IVX_OK;
+}
+
+// ---------------------------------------------------------------- subtract
+
+struct SegMax64 { i64 v; u32 head; u32 pad; };
+struct SegMax64Op {
+    using T = SegMax64;
+    __host__ __device__ static T identity() { T t; t.v = INT64_MIN; t.head = 0; t.pad = 0; return t; }
+    __device__ static T combine(const T &a, const T &b)
+    {
+        T r; r.pad = 0; r.head = a.head | b.head; r.v = b.head ? b.v : (a.v > b.v ? a.v : b.v); return r;
+    }
+    __device__ static T shfl_up(const T &x, int d)
+    {
+        T r; r.pad = 0; r.v = __shfl_up(x.v, d, IVX_WAVE); r.head = __shfl_up(x.head, d, IVX_WAVE); return r;
+    }
+};
+
+__global__ __launch_bounds__(ST) void k_segmax64_in(const u32 *__restrict__ ks, const i64 *__restrict__ es, u64 n, SegMax64 *sm)
+{
+    const u64 i = (u64)blockIdx.x * ST + threadIdx.x;
+    if (i >= n) return;
+    SegMax64 t; t.pad = 0; t.v = es[i]; t.head = (i == 0 || ks[i] != ks[i - 1]) ? 1u : 0u;
+    sm[i] = t;
+}
+
+// gap-head flag of every right row (as u32 for the sum scan); sm = inclusive running max of right ends per key
+__global__ __launch_bounds__(ST) void k_gap_flags(const u32 *__restrict__ rk, const i64 *__restrict__ rs, const SegMax64 *__restrict__ sm,
+                                                  u64 n, u32 *flag)
+{
+    const u64 j = (u64)blockIdx.x * ST + threadIdx.x;
+    if (j > n) return;
+    if (j == n) { flag[j] = 0; return; }
+    const bool first = j == 0 || rk[j] != rk[j - 1];
+    flag[j] = (first || rs[j] > sm[j - 1].v) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(ST) void k_gap_compact(const u32 *__restrict__ rk, const i64 *__restrict__ rs, const SegMax64 *__restrict__ sm,
+                                                    const u32 *__restrict__ hid, u64 n, u32 *hk, i64 *hrs, i64 *hpm, u32 *hj)
+{
+    const u64 j = (u64)blockIdx.x * ST + threadIdx.x;
+    if (j >= n) return;
+    if (hid[j + 1] == hid[j]) return;
+    const bool first = j == 0 || rk[j] != rk[j - 1];
+    const u32 h = hid[j];
+    hk[h] = rk[j]; hrs[h] = rs[j]; hpm[h] = first ? INT64_MIN : sm[j - 1].v; hj[h] = (u32)j;
+}
+
+// #elements with (key,val) < (k,x)  [strict_lt]  or  <= (k,x)
+__device__ __forceinline__ u32 lex_rank(const u32 *__restrict__ kk, const i64 *__restrict__ vv, u32 n, u32 k, i64 x, bool le)
+{
+    u32 lo = 0, hi = n;
+    while (lo < hi) {
+        const u32 mid = lo + ((hi - lo) >> 1);
+        const u32 mk = kk[mid];
+        bool before;
+        if (mk != k) before = mk < k;
+        else { const i64 mv = vv[mid]; before = le ? (mv <= x) : (mv < x); }
+        if (before) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// first j of key k whose running max of right ends is >= x (le=false) / > x (le=true); end of the key if none
+__device__ __forceinline__ u32 pm_rank(const u32 *__restrict__ kk, const SegMax64 *__restrict__ sm, u32 n, u32 k, i64 x, bool le)
+{
+    u32 lo = 0, hi = n;
+    while (lo < hi) {
+        const u32 mid = lo + ((hi - lo) >> 1);
+        const u32 mk = kk[mid];
+        bool before;
+        if (mk != k) before = mk < k;
+        else { const i64 mv = sm[mid].v; before = le ? (mv <= x) : (mv < x); }
+        if (before) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ u32 lower_bound_u32(const u32 *__restrict__ a, u32 n, u32 x)
+{
+    u32 lo = 0, hi = n;
+    while (lo < hi) { const u32 mid = lo + ((hi - lo) >> 1); if (a[mid] < x) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+struct SubPlan { u32 h_lo, h_hi; i64 tail_from; u32 has_tail; };
+
+__device__ __forceinline__ SubPlan plan_row(u32 k, i64 ls, i64 le, int strict,
+                                            const u32 *hk, const i64 *hrs, const u32 *hj, u32 nh,
+                                            const u32 *rk, const i64 *rs, const SegMax64 *sm, u32 nr)
+{
+    SubPlan p;
+    p.h_lo = lex_rank(hk, hrs, nh, k, ls, true);                       // heads with rs <= ls never emit
+    const u32 rc = pm_rank(rk, sm, nr, k, ls, strict != 0);            // right_cursor (subtract.rs:401-412)
+    const u32 hc = lower_bound_u32(hj, nh, rc);                        // heads behind the cursor are skipped
+    if (hc > p.h_lo) p.h_lo = hc;
+    p.h_hi = lex_rank(hk, hrs, nh, k, le, !strict);                    // rs <= le (strict: rs < le)
+    if (p.h_hi < p.h_lo) p.h_hi = p.h_lo;
+    const u32 jhi = lex_rank(rk, rs, nr, k, le, !strict);              // rights visited by the walk
+    i64 cursor = ls;
+    if (jhi > 0 && rk[jhi - 1] == k) { const i64 pm = sm[jhi - 1].v; if (pm > cursor) cursor = pm; }
+    p.tail_from = cursor;
+    p.has_tail = cursor < le ? 1u : 0u;                                 // subtract.rs:435
+    return p;
+}
+
+__global__ __launch_bounds__(ST) void k_sub_count(const u32 *__restrict__ lk, const i64 *__restrict__ lsv, const i64 *__restrict__ lev, u64 nl,
+                                                  int strict, const u32 *hk, const i64 *hrs, const u32 *hj, u32 nh,
+                                                  const u32 *rk, const i64 *rs, const SegMax64 *sm, u32 nr, u64 *cnt)
+{
+    const u64 i = (u64)blockIdx.x * ST + threadIdx.x;
+    if (i > nl) return;
+    if (i == nl) { cnt[i] = 0; return; }
+    const SubPlan p = plan_row(lk[i], lsv[i], lev[i], strict, hk, hrs, hj, nh, rk, rs, sm, nr);
+    cnt[i] = (u64)(p.h_hi - p.h_lo) + p.has_tail;
+}
+
+__global__ __launch_bounds__(ST) void k_sub_fill(const u32 *__restrict__ lk, const i64 *__restrict__ lsv, const i64 *__restrict__ lev,
+                                                 const u32 *__restrict__ lrow, u64 nl, int strict,
+                                                 const u32 *hk, const i64 *hrs, const i64 *hpm, const u32 *hj, u32 nh,
+                                                 const u32 *rk, const i64 *rs, const SegMax64 *sm, u32 nr,
+                                                 const u64 *__restrict__ offs, u64 cap,
+                                                 u32 *ok, i64 *os, i64 *oe, u32 *orow)
+{
+    const u64 i = (u64)blockIdx.x * ST + threadIdx.x;
+    if (i >= nl) return;
+    const u32 k = lk[i];
+    const i64 ls = lsv[i], le = lev[i];
+    const SubPlan p = plan_row(k, ls, le, strict, hk, hrs, hj, nh, rk, rs, sm, nr);
+    u64 at = offs[i];
+    const u32 row = lrow[i];
+    for (u32 h = p.h_lo; h < p.h_hi; h++, at++) {                       // [cursor, rs)  subtract.rs:423-428
+        if (at >= cap) return;
+        const i64 pm = hpm[h];
+        if (ok) ok[at] = k;
+        if (os) os[at] = pm > ls ? pm : ls;
+        if (oe) oe[at] = hrs[h];
+        if (orow) orow[at] = row;
+    }
+    if (p.has_tail && at < cap) {                                       // [cursor, le)  :435-440
+        if (ok) ok[at] = k;
+        if (os) os[at] = p.tail_from;
+        if (oe) oe[at] = le;
+        if (orow) orow[at] = row;
+    }
+}
+
+ivx_status keyflag(ivx_ctx *ctx, const char *what)
+{
+    IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 8, ctx->d_scalars + 8, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+    IVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (*(u32 *)(ctx->h_scalars + 8)) return ctx->fail(IVX_ERR_INVALID, what);
+    return IVX_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------ device entry points
+
+ivx_status ivx_merge_device(ivx_ctx *ctx, const u32 *key, const i64 *s, const i64 *e, u64 n, u32 nkeys,
+                            i64 min_dist, int strict, u32 *ok, i64 *os, i64 *oe, i64 *on, u64 *m)
+{
+    *m = 0;
+    if (n == 0) return IVX_OK;
+    IVX_HIP(ctx, hipMemsetAsync(ctx->d_scalars + 8, 0, sizeof(u64), ctx->stream));
+    u32 *ks; i64 *ss, *es;
+    IVX_TRY(ctx->get_scratch(WS_T0, n * sizeof(u32), (void **)&ks));
+    IVX_TRY(ctx->get_scratch(WS_T1, n * sizeof(i64), (void **)&ss));
+    IVX_TRY(ctx->get_scratch(WS_T2, n * sizeof(i64), (void **)&es));
+    IVX_TRY(sort64(ctx, WS_SA0, WS_SB0, key, s, e, n, nkeys, ks, ss, es, nullptr));
+    ivx_runs_out ro{ok, os, oe, on};
+    IVX_TRY(ivx_merge_runs(ctx, ks, ss, es, n, min_dist, strict, ro, m));
+    return keyflag(ctx, "merge: key id >= n_keys");
+}
+
+ivx_status ivx_subtract_device(ivx_ctx *ctx, const u32 *lkey, const i64 *ls, const i64 *le, u64 nl,
+                               const u32 *rkey, const i64 *rs, const i64 *re, u64 nr, u32 nkeys, int strict,
+                               u32 *ok, i64 *os, i64 *oe, u32 *orow, u64 cap, u64 *n_out)
+{
+    *n_out = 0;
+    if (nl == 0) return IVX_OK;
+    hipStream_t st = ctx->stream;
+    IVX_HIP(ctx, hipMemsetAsync(ctx->d_scalars + 8, 0, sizeof(u64), st));
+    u32 *lk, *lrow, *rk; i64 *lsv, *lev, *rsv, *rev;
+    IVX_TRY(ctx->get_scratch(WS_T0, nl * sizeof(u32), (void **)&lk));
+    IVX_TRY(ctx->get_scratch(WS_T1, nl * sizeof(i64), (void **)&lsv));
+    IVX_TRY(ctx->get_scratch(WS_T2, nl * sizeof(i64), (void **)&lev));
+    IVX_TRY(ctx->get_scratch(WS_T3, nl * sizeof(u32), (void **)&lrow));
+    IVX_TRY(sort64(ctx, WS_SA0, WS_SB0, lkey, ls, le, nl, nkeys, lk, lsv, lev, lrow));
+    const u64 nra = nr ? nr : 1;
+    IVX_TRY(ctx->get_scratch(WS_T4, nra * sizeof(u32), (void **)&rk));
+    IVX_TRY(ctx->get_scratch(WS_T5, nra * sizeof(i64), (void **)&rsv));
+    IVX_TRY(ctx->get_scratch(WS_T6, nra * sizeof(i64), (void **)&rev));
+    IVX_TRY(sort64(ctx, WS_RA0, WS_RB0, rkey, rs, re, nr, nkeys, rk, rsv, rev, nullptr));
+    IVX_TRY(keyflag(ctx, "subtract: key id >= n_keys"));
+
+    // right side: running max of ends per key, gap heads
+    SegMax64 *sm; u32 *hid, *hk, *hj; i64 *hrs, *hpm;
+    IVX_TRY(ctx->get_scratch(WS_T7, nra * sizeof(SegMax64), (void **)&sm));
+    IVX_TRY(ctx->get_scratch(WS_T8, (nr + 1) * sizeof(u32), (void **)&hid));
+    u64 nh = 0;
+    if (nr) {
+        hipLaunchKernelGGL(k_segmax64_in, dim3(grid1(nr)), dim3(ST), 0, st, (const u32 *)rk, (const i64 *)rev, nr, sm);
+        IVX_TRY(ivxscan::inclusive<SegMax64Op>(ctx, sm, nr));
+        hipLaunchKernelGGL(k_gap_flags, dim3(grid1(nr + 1)), dim3(ST), 0, st, (const u32 *)rk, (const i64 *)rsv, (const SegMax64 *)sm, nr, hid);
+        IVX_TRY(ivx_scan_exclusive_u32(ctx, hid, nr + 1));
+        IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 4, hid + nr, sizeof(u32), hipMemcpyDeviceToHost, st));
+        IVX_HIP(ctx, hipStreamSynchronize(st));
+        nh = *(u32 *)(ctx->h_scalars + 4);
+    }
+    const u64 nha = nh ? nh : 1;
+    // the sorted right ends are no longer needed: reuse their slot for the heads' keys
+    IVX_TRY(ctx->get_scratch(WS_T9, nha * sizeof(i64), (void **)&hrs));
+    IVX_TRY(ctx->get_scratch(WS_RA0, nha * sizeof(i64), (void **)&hpm));
+    IVX_TRY(ctx->get_scratch(WS_RA1, nha * sizeof(u32), (void **)&hk));
+    IVX_TRY(ctx->get_scratch(WS_RB0, nha * sizeof(u32), (void **)&hj));
+    if (nr) hipLaunchKernelGGL(k_gap_compact, dim3(grid1(nr)), dim3(ST), 0, st, (const u32 *)rk, (const i64 *)rsv, (const SegMax64 *)sm, (const u32 *)hid, nr, hk, hrs, hpm, hj);
+
+    u64 *cnt;
+    IVX_TRY(ctx->get_scratch(WS_RA2, (nl + 1) * sizeof(u64), (void **)&cnt));
+    hipLaunchKernelGGL(k_sub_count, dim3(grid1(nl + 1)), dim3(ST), 0, st, (const u32 *)lk, (const i64 *)lsv, (const i64 *)lev, nl, strict,
+                       (const u32 *)hk, (const i64 *)hrs, (const u32 *)hj, (u32)nh, (const u32 *)rk, (const i64 *)rsv, (const SegMax64 *)sm, (u32)nr, cnt);
+    IVX_TRY(ivx_scan_exclusive_u64(ctx, cnt, nl + 1));
+    IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 5, cnt + nl, sizeof(u64), hipMemcpyDeviceToHost, st));
+    IVX_HIP(ctx, hipStreamSynchronize(st));
+    const u64 total = ctx->h_scalars[5];
+    *n_out = total;
+    if (cap == 0 && !ok && !os && !oe && !orow) return IVX_OK;          // count only
+    if (total > cap) return ctx->fail(IVX_ERR_CAPACITY, "subtract: output buffers too small");
+    hipLaunchKernelGGL(k_sub_fill, dim3(grid1(nl)), dim3(ST), 0, st, (const u32 *)lk, (const i64 *)lsv, (const i64 *)lev, (const u32 *)lrow, nl, strict,
+                       (const u32 *)hk, (const i64 *)hrs, (const i64 *)hpm, (const u32 *)hj, (u32)nh, (const u32 *)rk, (const i64 *)rsv, (const SegMax64 *)sm, (u32)nr,
+                       (const u64 *)cnt, cap, ok, os, oe, orow);
+    IVX_HIP(ctx, hipGetLastError());
+    return IVX_OK;
+}
