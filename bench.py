@@ -40,7 +40,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="join_100Mx1M_24contigs", choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-sample", type=int, default=10_000_000, help="probe rows timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=20_000_000, help="probe rows timed on the CPU baseline (0 = skip)")
     ap.add_argument("--gather", action="store_true", help="also all-gather the per-rank pair counts+buffers (RCCL) inside the step")
     args = ap.parse_args()
 
@@ -141,7 +141,7 @@ def main():
             "config": {"workload": args.workload, "probe_rows_per_gpu": n_probe, "build_rows_per_gpu": n_build,
                        "contigs": n_contigs, "pairs_per_gpu": pairs, "parallelism": f"partition-per-gpu x{world}",
                        "gather": bool(args.gather)},
-            "roofline": {"bound": "hbm", "kernel": "k_probe_overlap<FILL>", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+            "roofline": {"bound": "hbm", "kernel": "overlap probe pipeline: k_part_hist + k_part_scatter + k_probe_regions<count> + k_probe_regions<fill>", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                          "kernel_ms": kern_ms, "algorithmic_bytes": alg_bytes,
                          "build_ms": float(np.mean(build_ms))},
@@ -151,7 +151,7 @@ def main():
             ns = min(args.cpu_sample, n_probe)
             hb = (bk.cpu().numpy().view(np.uint32), bs.cpu().numpy(), be.cpu().numpy())
             hp = (pk[:ns].cpu().numpy().view(np.uint32), ps[:ns].cpu().numpy(), pe[:ns].cpu().numpy())
-            cores = os.cpu_count() or 1
+            cores = min(16, len(os.sched_getaffinity(0)))      # the 1-GPU box's CPU share
             orc.lib()
             c0 = time.perf_counter()
             cb, cp = orc.join(*hb, *hp, threads=cores)

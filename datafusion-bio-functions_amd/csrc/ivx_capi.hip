@@ -2,6 +2,7 @@
 // Host-side plumbing only: argument checks, staging of host buffers, stream and
 // scratch management.  All arithmetic happens in the HIP kernels.
 #include "ivx_internal.hpp"
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -261,8 +262,16 @@ static ivx_status overlap_common(ivx_ctx *ctx, const ivx_index *ix, int mem, int
     IVX_TRY(stage_out(ctx, mem, WS_OUT_D, pidx, cap, &d_p));
     IVX_HIP(ctx, hipMemsetAsync(ctx->d_scalars, 0, sizeof(u64), ctx->stream));
     {
+        // large COUNT/FILL batches: partition the probe rows by index region and probe from LDS;
+        // small batches and the per-row modes gather straight from the index
+        bool regions = ix->jv_nreg > 0 && (mode == JP_COUNT || mode == JP_FILL) && n >= (1u << 18);
+        if (const char *f = getenv("IVX_JOIN_PATH")) {
+            if (!strcmp(f, "direct")) regions = false;
+            else if (!strcmp(f, "regions")) regions = ix->jv_nreg > 0 && (mode == JP_COUNT || mode == JP_FILL);
+        }
         KernelTimer t(ctx);
-        IVX_TRY(ivx_join_probe(ctx, ix->jv, mode, dk, ds, de, n, d_row, d_ex, d_b, d_p, cap, ctx->d_scalars));
+        if (regions) IVX_TRY(ivx_join_probe_regions(ctx, ix->jv, mode, dk, ds, de, n, d_b, d_p, cap, ctx->d_scalars));
+        else IVX_TRY(ivx_join_probe(ctx, ix->jv, mode, dk, ds, de, n, d_row, d_ex, d_b, d_p, cap, ctx->d_scalars));
     }
     u64 tot = 0;
     if (mode != JP_EXISTS) IVX_TRY(read_scalar(ctx, 0, &tot));

@@ -74,7 +74,8 @@ enum {
 struct ivx_ent { i32 s, e; u32 row; };          // 12-byte AoS entry of the overlap index
 
 // header words written by the layout kernel (device resident, read by probes)
-enum { HDR_SH0 = 0, HDR_NLEV = 1, HDR_NBINS = 2, HDR_LEVCNT = 4 /* .. +IVX_MAXL */, HDR_WORDS = 16 };
+enum { HDR_SH0 = 0, HDR_NLEV = 1, HDR_NBINS = 2, HDR_LEVCNT = 4 /* .. +IVX_MAXL */, HDR_CS = 12, HDR_NREG = 13, HDR_WORDS = 16 };
+#define IVX_MAXREG 255   // probe regions (one radix digit; 255 = rows that cannot match)
 
 struct JoinIndexView {
     const i32 *origin;      // [nkeys] smallest start of the key
@@ -84,6 +85,8 @@ struct JoinIndexView {
     const u32 *binstart;    // [nbins+1] CSR offsets into ent
     const ivx_ent *ent;     // [n] entries grouped by bin
     const u32 *hdr;         // [HDR_WORDS]
+    const u32 *kreg;        // [nkeys+1] first probe region of the key (regions never straddle keys)
+    const u32 *rkey;        // [IVX_MAXREG+1] key of a region
     u32 nkeys;
 };
 
@@ -123,6 +126,7 @@ struct ivx_index {
     size_t bytes = 0;
     std::vector<void *> allocs;
     JoinIndexView jv{};
+    u32 jv_nreg = 0;            // >0: the region-partitioned probe is available
     RankGridView gs{}, ge{};
     CoverageView cv{};
     NearestView nv{};
@@ -140,5 +144,9 @@ ivx_status ivx_join_probe(ivx_ctx *ctx, const JoinIndexView &jv, int mode,
                           const u32 *key, const i32 *s, const i32 *e, u64 n,
                           u32 *per_row, u8 *exists, u32 *ob, u32 *op, u64 cap, u64 *d_cursor);
 enum { JP_COUNT = 0, JP_PER_ROW = 1, JP_EXISTS = 2, JP_FILL = 3 };
+// join_regions.hip: partition the probe rows by index region, probe each region from LDS
+ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, int mode,
+                                  const u32 *key, const i32 *s, const i32 *e, u64 n,
+                                  u32 *ob, u32 *op, u64 cap, u64 *d_cursor);
 
 ivx_status ivx_index_alloc(ivx_ctx *ctx, ivx_index *ix, size_t bytes, void **out);

@@ -19,6 +19,7 @@
 //   finest level has at most ~2 cells per build row.
 #include "ivx_device.hpp"
 #include "ivx_grid.hpp"
+#include "ivx_join.hpp"
 
 namespace {
 
@@ -31,7 +32,8 @@ __device__ __forceinline__ u32 cells_of(u32 cnt, u32 span, u32 sh) { return cnt 
 // One workgroup: turn per-key (min,max,count) into origin/span, pick sh0 and
 // lay out the (level,key) cell ranges.  hdr: sh0, #levels, #cells.
 __global__ __launch_bounds__(1024) void k_join_layout(const i32 *kmin, const i32 *kmax, const u32 *kcnt, u32 nkeys, u64 n,
-                                                      i32 *origin, u32 *span, u32 *lbase, u32 *hdr, u64 maxcells)
+                                                      i32 *origin, u32 *span, u32 *lbase, u32 *hdr, u64 maxcells,
+                                                      u32 *kreg, u32 *rkey)
 {
     __shared__ u64 red[1024 / IVX_WAVE + 1];
     __shared__ u32 s_sh0;
@@ -75,22 +77,38 @@ __global__ __launch_bounds__(1024) void k_join_layout(const i32 *kmin, const i32
         hdr[HDR_NLEV] = nlev;
         hdr[HDR_NBINS] = (u32)(run <= maxcells ? run : maxcells);   // never exceeds the budget by construction
     }
-}
-
-__device__ __forceinline__ u32 level_of(i32 s, i32 e, u32 sh0, u32 nlev)
-{
-    i64 len = (i64)e - (i64)s;
-    if (len <= 0) return 0;
-    u32 bits = 64 - __clzll((u64)len);                 // len < 2^bits
-    u32 l = bits <= sh0 ? 0 : (bits - sh0 + IVX_LSTEP - 1) / IVX_LSTEP;
-    return l < nlev ? l : nlev - 1;                    // top level has sh >= 32 >= bits
-}
-
-__device__ __forceinline__ u32 cell_of(const i32 *origin, const u32 *lbase, u32 nkeys, u32 k, i32 s, u32 l, u32 sh0)
-{
-    const u32 sh = sh0 + IVX_LSTEP * l;
-    const u32 off = (u32)((i64)s - (i64)origin[k]);
-    return lbase[(u64)l * nkeys + k] + (sh >= 32 ? 0u : off >> sh);
+    // ---- probe regions: runs of 2^cs level-0 cells that never straddle a key, at most IVX_MAXREG of them
+    //      (one radix digit of the probe partition pass)
+    u32 clo = 0, chi = 32;
+    while (clo < chi) {
+        const u32 mid = (clo + chi) / 2;
+        u64 s = 0;
+        for (u32 k = t; k < nkeys; k += 1024) {
+            const u64 c = cells_of(kcnt[k], span[k], sh0);
+            s += mid >= 32 ? (c ? 1u : 0u) : ((c + (1ull << mid) - 1) >> mid);
+        }
+        const u64 tot = block_sum<u64, 1024>(s, red);
+        if (tot <= IVX_MAXREG) chi = mid; else clo = mid + 1;
+    }
+    const u32 cs = clo;                                             // 32 = not even one region per key fits
+    u64 rrun = 0;
+    for (u32 k0 = 0; k0 < nkeys; k0 += 1024) {
+        const u32 k = k0 + t;
+        u64 c = k < nkeys ? cells_of(kcnt[k], span[k], sh0) : 0u;
+        c = cs >= 32 ? 0 : ((c + (1ull << cs) - 1) >> cs);
+        u64 tot;
+        const u64 ex = block_excl_scan<u64, 1024>(c, red, &tot);
+        if (k < nkeys && cs < 32) {
+            kreg[k] = (u32)(rrun + ex);
+            for (u64 r = 0; r < c; r++) rkey[rrun + ex + r] = k;
+        }
+        rrun += tot;
+    }
+    if (t == 0) {
+        kreg[nkeys] = (u32)rrun;
+        hdr[HDR_CS] = cs;
+        hdr[HDR_NREG] = cs < 32 ? (u32)rrun : 0u;
+    }
 }
 
 __global__ __launch_bounds__(BT) void k_join_count(const u32 *__restrict__ key, const i32 *__restrict__ s,
@@ -137,39 +155,6 @@ constexpr int PT = 256;     // probe workgroup
 constexpr int PI = 4;       // probe rows per thread per tile
 constexpr int PTILE = PT * PI;
 
-// visit every build row of key k overlapping [qs,qe]
-template <class F>
-__device__ __forceinline__ void walk(const JoinIndexView &ix, u32 sh0, u32 nlev, u32 k, i32 qs, i32 qe, F &&f)
-{
-    if (k >= ix.nkeys) return;
-    if (ix.kcnt[k] == 0) return;
-    const i32 origin = ix.origin[k];
-    const u32 span = ix.span[k];
-    const i64 hi64 = (i64)qe - (i64)origin;
-    if (hi64 < 0) return;                                 // every start of this key is > qe
-    for (u32 l = 0; l < nlev; l++) {
-        if (ix.hdr[HDR_LEVCNT + l] == 0) continue;        // wave-uniform
-        const u32 sh = sh0 + IVX_LSTEP * l;
-        u32 blo = 0, bhi = 0;
-        if (sh < 32) {
-            const u32 ncell = (span >> sh) + 1u;
-            const i64 lo64 = (i64)qs - ((i64)1 << sh) + 1 - (i64)origin;   // starts below this cannot reach qs
-            const i64 bl = lo64 <= 0 ? 0 : (lo64 >> sh);
-            const i64 bh = hi64 >> sh;
-            if (bl >= (i64)ncell) continue;
-            blo = (u32)bl;
-            bhi = bh >= (i64)ncell ? ncell - 1u : (u32)bh;
-            if (blo > bhi) continue;
-        }
-        const u32 base = ix.lbase[(u64)l * ix.nkeys + k];
-        const u32 a = ix.binstart[base + blo], b = ix.binstart[base + bhi + 1];
-        for (u32 j = a; j < b; j++) {
-            const ivx_ent x = ix.ent[j];
-            if (x.s <= qe && x.e >= qs) f(x.row);
-        }
-    }
-}
-
 template <int MODE>
 __global__ __launch_bounds__(PT) void k_probe_overlap(JoinIndexView ix, const u32 *__restrict__ pkey,
                                                       const i32 *__restrict__ ps, const i32 *__restrict__ pe, u64 n,
@@ -192,7 +177,7 @@ __global__ __launch_bounds__(PT) void k_probe_overlap(JoinIndexView ix, const u3
             if (i < n) {
                 const u32 k = pkey ? pkey[i] : 0u;
                 const i32 qs = ps[i], qe = pe[i];
-                walk(ix, sh0, nlev, k, qs, qe, [&](u32 row) {
+                walk(ix, sh0, 0, nlev, k, qs, qe, [&](u32 row) {
                     if (m == 0) a0 = row; else if (m == 1) a1 = row;
                     m++;
                 });
@@ -222,7 +207,7 @@ __global__ __launch_bounds__(PT) void k_probe_overlap(JoinIndexView ix, const u3
                     at += m;
                 } else {
                     const u32 k = pkey ? pkey[i] : 0u;
-                    walk(ix, sh0, nlev, k, ps[i], pe[i], [&](u32 row) { ob[at] = row; op[at] = (u32)i; at++; });
+                    walk(ix, sh0, 0, nlev, k, ps[i], pe[i], [&](u32 row) { ob[at] = row; op[at] = (u32)i; at++; });
                 }
             }
         }
@@ -246,13 +231,15 @@ ivx_status ivx_join_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32
     const u64 maxcells = 2 * n + n / 4 + (u64)IVX_MAXL * nkeys + 64;
     if (maxcells + 1 >= 0xFFFFFFFFull) return ctx->fail(IVX_ERR_INVALID, "build side too large for 32-bit cell ids");
 
-    i32 *origin; u32 *span, *kcnt, *lbase, *binstart, *hdr; ivx_ent *ent;
+    i32 *origin; u32 *span, *kcnt, *lbase, *binstart, *hdr, *kreg, *rkey; ivx_ent *ent;
     IVX_TRY(ivx_index_alloc(ctx, ix, nkeys * sizeof(i32), (void **)&origin));
     IVX_TRY(ivx_index_alloc(ctx, ix, nkeys * sizeof(u32), (void **)&span));
     IVX_TRY(ivx_index_alloc(ctx, ix, nkeys * sizeof(u32), (void **)&kcnt));
     IVX_TRY(ivx_index_alloc(ctx, ix, (size_t)IVX_MAXL * nkeys * sizeof(u32), (void **)&lbase));
     IVX_TRY(ivx_index_alloc(ctx, ix, (maxcells + 1) * sizeof(u32), (void **)&binstart));
     IVX_TRY(ivx_index_alloc(ctx, ix, HDR_WORDS * sizeof(u32), (void **)&hdr));
+    IVX_TRY(ivx_index_alloc(ctx, ix, ((size_t)nkeys + 1) * sizeof(u32), (void **)&kreg));
+    IVX_TRY(ivx_index_alloc(ctx, ix, (IVX_MAXREG + 1) * sizeof(u32), (void **)&rkey));
     IVX_TRY(ivx_index_alloc(ctx, ix, (n ? n : 1) * sizeof(ivx_ent), (void **)&ent));
 
     i32 *kmin, *kmax; u32 *cursor, *errflag;
@@ -267,7 +254,7 @@ ivx_status ivx_join_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32
     IVX_HIP(ctx, hipMemsetAsync(hdr, 0, HDR_WORDS * sizeof(u32), st));
     IVX_TRY(ivx_keystats(ctx, key, s, n, nkeys, kmin, kmax, kcnt, errflag));
     const u32 grid = ivx_stream_grid(n, BT * 8, 1024);
-    hipLaunchKernelGGL(k_join_layout, dim3(1), dim3(1024), 0, st, kmin, kmax, kcnt, nkeys, n, origin, span, lbase, hdr, maxcells);
+    hipLaunchKernelGGL(k_join_layout, dim3(1), dim3(1024), 0, st, kmin, kmax, kcnt, nkeys, n, origin, span, lbase, hdr, maxcells, kreg, rkey);
     hipLaunchKernelGGL(k_join_count, dim3(grid), dim3(BT), 0, st, key, s, e, n, nkeys, origin, lbase, hdr, binstart);
     IVX_TRY(ivx_scan_exclusive_u32(ctx, binstart, maxcells + 1));
     hipLaunchKernelGGL(k_join_scatter, dim3(grid), dim3(BT), 0, st, key, s, e, n, nkeys, origin, lbase, hdr, binstart, cursor, ent);
@@ -275,11 +262,14 @@ ivx_status ivx_join_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32
 
     // key ids are validated on the device; surface the flag (one small D2H)
     IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 8, errflag, sizeof(u32), hipMemcpyDeviceToHost, st));
+    IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 32, hdr, HDR_WORDS * sizeof(u32), hipMemcpyDeviceToHost, st));
     IVX_HIP(ctx, hipStreamSynchronize(st));
     if (*(u32 *)(ctx->h_scalars + 8)) return ctx->fail(IVX_ERR_INVALID, "build key id >= n_keys");
+    ix->jv_nreg = ((const u32 *)(ctx->h_scalars + 32))[HDR_NREG];
 
     ix->jv.origin = origin; ix->jv.span = span; ix->jv.kcnt = kcnt; ix->jv.lbase = lbase;
     ix->jv.binstart = binstart; ix->jv.ent = ent; ix->jv.hdr = hdr; ix->jv.nkeys = nkeys;
+    ix->jv.kreg = kreg; ix->jv.rkey = rkey;
     return IVX_OK;
 }
 

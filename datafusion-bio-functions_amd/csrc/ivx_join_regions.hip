@@ -1,0 +1,406 @@
+// ivx_join_regions.hip -- the overlap probe without random HBM gathers.
+//
+// Unsorted probe rows gathered straight from the index cost ~1.6 fabric reads of
+// 64 B per row (profiles/r1_a_probe_count_v1_pmc.txt): the index (tens of MB) does
+// not fit a 4 MB XCD L2.  Here the probe side is first radix-partitioned by index
+// REGION (a run of 2^cs level-0 cells of one key, at most 255 regions = one 8-bit
+// digit), then every region is probed by workgroups that stage its slice of the
+// index -- cell offsets and (start,end) of its entries -- in LDS and stream the
+// region's probe rows through it with coalesced reads:
+//
+//   k_part_hist     region histogram per workgroup (wave ballot match + LDS counters)
+//   scan            exclusive prefix over [region][workgroup]
+//   k_part_scatter  (qs,qe,row) records re-ordered through LDS, contiguous runs out
+//   k_probe_regions LDS-resident slice, two-phase (count, workgroup scan, write)
+//                   compaction: pairs go to an LDS queue that is flushed with ONE
+//                   global atomicAdd per ~1500 pairs; no LDS or global atomics
+//                   per pair.  Rows longer than the slice halo, regions whose
+//                   slice exceeds LDS and the long-interval levels fall back to
+//                   global reads inside the same kernel.
+//
+// HBM traffic per probe row: 8 B (hist) + 12 B + 12 B (scatter) + 12 B (probe) +
+// 8 B per pair, all streaming.
+#include "ivx_join.hpp"
+
+namespace {
+
+// ------------------------------------------------------------------ partition pass
+
+constexpr int PA_T = 256;
+constexpr int PA_I = 8;
+constexpr int PA_TILE = PA_T * PA_I;              // 2048 rows
+constexpr int PA_TPB = 8;
+constexpr u64 PA_CHUNK = (u64)PA_TILE * PA_TPB;   // 16384 rows per workgroup
+constexpr u32 NO_REGION = 0xFFFFFFFFu;
+constexpr u32 KT_MAX = 256;                       // per-key tables cached in LDS up to this many keys
+
+// per-key lookup for "which region does a probe row start in", cached in LDS
+struct KeyTab {
+    const i32 *origin; const u32 *lastcell; const u32 *kreg;   // lastcell = 0xFFFFFFFF: key has no build rows
+    u32 nkeys, sh0, cs;
+};
+
+__device__ __forceinline__ void keytab_load(const JoinIndexView &ix, i32 *s_origin, u32 *s_last, u32 *s_kreg, KeyTab &kt)
+{
+    kt.nkeys = ix.nkeys; kt.sh0 = ix.hdr[HDR_SH0]; kt.cs = ix.hdr[HDR_CS];
+    if (ix.nkeys <= KT_MAX) {
+        for (u32 k = threadIdx.x; k < ix.nkeys; k += blockDim.x) {
+            s_origin[k] = ix.origin[k];
+            s_last[k] = ix.kcnt[k] ? (ix.span[k] >> kt.sh0) : 0xFFFFFFFFu;
+            s_kreg[k] = ix.kreg[k];
+        }
+        kt.origin = s_origin; kt.lastcell = s_last; kt.kreg = s_kreg;
+    } else {
+        kt.origin = nullptr; kt.lastcell = nullptr; kt.kreg = nullptr;
+    }
+}
+
+// region of a probe row = region of the level-0 cell its START falls in (clamped into the key)
+__device__ __forceinline__ u32 region_of(const JoinIndexView &ix, const KeyTab &kt, u32 k, i32 qs)
+{
+    if (k >= kt.nkeys) return NO_REGION;
+    i32 origin; u32 last, kreg;
+    if (kt.origin) { origin = kt.origin[k]; last = kt.lastcell[k]; kreg = kt.kreg[k]; }
+    else { origin = ix.origin[k]; last = ix.kcnt[k] ? (ix.span[k] >> kt.sh0) : 0xFFFFFFFFu; kreg = ix.kreg[k]; }
+    if (last == 0xFFFFFFFFu) return NO_REGION;                    // cannot match anything
+    const i64 d = (i64)qs - (i64)origin;
+    const i64 c64 = d <= 0 ? 0 : (d >> kt.sh0);
+    const u32 c = c64 > (i64)last ? last : (u32)c64;
+    return kreg + (c >> kt.cs);
+}
+
+__global__ __launch_bounds__(PA_T) void k_part_hist(JoinIndexView ix, const u32 *__restrict__ pkey, const i32 *__restrict__ ps,
+                                                    u64 n, u32 nblk, u32 *__restrict__ hist)
+{
+    __shared__ u32 cnt[256];
+    __shared__ i32 s_origin[KT_MAX];
+    __shared__ u32 s_last[KT_MAX], s_kreg[KT_MAX];
+    KeyTab kt;
+    keytab_load(ix, s_origin, s_last, s_kreg, kt);
+    cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const u64 lo = (u64)blockIdx.x * PA_CHUNK;
+    const u64 hi = lo + PA_CHUNK < n ? lo + PA_CHUNK : n;
+    for (u64 i0 = lo; i0 < hi; i0 += (u64)PA_T * 4) {
+        u32 k[4]; i32 q[4]; bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const u64 i = i0 + (u64)u * PA_T + threadIdx.x;
+            ok[u] = i < hi;
+            k[u] = ok[u] ? (pkey ? pkey[i] : 0u) : 0u;
+            q[u] = ok[u] ? ps[i] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (!ok[u]) continue;
+            const u32 d = region_of(ix, kt, k[u], q[u]);
+            if (d != NO_REGION) atomicAdd(&cnt[d], 1u);
+        }
+    }
+    __syncthreads();
+    hist[(u64)threadIdx.x * nblk + blockIdx.x] = cnt[threadIdx.x];
+}
+
+// order inside a region is irrelevant (the reference pins only the pair multiset), so the local
+// rank of a row is just the value an LDS counter held when the row arrived
+__global__ __launch_bounds__(PA_T) void k_part_scatter(JoinIndexView ix, const u32 *__restrict__ pkey, const i32 *__restrict__ ps,
+                                                       const i32 *__restrict__ pe, u64 n, u32 nblk, const u32 *__restrict__ offs,
+                                                       u64 *__restrict__ out_se, u32 *__restrict__ out_row)
+{
+    __shared__ u64 r_se[PA_TILE];
+    __shared__ u32 r_row[PA_TILE];
+    __shared__ unsigned char r_dig[PA_TILE];
+    __shared__ u32 tcnt[256], dstart[256], gbase[256];
+    __shared__ u32 scan_lds[PA_T / IVX_WAVE + 1];
+    __shared__ i32 s_origin[KT_MAX];
+    __shared__ u32 s_last[KT_MAX], s_kreg[KT_MAX];
+
+    const u32 tid = threadIdx.x;
+    KeyTab kt;
+    keytab_load(ix, s_origin, s_last, s_kreg, kt);
+    gbase[tid] = offs[(u64)tid * nblk + blockIdx.x];
+    const u64 lo = (u64)blockIdx.x * PA_CHUNK;
+    const u64 hi = lo + PA_CHUNK < n ? lo + PA_CHUNK : n;
+    for (u64 t0 = lo; t0 < hi; t0 += PA_TILE) {
+        tcnt[tid] = 0;
+        __syncthreads();
+        u64 se[PA_I]; u32 dig[PA_I], lrank[PA_I];
+        u32 kk[PA_I]; i32 qs[PA_I], qe[PA_I];
+#pragma unroll
+        for (int k = 0; k < PA_I; k++) {
+            const u64 i = t0 + (u64)k * PA_T + tid;
+            const bool ok = i < hi;
+            kk[k] = ok ? (pkey ? pkey[i] : 0u) : 0xFFFFFFFFu;
+            qs[k] = ok ? ps[i] : 0;
+            qe[k] = ok ? pe[i] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < PA_I; k++) {
+            se[k] = (u64)(u32)qs[k] | ((u64)(u32)qe[k] << 32);
+            const u32 d = region_of(ix, kt, kk[k], qs[k]);
+            dig[k] = d;
+            lrank[k] = d != NO_REGION ? atomicAdd(&tcnt[d], 1u) : 0u;
+        }
+        __syncthreads();
+        u32 tot;
+        const u32 mine = tcnt[tid];
+        const u32 ds = block_excl_scan<u32, PA_T>(mine, scan_lds, &tot);
+        dstart[tid] = ds;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PA_I; k++) {
+            if (dig[k] != NO_REGION) {
+                const u32 pos = dstart[dig[k]] + lrank[k];
+                r_se[pos] = se[k];
+                r_row[pos] = (u32)(t0 + (u64)k * PA_T + tid);
+                r_dig[pos] = (unsigned char)dig[k];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PA_I; k++) {
+            const u32 j = k * PA_T + tid;
+            if (j < tot) {
+                const u32 d = r_dig[j];
+                const u64 g = (u64)gbase[d] + (j - dstart[d]);
+                out_se[g] = r_se[j];
+                out_row[g] = r_row[j];
+            }
+        }
+        __syncthreads();
+        gbase[tid] += mine;
+    }
+}
+
+// ------------------------------------------------------------------ region probe
+
+constexpr int RP_T = 1024;                 // one workgroup per CU (LDS-bound), 16 wavefronts
+constexpr int RP_W = RP_T / IVX_WAVE;
+constexpr int RP_B = 8;                    // probe rows per lane per wave batch
+constexpr u32 RP_WB = IVX_WAVE * RP_B;     // rows per wave batch
+constexpr u32 RP_HALO = 8;                 // slice cells past the region's last cell
+constexpr u32 RP_CCAP = 8192 + RP_HALO + 2;
+constexpr u32 RP_ECAP = 8448;              // entries staged per slice
+constexpr u32 RP_GRID = 256;
+
+struct Slice {
+    const JoinIndexView *ix;
+    const unsigned short *s_off; const u64 *s_ent; const u32 *s_row;
+    u32 sh0, nlev, k, lb, slo, shi, e0, ncell0; bool inlds, upper, lev0;
+    i32 origin; u32 span;
+};
+
+// every match of one probe row: f(build row)
+template <class F>
+__device__ __forceinline__ void probe_row(const Slice &S, i32 qs, i32 qe, F &&f)
+{
+    const JoinIndexView &ix = *S.ix;
+    const i64 hi64 = (i64)qe - (i64)S.origin;
+    if (hi64 < 0) return;
+    if (S.lev0) {
+        const u32 ncell = S.ncell0;
+        const i64 lo64 = (i64)qs - ((i64)1 << S.sh0) + 1 - (i64)S.origin;
+        const i64 bl = lo64 <= 0 ? 0 : (lo64 >> S.sh0);
+        if (bl < (i64)ncell) {
+            const u32 blo = (u32)bl;
+            const i64 bh = hi64 >> S.sh0;
+            const u32 bhi = bh >= (i64)ncell ? ncell - 1u : (u32)bh;
+            if (blo <= bhi) {
+                if (S.inlds && blo >= S.slo && bhi < S.shi) {
+                    const u32 a = S.s_off[blo - S.slo], b = S.s_off[bhi + 1 - S.slo];
+                    for (u32 j = a; j < b; j++) {
+                        const u64 x = S.s_ent[j];
+                        if ((i32)(u32)x <= qe && (i32)(u32)(x >> 32) >= qs) f(S.s_row[j]);
+                    }
+                } else {
+                    const u32 a = ix.binstart[S.lb + blo], b = ix.binstart[S.lb + bhi + 1];
+                    for (u32 j = a; j < b; j++) {
+                        const ivx_ent x = ix.ent[j];
+                        if (x.s <= qe && x.e >= qs) f(x.row);
+                    }
+                }
+            }
+        }
+    }
+    if (S.upper) {                                              // long-interval levels: global reads
+        for (u32 l = 1; l < S.nlev; l++) {
+            if (ix.hdr[HDR_LEVCNT + l] == 0) continue;
+            const u32 sh = S.sh0 + IVX_LSTEP * l;
+            u32 blo = 0, bhi = 0;
+            if (sh < 32) {
+                const u32 ncell = (S.span >> sh) + 1u;
+                const i64 lo64 = (i64)qs - ((i64)1 << sh) + 1 - (i64)S.origin;
+                const i64 bl = lo64 <= 0 ? 0 : (lo64 >> sh);
+                const i64 bh = hi64 >> sh;
+                if (bl >= (i64)ncell) continue;
+                blo = (u32)bl;
+                bhi = bh >= (i64)ncell ? ncell - 1u : (u32)bh;
+                if (blo > bhi) continue;
+            }
+            const u32 base = ix.lbase[(u64)l * ix.nkeys + S.k];
+            const u32 a = ix.binstart[base + blo], b = ix.binstart[base + bhi + 1];
+            for (u32 j = a; j < b; j++) {
+                const ivx_ent x = ix.ent[j];
+                if (x.s <= qe && x.e >= qs) f(x.row);
+            }
+        }
+    }
+}
+
+// Persistent workgroups, one per CU: workgroup b takes rows [T*b/G, T*(b+1)/G) of the partitioned
+// probe rows, region segment by region segment; inside a segment wavefront w owns wave batches
+// w, w+16, ... and never synchronises with the others.  FILL = false counts the pairs of every
+// (workgroup, wavefront) into wave_tot; FILL = true reads the scanned totals as each wavefront's
+// private output cursor and writes its pairs there: no atomics and no barriers in the hot loop.
+template <bool FILL>
+__global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const u64 *__restrict__ pse, const u32 *__restrict__ prow,
+                                                        const u32 *__restrict__ offs, u32 nblk,
+                                                        u64 *__restrict__ wave_tot,
+                                                        u32 *__restrict__ ob, u32 *__restrict__ op, u64 cap)
+{
+    __shared__ unsigned short s_off[RP_CCAP];
+    __shared__ u64 s_ent[RP_ECAP];
+    __shared__ u32 s_row[RP_ECAP];
+
+    const u32 tid = threadIdx.x, wv = tid / IVX_WAVE, ln = lane_id();
+    const u32 nreg = ix.hdr[HDR_NREG];
+    const u64 total_rows = offs[(u64)nreg * nblk];
+    u64 lo = total_rows * blockIdx.x / gridDim.x;
+    const u64 hi = total_rows * (blockIdx.x + 1) / gridDim.x;
+    u64 wcur = FILL ? wave_tot[(u64)blockIdx.x * RP_W + wv] : 0;     // FILL: output cursor, else pair count
+    const u64 wend = FILL ? wave_tot[(u64)blockIdx.x * RP_W + wv + 1] : 0;
+    const bool fits = !FILL || wend <= cap;                           // capacity error: write nothing
+    if (lo < hi) {
+        u32 r;
+        {   // last region whose first row is <= lo
+            u32 a = 0, b = nreg;
+            while (a < b) { const u32 m = (a + b + 1) >> 1; if (offs[(u64)m * nblk] <= lo) a = m; else b = m - 1; }
+            r = a;
+        }
+        Slice S;
+        S.ix = &ix; S.s_off = s_off; S.s_ent = s_ent; S.s_row = s_row;
+        S.sh0 = ix.hdr[HDR_SH0]; S.nlev = ix.hdr[HDR_NLEV];
+        const u32 cs = ix.hdr[HDR_CS];
+        S.upper = false;
+        for (u32 l = 1; l < S.nlev; l++) S.upper |= ix.hdr[HDR_LEVCNT + l] != 0;
+        S.lev0 = ix.hdr[HDR_LEVCNT] != 0;
+
+        for (; lo < hi; r++) {
+            const u64 rend = offs[(u64)(r + 1) * nblk];
+            const u64 c_hi = hi < rend ? hi : rend;
+            if (c_hi <= lo) continue;
+            // ---- stage the region's slice of the index in LDS
+            __syncthreads();
+            S.k = ix.rkey[r];
+            S.origin = ix.origin[S.k]; S.span = ix.span[S.k];
+            S.lb = ix.lbase[S.k];
+            const u32 cells0 = (S.span >> S.sh0) + 1u;
+            S.ncell0 = cells0;
+            const u32 rc0 = (r - ix.kreg[S.k]) << cs;
+            const u64 rc1w = (u64)rc0 + (1ull << cs);
+            const u32 rc1 = rc1w < cells0 ? (u32)rc1w : cells0;
+            S.slo = rc0 ? rc0 - 1u : 0u;
+            S.shi = rc1 + RP_HALO < cells0 ? rc1 + RP_HALO : cells0;
+            S.e0 = ix.binstart[S.lb + S.slo];
+            const u32 ne = ix.binstart[S.lb + S.shi] - S.e0;
+            const u32 nc = S.shi - S.slo + 1u;
+            S.inlds = ne <= RP_ECAP && nc <= RP_CCAP;
+            if (S.inlds) {
+                for (u32 c0 = 0; c0 < nc; c0 += RP_T * 4) {
+                    u32 v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { const u32 c = c0 + u * RP_T + tid; v[u] = c < nc ? ix.binstart[S.lb + S.slo + c] : 0u; }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { const u32 c = c0 + u * RP_T + tid; if (c < nc) s_off[c] = (unsigned short)(v[u] - S.e0); }
+                }
+                for (u32 j0 = 0; j0 < ne; j0 += RP_T * 4) {
+                    ivx_ent x[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { const u32 j = j0 + u * RP_T + tid; if (j < ne) x[u] = ix.ent[S.e0 + j]; }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const u32 j = j0 + u * RP_T + tid;
+                        if (j < ne) { s_ent[j] = (u64)(u32)x[u].s | ((u64)(u32)x[u].e << 32); s_row[j] = x[u].row; }
+                    }
+                }
+            }
+            __syncthreads();
+
+            // ---- wavefronts stream their batches independently
+            for (u64 b0 = lo + (u64)wv * RP_WB; b0 < c_hi; b0 += (u64)RP_W * RP_WB) {
+                i32 qs[RP_B], qe[RP_B]; u32 cnt[RP_B];
+#pragma unroll
+                for (int q = 0; q < RP_B; q++) {
+                    const u64 i = b0 + (u64)q * IVX_WAVE + ln;
+                    u64 x = 0;
+                    if (i < c_hi) x = pse[i];
+                    qs[q] = (i32)(u32)x; qe[q] = (i32)(u32)(x >> 32);
+                }
+                u32 tsum = 0;
+#pragma unroll
+                for (int q = 0; q < RP_B; q++) {
+                    const u64 i = b0 + (u64)q * IVX_WAVE + ln;
+                    u32 m = 0;
+                    if (i < c_hi) probe_row(S, qs[q], qe[q], [&](u32) { m++; });
+                    cnt[q] = m;
+                    tsum += m;
+                }
+                if (!FILL) { wcur += tsum; continue; }
+                // wavefront prefix sum -> every lane's slot range inside the wave's private output range
+                const u32 inc = wave_incl_scan(tsum);
+                const u32 wtot = __shfl(inc, IVX_WAVE - 1, IVX_WAVE);
+                u64 at = wcur + (inc - tsum);
+                if (fits) {
+#pragma unroll
+                    for (int q = 0; q < RP_B; q++) {
+                        if (cnt[q] == 0) continue;
+                        const u64 i = b0 + (u64)q * IVX_WAVE + ln;
+                        const u32 row = prow[i];
+                        probe_row(S, qs[q], qe[q], [&](u32 brow) { ob[at] = brow; op[at] = row; at++; });
+                    }
+                }
+                wcur += wtot;
+            }
+            lo = c_hi;
+        }
+    }
+    if (!FILL) {
+        const u64 tot = wave_sum(wcur);
+        if (ln == 0) wave_tot[(u64)blockIdx.x * RP_W + wv] = tot;
+    }
+}
+
+// total pairs -> the caller's cursor word (read back by the host)
+__global__ void k_publish_total(const u64 *wave_tot, u32 nwaves, unsigned long long *cursor) { *cursor = wave_tot[nwaves]; }
+
+}  // namespace
+
+ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, int mode,
+                                  const u32 *key, const i32 *s, const i32 *e, u64 n,
+                                  u32 *ob, u32 *op, u64 cap, u64 *d_cursor)
+{
+    if (n == 0) return IVX_OK;
+    hipStream_t st = ctx->stream;
+    const u32 nblk = (u32)((n + PA_CHUNK - 1) / PA_CHUNK);
+    u32 *hist; u64 *pse; u32 *prow;
+    const u64 nh = (u64)256 * nblk + 1;
+    IVX_TRY(ctx->get_scratch(WS_SORTHIST, nh * sizeof(u32), (void **)&hist));
+    IVX_TRY(ctx->get_scratch(WS_T0, n * sizeof(u64), (void **)&pse));
+    IVX_TRY(ctx->get_scratch(WS_T1, n * sizeof(u32), (void **)&prow));
+    IVX_HIP(ctx, hipMemsetAsync(hist + (nh - 1), 0, sizeof(u32), st));
+    hipLaunchKernelGGL(k_part_hist, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, n, nblk, hist);
+    IVX_TRY(ivx_scan_exclusive_u32(ctx, hist, nh));
+    hipLaunchKernelGGL(k_part_scatter, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, prow);
+    // pass 1: pairs per (workgroup, wavefront); exclusive scan = every wavefront's private output range
+    const u32 nwaves = RP_GRID * RP_W;
+    u64 *wave_tot;
+    IVX_TRY(ctx->get_scratch(WS_T2, ((size_t)nwaves + 1) * sizeof(u64), (void **)&wave_tot));
+    IVX_HIP(ctx, hipMemsetAsync(wave_tot + nwaves, 0, sizeof(u64), st));
+    hipLaunchKernelGGL(k_probe_regions<false>, dim3(RP_GRID), dim3(RP_T), 0, st, jv, (const u64 *)pse, (const u32 *)prow, (const u32 *)hist, nblk, wave_tot, ob, op, cap);
+    IVX_TRY(ivx_scan_exclusive_u64(ctx, wave_tot, (u64)nwaves + 1));
+    hipLaunchKernelGGL(k_publish_total, dim3(1), dim3(1), 0, st, (const u64 *)wave_tot, nwaves, (unsigned long long *)d_cursor);
+    if (mode == JP_FILL)   // pass 2: same walk, pairs written at their final offsets
+        hipLaunchKernelGGL(k_probe_regions<true>, dim3(RP_GRID), dim3(RP_T), 0, st, jv, (const u64 *)pse, (const u32 *)prow, (const u32 *)hist, nblk, wave_tot, ob, op, cap);
+    IVX_HIP(ctx, hipGetLastError());
+    return IVX_OK;
+}

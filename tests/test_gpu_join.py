@@ -27,10 +27,16 @@ def _check_join(ctx, bk, bs, be, pk, ps, pe, nkeys):
     total, per_row = ctx.overlap_count(ix, pk, ps, pe, per_row=True)
     assert total == len(want_b)
     assert (per_row.astype(np.uint64) == want_cnt).all()
-    assert ctx.overlap_count(ix, pk, ps, pe) == total
-    ob, op = ctx.overlap_fill(ix, pk, ps, pe, cap=total)
-    assert len(ob) == total
-    assert (pair_set(ob, op) == pair_set(want_b, want_p)).all()
+    # both probe paths: gathers straight from the index, and region-partitioned through LDS
+    for path in ("direct", "regions"):
+        os.environ["IVX_JOIN_PATH"] = path
+        try:
+            assert ctx.overlap_count(ix, pk, ps, pe) == total, path
+            ob, op = ctx.overlap_fill(ix, pk, ps, pe, cap=total)
+        finally:
+            del os.environ["IVX_JOIN_PATH"]
+        assert len(ob) == total, path
+        assert (pair_set(ob, op) == pair_set(want_b, want_p)).all(), path
     ex = ctx.exists(ix, pk, ps, pe)
     assert (ex == (want_cnt > 0)).all()
     ix.free()
@@ -97,6 +103,24 @@ def test_join_skew_deep_pileup(ctx):
     be = np.concatenate([bs[:-1] + rng.integers(100, 2000, 5000), [200_000_000]]).astype(np.int32)
     ps = rng.integers(999_000, 1_003_000, 3000).astype(np.int32)
     pe = ps + 150
+    z = np.zeros
+    _check_join(ctx, z(len(bs), np.uint32), bs, be, z(len(ps), np.uint32), ps, pe, 1)
+
+
+def test_join_regions_large_batch(ctx):
+    # big enough for the region path by default; many keys with uneven sizes, some without build rows
+    bk, bs, be = synth(300_000, 21, nkeys=40, mean_len=800, span=40_000_000)
+    pk, ps, pe = synth(3_000_000, 22, nkeys=44, mean_len=150, span=40_000_000)
+    pe[::101] = ps[::101] + 100_000                      # rows longer than the LDS slice halo
+    bs[:50] = 0; be[:50] = 39_000_000                    # a few chromosome-long build rows (upper levels)
+    _check_join(ctx, bk, bs, be, pk, ps, pe, 44)
+
+
+def test_join_regions_dense_slices_fall_back(ctx):
+    # regions whose slice does not fit LDS: 200k build rows inside 2 Mbp of one key
+    rng = np.random.default_rng(3)
+    bs = rng.integers(0, 2_000_000, 200_000).astype(np.int32); be = bs + rng.integers(0, 300, 200_000).astype(np.int32)
+    ps = rng.integers(0, 2_000_000, 400_000).astype(np.int32); pe = ps + 50
     z = np.zeros
     _check_join(ctx, z(len(bs), np.uint32), bs, be, z(len(ps), np.uint32), ps, pe, 1)
 
