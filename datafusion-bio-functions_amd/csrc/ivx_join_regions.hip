@@ -26,11 +26,12 @@ namespace {
 
 // ------------------------------------------------------------------ partition pass
 
-constexpr int PA_T = 256;
+constexpr int PA_T = 512;
 constexpr int PA_I = 8;
-constexpr int PA_TILE = PA_T * PA_I;              // 2048 rows
-constexpr int PA_TPB = 8;
+constexpr int PA_TILE = PA_T * PA_I;              // 4096 rows: ~20 rows per region and tile -> runs of a few cache lines
+constexpr int PA_TPB = 4;
 constexpr u64 PA_CHUNK = (u64)PA_TILE * PA_TPB;   // 16384 rows per workgroup
+constexpr int PA_ND = 256;                        // radix digits = regions (+ unused)
 constexpr u32 NO_REGION = 0xFFFFFFFFu;
 constexpr u32 KT_MAX = 256;                       // per-key tables cached in LDS up to this many keys
 
@@ -69,6 +70,29 @@ __device__ __forceinline__ u32 region_of(const JoinIndexView &ix, const KeyTab &
     return kreg + (c >> kt.cs);
 }
 
+// four consecutive probe rows per lane: 16-byte loads when the columns are 16-byte aligned
+template <bool VEC>
+__device__ __forceinline__ void load4(const u32 *__restrict__ pkey, const i32 *__restrict__ ps, const i32 *__restrict__ pe,
+                                      u64 i, u64 hi, u32 (&k)[4], i32 (&s)[4], i32 (&e)[4])
+{
+    if (VEC && i + 4 <= hi) {
+        const uint4 kv = pkey ? *reinterpret_cast<const uint4 *>(pkey + i) : make_uint4(0, 0, 0, 0);
+        const int4 sv = *reinterpret_cast<const int4 *>(ps + i);
+        k[0] = kv.x; k[1] = kv.y; k[2] = kv.z; k[3] = kv.w;
+        s[0] = sv.x; s[1] = sv.y; s[2] = sv.z; s[3] = sv.w;
+        if (pe) { const int4 ev = *reinterpret_cast<const int4 *>(pe + i); e[0] = ev.x; e[1] = ev.y; e[2] = ev.z; e[3] = ev.w; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const bool ok = i + j < hi;
+            k[j] = ok ? (pkey ? pkey[i + j] : 0u) : 0xFFFFFFFFu;       // key id 0xFFFFFFFF never matches
+            s[j] = ok ? ps[i + j] : 0;
+            e[j] = (ok && pe) ? pe[i + j] : 0;
+        }
+    }
+}
+
+template <bool VEC>
 __global__ __launch_bounds__(PA_T) void k_part_hist(JoinIndexView ix, const u32 *__restrict__ pkey, const i32 *__restrict__ ps,
                                                     u64 n, u32 nblk, u32 *__restrict__ hist)
 {
@@ -77,32 +101,28 @@ __global__ __launch_bounds__(PA_T) void k_part_hist(JoinIndexView ix, const u32 
     __shared__ u32 s_last[KT_MAX], s_kreg[KT_MAX];
     KeyTab kt;
     keytab_load(ix, s_origin, s_last, s_kreg, kt);
-    cnt[threadIdx.x] = 0;
+    if (threadIdx.x < PA_ND) cnt[threadIdx.x] = 0;
     __syncthreads();
     const u64 lo = (u64)blockIdx.x * PA_CHUNK;
     const u64 hi = lo + PA_CHUNK < n ? lo + PA_CHUNK : n;
     for (u64 i0 = lo; i0 < hi; i0 += (u64)PA_T * 4) {
-        u32 k[4]; i32 q[4]; bool ok[4];
+        u32 k[4]; i32 q[4], unused[4];
+        const u64 i = i0 + (u64)threadIdx.x * 4;
+        if (i >= hi) continue;
+        load4<VEC>(pkey, ps, nullptr, i, hi, k, q, unused);
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const u64 i = i0 + (u64)u * PA_T + threadIdx.x;
-            ok[u] = i < hi;
-            k[u] = ok[u] ? (pkey ? pkey[i] : 0u) : 0u;
-            q[u] = ok[u] ? ps[i] : 0;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            if (!ok[u]) continue;
             const u32 d = region_of(ix, kt, k[u], q[u]);
             if (d != NO_REGION) atomicAdd(&cnt[d], 1u);
         }
     }
     __syncthreads();
-    hist[(u64)threadIdx.x * nblk + blockIdx.x] = cnt[threadIdx.x];
+    if (threadIdx.x < PA_ND) hist[(u64)threadIdx.x * nblk + blockIdx.x] = cnt[threadIdx.x];
 }
 
 // order inside a region is irrelevant (the reference pins only the pair multiset), so the local
 // rank of a row is just the value an LDS counter held when the row arrived
+template <bool VEC>
 __global__ __launch_bounds__(PA_T) void k_part_scatter(JoinIndexView ix, const u32 *__restrict__ pkey, const i32 *__restrict__ ps,
                                                        const i32 *__restrict__ pe, u64 n, u32 nblk, const u32 *__restrict__ offs,
                                                        u64 *__restrict__ out_se, u32 *__restrict__ out_row)
@@ -118,21 +138,20 @@ __global__ __launch_bounds__(PA_T) void k_part_scatter(JoinIndexView ix, const u
     const u32 tid = threadIdx.x;
     KeyTab kt;
     keytab_load(ix, s_origin, s_last, s_kreg, kt);
-    gbase[tid] = offs[(u64)tid * nblk + blockIdx.x];
+    if (tid < PA_ND) gbase[tid] = offs[(u64)tid * nblk + blockIdx.x];
     const u64 lo = (u64)blockIdx.x * PA_CHUNK;
     const u64 hi = lo + PA_CHUNK < n ? lo + PA_CHUNK : n;
     for (u64 t0 = lo; t0 < hi; t0 += PA_TILE) {
-        tcnt[tid] = 0;
+        if (tid < PA_ND) tcnt[tid] = 0;
         __syncthreads();
         u64 se[PA_I]; u32 dig[PA_I], lrank[PA_I];
         u32 kk[PA_I]; i32 qs[PA_I], qe[PA_I];
 #pragma unroll
-        for (int k = 0; k < PA_I; k++) {
-            const u64 i = t0 + (u64)k * PA_T + tid;
-            const bool ok = i < hi;
-            kk[k] = ok ? (pkey ? pkey[i] : 0u) : 0xFFFFFFFFu;
-            qs[k] = ok ? ps[i] : 0;
-            qe[k] = ok ? pe[i] : 0;
+        for (int v = 0; v < PA_I / 4; v++) {
+            u32 k4[4]; i32 s4[4], e4[4];
+            load4<VEC>(pkey, ps, pe, t0 + ((u64)v * PA_T + tid) * 4, hi, k4, s4, e4);
+#pragma unroll
+            for (int j = 0; j < 4; j++) { kk[v * 4 + j] = k4[j]; qs[v * 4 + j] = s4[j]; qe[v * 4 + j] = e4[j]; }
         }
 #pragma unroll
         for (int k = 0; k < PA_I; k++) {
@@ -143,16 +162,16 @@ __global__ __launch_bounds__(PA_T) void k_part_scatter(JoinIndexView ix, const u
         }
         __syncthreads();
         u32 tot;
-        const u32 mine = tcnt[tid];
+        const u32 mine = tid < PA_ND ? tcnt[tid] : 0u;
         const u32 ds = block_excl_scan<u32, PA_T>(mine, scan_lds, &tot);
-        dstart[tid] = ds;
+        if (tid < PA_ND) dstart[tid] = ds;
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < PA_I; k++) {
             if (dig[k] != NO_REGION) {
                 const u32 pos = dstart[dig[k]] + lrank[k];
                 r_se[pos] = se[k];
-                r_row[pos] = (u32)(t0 + (u64)k * PA_T + tid);
+                r_row[pos] = (u32)(t0 + ((u64)(k / 4) * PA_T + tid) * 4 + (k % 4));
                 r_dig[pos] = (unsigned char)dig[k];
             }
         }
@@ -168,7 +187,7 @@ __global__ __launch_bounds__(PA_T) void k_part_scatter(JoinIndexView ix, const u
             }
         }
         __syncthreads();
-        gbase[tid] += mine;
+        if (tid < PA_ND) gbase[tid] += mine;
     }
 }
 
@@ -180,7 +199,8 @@ constexpr int RP_B = 8;                    // probe rows per lane per wave batch
 constexpr u32 RP_WB = IVX_WAVE * RP_B;     // rows per wave batch
 constexpr u32 RP_HALO = 8;                 // slice cells past the region's last cell
 constexpr u32 RP_CCAP = 8192 + RP_HALO + 2;
-constexpr u32 RP_ECAP = 8448;              // entries staged per slice
+constexpr u32 RP_ECAP = 7424;              // entries staged per slice
+constexpr u32 RP_QW = 384;                 // pairs a wavefront stages in LDS before one coalesced write
 constexpr u32 RP_GRID = 256;
 
 struct Slice {
@@ -261,6 +281,8 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
     __shared__ unsigned short s_off[RP_CCAP];
     __shared__ u64 s_ent[RP_ECAP];
     __shared__ u32 s_row[RP_ECAP];
+    __shared__ u32 s_qb[FILL ? RP_W : 1][FILL ? RP_QW : 1];     // per-wavefront pair staging
+    __shared__ u32 s_qp[FILL ? RP_W : 1][FILL ? RP_QW : 1];
 
     const u32 tid = threadIdx.x, wv = tid / IVX_WAVE, ln = lane_id();
     const u32 nreg = ix.hdr[HDR_NREG];
@@ -326,15 +348,20 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
             }
             __syncthreads();
 
-            // ---- wavefronts stream their batches independently
-            for (u64 b0 = lo + (u64)wv * RP_WB; b0 < c_hi; b0 += (u64)RP_W * RP_WB) {
+            // ---- wavefronts stream their batches independently; the next batch's rows are
+            //      in flight while the current one walks the LDS slice
+            u64 nx[RP_B];
+            u64 b0 = lo + (u64)wv * RP_WB;
+#pragma unroll
+            for (int q = 0; q < RP_B; q++) { const u64 i = b0 + (u64)q * IVX_WAVE + ln; nx[q] = i < c_hi ? pse[i] : 0; }
+            for (; b0 < c_hi; b0 += (u64)RP_W * RP_WB) {
                 i32 qs[RP_B], qe[RP_B]; u32 cnt[RP_B];
 #pragma unroll
-                for (int q = 0; q < RP_B; q++) {
-                    const u64 i = b0 + (u64)q * IVX_WAVE + ln;
-                    u64 x = 0;
-                    if (i < c_hi) x = pse[i];
-                    qs[q] = (i32)(u32)x; qe[q] = (i32)(u32)(x >> 32);
+                for (int q = 0; q < RP_B; q++) { qs[q] = (i32)(u32)nx[q]; qe[q] = (i32)(u32)(nx[q] >> 32); }
+                {
+                    const u64 b1 = b0 + (u64)RP_W * RP_WB;
+#pragma unroll
+                    for (int q = 0; q < RP_B; q++) { const u64 i = b1 + (u64)q * IVX_WAVE + ln; nx[q] = i < c_hi ? pse[i] : 0; }
                 }
                 u32 tsum = 0;
 #pragma unroll
@@ -349,14 +376,28 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
                 // wavefront prefix sum -> every lane's slot range inside the wave's private output range
                 const u32 inc = wave_incl_scan(tsum);
                 const u32 wtot = __shfl(inc, IVX_WAVE - 1, IVX_WAVE);
-                u64 at = wcur + (inc - tsum);
-                if (fits) {
+                if (fits && wtot) {
+                    if (wtot <= RP_QW) {
+                        u32 at = inc - tsum;                              // stage in LDS, then one coalesced copy
 #pragma unroll
-                    for (int q = 0; q < RP_B; q++) {
-                        if (cnt[q] == 0) continue;
-                        const u64 i = b0 + (u64)q * IVX_WAVE + ln;
-                        const u32 row = prow[i];
-                        probe_row(S, qs[q], qe[q], [&](u32 brow) { ob[at] = brow; op[at] = row; at++; });
+                        for (int q = 0; q < RP_B; q++) {
+                            if (cnt[q] == 0) continue;
+                            const u64 i = b0 + (u64)q * IVX_WAVE + ln;
+                            const u32 row = prow[i];
+                            probe_row(S, qs[q], qe[q], [&](u32 brow) { s_qb[wv][at] = brow; s_qp[wv][at] = row; at++; });
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        for (u32 t = ln; t < wtot; t += IVX_WAVE) { ob[wcur + t] = s_qb[wv][t]; op[wcur + t] = s_qp[wv][t]; }
+                        __builtin_amdgcn_wave_barrier();
+                    } else {
+                        u64 at = wcur + (inc - tsum);
+#pragma unroll
+                        for (int q = 0; q < RP_B; q++) {
+                            if (cnt[q] == 0) continue;
+                            const u64 i = b0 + (u64)q * IVX_WAVE + ln;
+                            const u32 row = prow[i];
+                            probe_row(S, qs[q], qe[q], [&](u32 brow) { ob[at] = brow; op[at] = row; at++; });
+                        }
                     }
                 }
                 wcur += wtot;
@@ -388,9 +429,12 @@ ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, int mod
     IVX_TRY(ctx->get_scratch(WS_T0, n * sizeof(u64), (void **)&pse));
     IVX_TRY(ctx->get_scratch(WS_T1, n * sizeof(u32), (void **)&prow));
     IVX_HIP(ctx, hipMemsetAsync(hist + (nh - 1), 0, sizeof(u32), st));
-    hipLaunchKernelGGL(k_part_hist, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, n, nblk, hist);
+    const bool vec = (((uintptr_t)key | (uintptr_t)s | (uintptr_t)e) & 15) == 0;
+    if (vec) hipLaunchKernelGGL(k_part_hist<true>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, n, nblk, hist);
+    else hipLaunchKernelGGL(k_part_hist<false>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, n, nblk, hist);
     IVX_TRY(ivx_scan_exclusive_u32(ctx, hist, nh));
-    hipLaunchKernelGGL(k_part_scatter, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, prow);
+    if (vec) hipLaunchKernelGGL(k_part_scatter<true>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, prow);
+    else hipLaunchKernelGGL(k_part_scatter<false>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, prow);
     // pass 1: pairs per (workgroup, wavefront); exclusive scan = every wavefront's private output range
     const u32 nwaves = RP_GRID * RP_W;
     u64 *wave_tot;

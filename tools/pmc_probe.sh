@@ -3,6 +3,8 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/pmc_$1
+shift
+[ $# -gt 0 ] && export "$@"
 mkdir -p $OUT
 i=0
 while read -r set; do
@@ -10,7 +12,7 @@ while read -r set; do
   rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -- python3 $R/tools/probe_only.py > $OUT/p$i.log 2>&1 || echo "pass $i failed"
 done <<SETS
 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY
-SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM_RD SQ_INSTS_LDS GRBM_GUI_ACTIVE
+SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE
 TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TA_BUSY_avr
 TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum
 FETCH_SIZE
