@@ -40,13 +40,16 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="join_100Mx1M_24contigs", choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-sample", type=int, default=20_000_000, help="probe rows timed on the CPU baseline (0 = skip)")
-    ap.add_argument("--gather", action="store_true", help="also all-gather the per-rank pair counts+buffers (RCCL) inside the step")
+    ap.add_argument("--cpu-sample", type=int, default=100_000_000, help="probe rows timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--gather", action="store_true", help="also all-gather the per-rank pair buffers (RCCL all-gatherv) inside the step")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank owns a full-size partition; strong: ONE job, contigs sharded over ranks by LPT")
     args = ap.parse_args()
 
     import numpy as np
     import torch
     import pyivx
+    import shard
     import synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -64,9 +67,21 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev)
 
     n_probe, n_build, n_contigs, cfg = WORKLOADS[args.workload]
-    seed = 0x5EED0000 + 2 * cfg + (rank << 8)                 # rank salt: every partition is different data
-    bk, bs, be = synth.gen_torch(n_build, 1000, n_contigs, seed + 0, dev)
-    pk, ps, pe = synth.gen_torch(n_probe, 150, n_contigs, seed + 1, dev)
+    if args.scaling == "weak":
+        seed = 0x5EED0000 + 2 * cfg + (rank << 8)             # rank salt: every partition is different data
+        bk, bs, be = synth.gen_torch(n_build, 1000, n_contigs, seed + 0, dev)
+        pk, ps, pe = synth.gen_torch(n_probe, 150, n_contigs, seed + 1, dev)
+    else:
+        # one fixed job; whole contigs go to ranks (greedy LPT on probe+build rows), no row crosses ranks
+        seed = 0x5EED0000 + 2 * cfg
+        bk, bs, be = synth.gen_torch(n_build, 1000, n_contigs, seed + 0, dev)
+        pk, ps, pe = synth.gen_torch(n_probe, 150, n_contigs, seed + 1, dev)
+        w = (torch.bincount(bk, minlength=n_contigs) + torch.bincount(pk, minlength=n_contigs)).cpu().numpy()
+        mine = torch.from_numpy(shard.assign_keys_lpt(w, world) == rank).to(dev)
+        mb, mp = mine[bk.long()], mine[pk.long()]
+        bk, bs, be = bk[mb].contiguous(), bs[mb].contiguous(), be[mb].contiguous()
+        pk, ps, pe = pk[mp].contiguous(), ps[mp].contiguous(), pe[mp].contiguous()
+        n_build, n_probe = int(bk.numel()), int(pk.numel())
     torch.cuda.synchronize()
 
     ctx = pyivx.Ctx(local_rank)                                # raises if the HIP library / gfx950 is missing
@@ -80,7 +95,7 @@ def main():
     ob = torch.empty(cap, dtype=torch.int32, device=dev)
     op = torch.empty(cap, dtype=torch.int32, device=dev)
     expect = n_probe * n_build * 1149.0 / sum(synth.HG38[:n_contigs])    # uniform-data expectation
-    if n_contigs == 24 and abs(pairs - expect) > 0.01 * expect:
+    if n_contigs == 24 and args.scaling == "weak" and abs(pairs - expect) > 0.01 * expect:
         raise SystemExit(f"pair count {pairs} is not within 1% of the uniform expectation {expect:.0f}")
 
     probe_ms = []
@@ -94,14 +109,7 @@ def main():
         assert b.numel() == pairs
         ix.free()
         if args.gather and dist is not None:
-            cnt = torch.tensor([pairs], dtype=torch.int64, device=dev)
-            allc = [torch.zeros_like(cnt) for _ in range(world)]
-            dist.all_gather(allc, cnt)
-            mx = int(max(int(c) for c in allc))
-            pad = torch.zeros(2 * mx, dtype=torch.int32, device=dev)
-            pad[:pairs] = ob[:pairs]; pad[mx:mx + pairs] = op[:pairs]
-            outb = torch.empty(world * 2 * mx, dtype=torch.int32, device=dev)
-            dist.all_gather_into_tensor(outb, pad)
+            shard.allgatherv(dist, (ob[:pairs], op[:pairs]))
 
     for _ in range(args.warmup):
         step()
@@ -118,9 +126,7 @@ def main():
     elapsed = time.perf_counter() - t0
     tot_pairs, tot_rows = pairs, n_probe
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
+        elapsed = shard.max_over_ranks(dist, elapsed, dev)
         c = torch.tensor([pairs, n_probe], dtype=torch.int64, device=dev)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         tot_pairs, tot_rows = int(c[0]), int(c[1])
@@ -136,7 +142,7 @@ def main():
             "unit": "overlap-pairs/s",
             "probe_rows_per_s": tot_rows * args.steps / elapsed,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": args.workload, "probe_rows_per_gpu": n_probe, "build_rows_per_gpu": n_build,
                        "contigs": n_contigs, "pairs_per_gpu": pairs, "parallelism": f"partition-per-gpu x{world}",

@@ -4,6 +4,7 @@
 #include "ivx_internal.hpp"
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 
 // ------------------------------------------------------------- ctx helpers
@@ -38,13 +39,53 @@ ivx_status ivx_ctx::get_pinned(int slot, size_t bytes, void **out)
     return IVX_OK;
 }
 
+// Index buffers are recycled through a small per-process pool: IntervalJoinExec builds one
+// index per query/partition and drops it, and hipMalloc/hipFree cost more than the build kernels.
+namespace {
+struct PoolBuf { void *p; size_t cap; int device; };
+std::mutex g_pool_mu;
+std::vector<PoolBuf> g_pool;
+constexpr size_t POOL_MAX_BUFS = 96;
+
+void *pool_take(int device, size_t bytes, size_t *cap)
+{
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    size_t best = g_pool.size();
+    for (size_t i = 0; i < g_pool.size(); i++) {
+        const PoolBuf &b = g_pool[i];
+        if (b.device != device || b.cap < bytes || b.cap > 2 * bytes + 4096) continue;
+        if (best == g_pool.size() || b.cap < g_pool[best].cap) best = i;
+    }
+    if (best == g_pool.size()) return nullptr;
+    void *p = g_pool[best].p;
+    *cap = g_pool[best].cap;
+    g_pool.erase(g_pool.begin() + best);
+    return p;
+}
+
+void pool_give(int device, void *p, size_t cap)
+{
+    void *drop = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        g_pool.push_back({p, cap, device});
+        if (g_pool.size() > POOL_MAX_BUFS) { drop = g_pool.front().p; g_pool.erase(g_pool.begin()); }
+    }
+    if (drop) (void)hipFree(drop);
+}
+}  // namespace
+
 ivx_status ivx_index_alloc(ivx_ctx *ctx, ivx_index *ix, size_t bytes, void **out)
 {
     if (bytes < 256) bytes = 256;
-    void *p = nullptr;
-    hipError_t e = hipMalloc(&p, bytes);
-    if (e != hipSuccess) return ctx->fail_hip("hipMalloc(index)", e);
+    size_t cap = bytes;
+    void *p = pool_take(ctx->device, bytes, &cap);
+    if (!p) {
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) return ctx->fail_hip("hipMalloc(index)", e);
+    }
     ix->allocs.push_back(p);
+    ix->alloc_caps.push_back(cap);
     ix->bytes += bytes;
     *out = p;
     return IVX_OK;
@@ -236,8 +277,9 @@ extern "C" ivx_status ivx_index_build(ivx_ctx *ctx, int kind, int mem, const uin
 extern "C" void ivx_index_free(ivx_index *ix)
 {
     if (!ix) return;
-    (void)hipSetDevice(ix->device);
-    for (void *p : ix->allocs) (void)hipFree(p);
+    // the caller guarantees no probe on this index is still running (same contract as dropping
+    // Arc<JoinLeftData>); buffers go back to the pool, to be reused only by later builds
+    for (size_t i = 0; i < ix->allocs.size(); i++) pool_give(ix->device, ix->allocs[i], ix->alloc_caps[i]);
     delete ix;
 }
 

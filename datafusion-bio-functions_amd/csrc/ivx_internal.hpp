@@ -125,6 +125,7 @@ struct ivx_index {
     u32 nkeys = 0;
     size_t bytes = 0;
     std::vector<void *> allocs;
+    std::vector<size_t> alloc_caps;
     JoinIndexView jv{};
     u32 jv_nreg = 0;            // >0: the region-partitioned probe is available
     RankGridView gs{}, ge{};

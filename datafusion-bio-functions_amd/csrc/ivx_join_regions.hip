@@ -21,6 +21,7 @@
 // HBM traffic per probe row: 8 B (hist) + 12 B + 12 B (scatter) + 12 B (probe) +
 // 8 B per pair, all streaming.
 #include "ivx_join.hpp"
+#include <cstdlib>
 
 namespace {
 
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(PA_T) void k_part_hist(JoinIndexView ix, const u32 
 template <bool VEC>
 __global__ __launch_bounds__(PA_T) void k_part_scatter(JoinIndexView ix, const u32 *__restrict__ pkey, const i32 *__restrict__ ps,
                                                        const i32 *__restrict__ pe, u64 n, u32 nblk, const u32 *__restrict__ offs,
-                                                       u64 *__restrict__ out_se, u32 *__restrict__ out_row)
+                                                       u64 *__restrict__ out_se, u32 *__restrict__ out_row, int dbg)
 {
     __shared__ u64 r_se[PA_TILE];
     __shared__ u32 r_row[PA_TILE];
@@ -149,7 +150,8 @@ __global__ __launch_bounds__(PA_T) void k_part_scatter(JoinIndexView ix, const u
 #pragma unroll
         for (int v = 0; v < PA_I / 4; v++) {
             u32 k4[4]; i32 s4[4], e4[4];
-            load4<VEC>(pkey, ps, pe, t0 + ((u64)v * PA_T + tid) * 4, hi, k4, s4, e4);
+            if (dbg & 2) { for (int j = 0; j < 4; j++) { k4[j] = (tid + j) % 24; s4[j] = (i32)((tid * 977u + j * 131071u + (u32)t0 * 7u) % 40000000u); e4[j] = s4[j] + 100; } }
+            else load4<VEC>(pkey, ps, pe, t0 + ((u64)v * PA_T + tid) * 4, hi, k4, s4, e4);
 #pragma unroll
             for (int j = 0; j < 4; j++) { kk[v * 4 + j] = k4[j]; qs[v * 4 + j] = s4[j]; qe[v * 4 + j] = e4[j]; }
         }
@@ -182,8 +184,10 @@ __global__ __launch_bounds__(PA_T) void k_part_scatter(JoinIndexView ix, const u
             if (j < tot) {
                 const u32 d = r_dig[j];
                 const u64 g = (u64)gbase[d] + (j - dstart[d]);
-                out_se[g] = r_se[j];
-                out_row[g] = r_row[j];
+                if (!(dbg & 1)) {
+                    if (dbg & 8) { __builtin_nontemporal_store(r_se[j], &out_se[g]); __builtin_nontemporal_store(r_row[j], &out_row[g]); }
+                    else { out_se[g] = r_se[j]; out_row[g] = r_row[j]; }
+                }
             }
         }
         __syncthreads();
@@ -276,7 +280,7 @@ template <bool FILL>
 __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const u64 *__restrict__ pse, const u32 *__restrict__ prow,
                                                         const u32 *__restrict__ offs, u32 nblk,
                                                         u64 *__restrict__ wave_tot,
-                                                        u32 *__restrict__ ob, u32 *__restrict__ op, u64 cap)
+                                                        u32 *__restrict__ ob, u32 *__restrict__ op, u64 cap, int dbg)
 {
     __shared__ unsigned short s_off[RP_CCAP];
     __shared__ u64 s_ent[RP_ECAP];
@@ -368,7 +372,7 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
                 for (int q = 0; q < RP_B; q++) {
                     const u64 i = b0 + (u64)q * IVX_WAVE + ln;
                     u32 m = 0;
-                    if (i < c_hi) probe_row(S, qs[q], qe[q], [&](u32) { m++; });
+                    if (i < c_hi) { if (dbg & 4) m = (u32)(qs[q] ^ qe[q]) & 1u; else probe_row(S, qs[q], qe[q], [&](u32) { m++; }); }
                     cnt[q] = m;
                     tsum += m;
                 }
@@ -429,22 +433,23 @@ ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, int mod
     IVX_TRY(ctx->get_scratch(WS_T0, n * sizeof(u64), (void **)&pse));
     IVX_TRY(ctx->get_scratch(WS_T1, n * sizeof(u32), (void **)&prow));
     IVX_HIP(ctx, hipMemsetAsync(hist + (nh - 1), 0, sizeof(u32), st));
+    const int dbg = getenv("IVX_DBG") ? atoi(getenv("IVX_DBG")) : 0;
     const bool vec = (((uintptr_t)key | (uintptr_t)s | (uintptr_t)e) & 15) == 0;
     if (vec) hipLaunchKernelGGL(k_part_hist<true>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, n, nblk, hist);
     else hipLaunchKernelGGL(k_part_hist<false>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, n, nblk, hist);
     IVX_TRY(ivx_scan_exclusive_u32(ctx, hist, nh));
-    if (vec) hipLaunchKernelGGL(k_part_scatter<true>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, prow);
-    else hipLaunchKernelGGL(k_part_scatter<false>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, prow);
+    if (vec) hipLaunchKernelGGL(k_part_scatter<true>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, prow, dbg);
+    else hipLaunchKernelGGL(k_part_scatter<false>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, prow, dbg);
     // pass 1: pairs per (workgroup, wavefront); exclusive scan = every wavefront's private output range
     const u32 nwaves = RP_GRID * RP_W;
     u64 *wave_tot;
     IVX_TRY(ctx->get_scratch(WS_T2, ((size_t)nwaves + 1) * sizeof(u64), (void **)&wave_tot));
     IVX_HIP(ctx, hipMemsetAsync(wave_tot + nwaves, 0, sizeof(u64), st));
-    hipLaunchKernelGGL(k_probe_regions<false>, dim3(RP_GRID), dim3(RP_T), 0, st, jv, (const u64 *)pse, (const u32 *)prow, (const u32 *)hist, nblk, wave_tot, ob, op, cap);
+    hipLaunchKernelGGL(k_probe_regions<false>, dim3(RP_GRID), dim3(RP_T), 0, st, jv, (const u64 *)pse, (const u32 *)prow, (const u32 *)hist, nblk, wave_tot, ob, op, cap, dbg);
     IVX_TRY(ivx_scan_exclusive_u64(ctx, wave_tot, (u64)nwaves + 1));
     hipLaunchKernelGGL(k_publish_total, dim3(1), dim3(1), 0, st, (const u64 *)wave_tot, nwaves, (unsigned long long *)d_cursor);
     if (mode == JP_FILL)   // pass 2: same walk, pairs written at their final offsets
-        hipLaunchKernelGGL(k_probe_regions<true>, dim3(RP_GRID), dim3(RP_T), 0, st, jv, (const u64 *)pse, (const u32 *)prow, (const u32 *)hist, nblk, wave_tot, ob, op, cap);
+        hipLaunchKernelGGL(k_probe_regions<true>, dim3(RP_GRID), dim3(RP_T), 0, st, jv, (const u64 *)pse, (const u32 *)prow, (const u32 *)hist, nblk, wave_tot, ob, op, cap, dbg);
     IVX_HIP(ctx, hipGetLastError());
     return IVX_OK;
 }

@@ -1,0 +1,60 @@
+"""Device-resident timing of the non-join operators at BASELINE.json scale (1 GPU)."""
+import os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "datafusion-bio-functions_amd"))
+import pyivx, synth
+dev = torch.device("cuda:0")
+which = os.environ.get("OPS", "count,coverage,nearest,merge,subtract").split(",")
+scale = float(os.environ.get("SCALE", "1"))
+ctx = pyivx.Ctx(0); ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+
+def timed(fn, reps=3):
+    best = 1e9; out = None
+    for _ in range(reps):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); out = fn(); torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    return best, out
+
+def report(name, secs, nbytes, extra=""):
+    print(f"{name:34s} {secs*1e3:10.3f} ms  {nbytes/secs/1e9:9.1f} GB/s algorithmic  {extra}", flush=True)
+
+if "count" in which or "coverage" in which:
+    nb, npr = int(1_000_000 * scale), int(100_000_000 * scale)
+    bk, bs, be = synth.gen_torch(nb, 1000, 24, 0x5EED0004, dev)
+    pk, ps, pe = synth.gen_torch(npr, 150, 24, 0x5EED0005, dev)
+    for kind, name, fn in ((pyivx.KIND_COUNT, "count_overlaps", "count_overlaps"), (pyivx.KIND_COVERAGE, "coverage", "coverage")):
+        if name.split("_")[0] not in which and name not in which: continue
+        tb, ix = timed(lambda: ctx.build(kind, bk, bs, be, n_keys=24))
+        tp, out = timed(lambda: getattr(ctx, fn)(ix, pk, ps, pe))
+        km = ctx.last_kernel_ms()
+        report(f"{name} build {nb}", tb, 12 * nb)
+        report(f"{name} probe {npr}x{nb}", tp, 12 * (npr + nb) + 8 * npr, f"kernel {km:.3f} ms sum={int(out.sum())}")
+        ix.free()
+if "nearest" in which:
+    nb, npr = int(50_000_000 * scale), int(50_000_000 * scale)
+    bk, bs, be = synth.gen_torch(nb, 1000, 24, 0x5EED0006, dev)
+    pk, ps, pe = synth.gen_torch(npr, 150, 24, 0x5EED0007, dev)
+    tb, ix = timed(lambda: ctx.build(pyivx.KIND_NEAREST, bk, bs, be, n_keys=24), reps=2)
+    report(f"nearest build {nb}", tb, 12 * nb, f"index {ix.device_bytes/1e9:.2f} GB")
+    tp, out = timed(lambda: ctx.nearest(ix, pk, ps, pe, k=1))
+    report(f"nearest k=1 probe {npr}x{nb}", tp, 12 * (npr + nb) + 16 * npr, f"kernel {ctx.last_kernel_ms():.3f} ms")
+    tp, out = timed(lambda: ctx.nearest(ix, pk[:npr // 5], ps[:npr // 5], pe[:npr // 5], k=3), reps=2)
+    report(f"nearest k=3 probe {npr//5}x{nb}", tp, 12 * (npr // 5 + nb) + 48 * (npr // 5), f"rows {out[0].numel()}")
+    ix.free(); del bk, bs, be, pk, ps, pe
+if "merge" in which or "subtract" in which:
+    n = int(float(os.environ.get("NMERGE", 200_000_000)) * scale)
+    k, s, e = synth.gen_torch(n, 1000, 24, 0x5EED0008, dev)
+    s64, e64 = s.to(torch.int64), e.to(torch.int64) + 1
+    del s, e
+    if "merge" in which:
+        tm, out = timed(lambda: ctx.merge(k, s64, e64, n_keys=24), reps=2)
+        m = out[0].numel()
+        report(f"merge {n}", tm, 20 * n + 28 * m, f"kernel {ctx.last_kernel_ms():.3f} ms out rows {m}")
+    if "subtract" in which:
+        nr = n // 10
+        rk, rs, re = synth.gen_torch(nr, 150, 24, 0x5EED0009, dev)
+        rs64, re64 = rs.to(torch.int64), re.to(torch.int64) + 1
+        ts, out = timed(lambda: ctx.subtract(k, s64, e64, rk, rs64, re64, n_keys=24), reps=1)
+        m = out[0].numel()
+        report(f"subtract {n}-{nr} (count+fill)", ts, 20 * (n + nr) + 20 * m, f"out rows {m}")
