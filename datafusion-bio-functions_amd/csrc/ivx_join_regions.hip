@@ -22,14 +22,15 @@
 // 8 B per pair, all streaming.
 #include "ivx_join.hpp"
 #include <cstdlib>
+#include <cstdlib>
 
 namespace {
 
 // ------------------------------------------------------------------ partition pass
 
-constexpr int PA_T = 512;
+constexpr int PA_T = 1024;
 constexpr int PA_I = 8;
-constexpr int PA_TILE = PA_T * PA_I;              // 4096 rows: ~20 rows per region and tile -> runs of a few cache lines
+constexpr int PA_TILE = PA_T * PA_I;              // 8192 rows: ~40 rows per region and tile; one workgroup per CU keeps the open output lines within L2
 constexpr int PA_TPB = 4;
 constexpr u64 PA_CHUNK = (u64)PA_TILE * PA_TPB;   // 16384 rows per workgroup
 constexpr int PA_ND = 256;                        // radix digits = regions (+ unused)
@@ -214,7 +215,8 @@ struct Slice {
     i32 origin; u32 span;
 };
 
-// every match of one probe row: f(build row)
+// every match of one probe row: f(v, is_slot) -- v is a slot of the staged slice (build row = s_row[v])
+// when is_slot, else the build row itself (general path)
 template <class F>
 __device__ __forceinline__ void probe_row(const Slice &S, i32 qs, i32 qe, F &&f)
 {
@@ -234,13 +236,13 @@ __device__ __forceinline__ void probe_row(const Slice &S, i32 qs, i32 qe, F &&f)
                     const u32 a = S.s_off[blo - S.slo], b = S.s_off[bhi + 1 - S.slo];
                     for (u32 j = a; j < b; j++) {
                         const u64 x = S.s_ent[j];
-                        if ((i32)(u32)x <= qe && (i32)(u32)(x >> 32) >= qs) f(S.s_row[j]);
+                        if ((i32)(u32)x <= qe && (i32)(u32)(x >> 32) >= qs) f(j, true);
                     }
                 } else {
                     const u32 a = ix.binstart[S.lb + blo], b = ix.binstart[S.lb + bhi + 1];
                     for (u32 j = a; j < b; j++) {
                         const ivx_ent x = ix.ent[j];
-                        if (x.s <= qe && x.e >= qs) f(x.row);
+                        if (x.s <= qe && x.e >= qs) f(x.row, false);
                     }
                 }
             }
@@ -265,7 +267,7 @@ __device__ __forceinline__ void probe_row(const Slice &S, i32 qs, i32 qe, F &&f)
             const u32 a = ix.binstart[base + blo], b = ix.binstart[base + bhi + 1];
             for (u32 j = a; j < b; j++) {
                 const ivx_ent x = ix.ent[j];
-                if (x.s <= qe && x.e >= qs) f(x.row);
+                if (x.s <= qe && x.e >= qs) f(x.row, false);
             }
         }
     }
@@ -354,54 +356,77 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
 
             // ---- wavefronts stream their batches independently; the next batch's rows are
             //      in flight while the current one walks the LDS slice
-            u64 nx[RP_B];
+            u64 nx[RP_B]; u32 nxr[FILL ? RP_B : 1];
             u64 b0 = lo + (u64)wv * RP_WB;
 #pragma unroll
-            for (int q = 0; q < RP_B; q++) { const u64 i = b0 + (u64)q * IVX_WAVE + ln; nx[q] = i < c_hi ? pse[i] : 0; }
+            for (int q = 0; q < RP_B; q++) {
+                const u64 i = b0 + (u64)q * IVX_WAVE + ln;
+                nx[q] = i < c_hi ? pse[i] : 0;
+                if (FILL) nxr[q] = i < c_hi ? prow[i] : 0u;
+            }
             for (; b0 < c_hi; b0 += (u64)RP_W * RP_WB) {
-                i32 qs[RP_B], qe[RP_B]; u32 cnt[RP_B];
+                i32 qs[RP_B], qe[RP_B]; u32 rowv[FILL ? RP_B : 1];
 #pragma unroll
-                for (int q = 0; q < RP_B; q++) { qs[q] = (i32)(u32)nx[q]; qe[q] = (i32)(u32)(nx[q] >> 32); }
+                for (int q = 0; q < RP_B; q++) { qs[q] = (i32)(u32)nx[q]; qe[q] = (i32)(u32)(nx[q] >> 32); if (FILL) rowv[q] = nxr[q]; }
                 {
                     const u64 b1 = b0 + (u64)RP_W * RP_WB;
 #pragma unroll
-                    for (int q = 0; q < RP_B; q++) { const u64 i = b1 + (u64)q * IVX_WAVE + ln; nx[q] = i < c_hi ? pse[i] : 0; }
+                    for (int q = 0; q < RP_B; q++) {
+                        const u64 i = b1 + (u64)q * IVX_WAVE + ln;
+                        nx[q] = i < c_hi ? pse[i] : 0;
+                        if (FILL) nxr[q] = i < c_hi ? prow[i] : 0u;
+                    }
                 }
                 u32 tsum = 0;
+                u32 cnt[FILL ? RP_B : 1], p01[FILL ? RP_B : 1], p2[FILL ? RP_B : 1];   // first three matches as 16-bit slice slots
+                u32 rewalk = 0;                                           // bit q: more than 3 matches or a non-slot match
 #pragma unroll
                 for (int q = 0; q < RP_B; q++) {
                     const u64 i = b0 + (u64)q * IVX_WAVE + ln;
-                    u32 m = 0;
-                    if (i < c_hi) { if (dbg & 4) m = (u32)(qs[q] ^ qe[q]) & 1u; else probe_row(S, qs[q], qe[q], [&](u32) { m++; }); }
-                    cnt[q] = m;
-                    tsum += m;
+                    if (!FILL) {
+                        if (i >= c_hi) continue;
+                        if (dbg & 4) tsum += (u32)(qs[q] ^ qe[q]) & 1u;
+                        else probe_row(S, qs[q], qe[q], [&](u32, bool) { tsum++; });
+                    } else {
+                        u32 m = 0, a01 = 0, a2 = 0;
+                        if (i < c_hi)
+                            probe_row(S, qs[q], qe[q], [&](u32 v, bool sl) {
+                                if (!sl) rewalk |= 1u << q;
+                                if (m == 0) a01 = v; else if (m == 1) a01 |= v << 16; else if (m == 2) a2 = v;
+                                m++;
+                            });
+                        if (m > 3) rewalk |= 1u << q;
+                        cnt[q] = m; p01[q] = a01; p2[q] = a2;
+                        tsum += m;
+                    }
                 }
                 if (!FILL) { wcur += tsum; continue; }
-                // wavefront prefix sum -> every lane's slot range inside the wave's private output range
+                // wavefront prefix sum over the lanes' pair counts -> each lane's slots in the wave's private range
                 const u32 inc = wave_incl_scan(tsum);
                 const u32 wtot = __shfl(inc, IVX_WAVE - 1, IVX_WAVE);
                 if (fits && wtot) {
-                    if (wtot <= RP_QW) {
-                        u32 at = inc - tsum;                              // stage in LDS, then one coalesced copy
+                    const bool staged = wtot <= RP_QW;                   // stage in LDS, then one coalesced copy
+                    u32 at = inc - tsum;
+                    auto put = [&](u32 brow, u32 prow_id) {
+                        if (staged) { s_qb[wv][at] = brow; s_qp[wv][at] = prow_id; }
+                        else { ob[wcur + at] = brow; op[wcur + at] = prow_id; }
+                        at++;
+                    };
 #pragma unroll
-                        for (int q = 0; q < RP_B; q++) {
-                            if (cnt[q] == 0) continue;
-                            const u64 i = b0 + (u64)q * IVX_WAVE + ln;
-                            const u32 row = prow[i];
-                            probe_row(S, qs[q], qe[q], [&](u32 brow) { s_qb[wv][at] = brow; s_qp[wv][at] = row; at++; });
+                    for (int q = 0; q < RP_B; q++) {
+                        if (cnt[q] == 0) continue;
+                        if (!((rewalk >> q) & 1u)) {
+                            put(S.s_row[p01[q] & 0xFFFFu], rowv[q]);
+                            if (cnt[q] > 1) put(S.s_row[p01[q] >> 16], rowv[q]);
+                            if (cnt[q] > 2) put(S.s_row[p2[q]], rowv[q]);
+                        } else {
+                            probe_row(S, qs[q], qe[q], [&](u32 v, bool sl) { put(sl ? S.s_row[v] : v, rowv[q]); });
                         }
+                    }
+                    if (staged) {
                         __builtin_amdgcn_wave_barrier();
-                        for (u32 t = ln; t < wtot; t += IVX_WAVE) { ob[wcur + t] = s_qb[wv][t]; op[wcur + t] = s_qp[wv][t]; }
+                        if (!(dbg & 16)) for (u32 t = ln; t < wtot; t += IVX_WAVE) { ob[wcur + t] = s_qb[wv][t]; op[wcur + t] = s_qp[wv][t]; }
                         __builtin_amdgcn_wave_barrier();
-                    } else {
-                        u64 at = wcur + (inc - tsum);
-#pragma unroll
-                        for (int q = 0; q < RP_B; q++) {
-                            if (cnt[q] == 0) continue;
-                            const u64 i = b0 + (u64)q * IVX_WAVE + ln;
-                            const u32 row = prow[i];
-                            probe_row(S, qs[q], qe[q], [&](u32 brow) { ob[at] = brow; op[at] = row; at++; });
-                        }
                     }
                 }
                 wcur += wtot;
@@ -433,7 +458,7 @@ ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, int mod
     IVX_TRY(ctx->get_scratch(WS_T0, n * sizeof(u64), (void **)&pse));
     IVX_TRY(ctx->get_scratch(WS_T1, n * sizeof(u32), (void **)&prow));
     IVX_HIP(ctx, hipMemsetAsync(hist + (nh - 1), 0, sizeof(u32), st));
-    const int dbg = getenv("IVX_DBG") ? atoi(getenv("IVX_DBG")) : 0;
+    const int dbg = getenv("IVX_DBG") ? atoi(getenv("IVX_DBG")) : 0;   // ablation switches for profiling only
     const bool vec = (((uintptr_t)key | (uintptr_t)s | (uintptr_t)e) & 15) == 0;
     if (vec) hipLaunchKernelGGL(k_part_hist<true>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, n, nblk, hist);
     else hipLaunchKernelGGL(k_part_hist<false>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, n, nblk, hist);
