@@ -1,0 +1,231 @@
+"""Table-level mirror of the reference's range functions, driven through libbio_ranges_hip.so
+(Arrow C Data Interface) -- what a DataFusion session would expose as
+
+    count_overlaps('l','r'), coverage('l','r'), nearest('l','r',k,overlap,distance),
+    overlap('l','r'[,mode]), merge('t'[,min_dist]), subtract('l','r'),
+    and the SQL range join handled by IntervalJoinExec
+
+Argument meaning and output schemas follow R/src/table_function.rs and the providers
+(`left_`/`right_` prefixes: nearest.rs:57-78, overlap.rs:106-126; appended `count`/`coverage`
+column: count_overlaps.rs:60-66; Int64 start/end + n_intervals: merge.rs:43-48).  pyarrow only
+plays DataFusion's part (holding the tables, `take` of payload columns); every interval
+computation happens in the HIP kernels.  There is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+import pyarrow as pa
+import pyarrow.compute as pc
+
+import pyivx
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "lib", "libbio_ranges_hip.so")
+
+DEFAULT_COLS = ("contig", "pos_start", "pos_end")
+WEAK, STRICT = 0, 1
+JOIN_INNER, JOIN_RIGHT_SEMI, JOIN_RIGHT_ANTI = 0, 1, 2
+
+
+class _ArrowSchema(C.Structure):
+    pass
+
+
+class _ArrowArray(C.Structure):
+    pass
+
+
+_ArrowSchema._fields_ = [("format", C.c_char_p), ("name", C.c_char_p), ("metadata", C.c_char_p), ("flags", C.c_int64),
+                         ("n_children", C.c_int64), ("children", C.POINTER(C.POINTER(_ArrowSchema))),
+                         ("dictionary", C.POINTER(_ArrowSchema)), ("release", C.c_void_p), ("private_data", C.c_void_p)]
+_ArrowArray._fields_ = [("length", C.c_int64), ("null_count", C.c_int64), ("offset", C.c_int64), ("n_buffers", C.c_int64),
+                        ("n_children", C.c_int64), ("buffers", C.POINTER(C.c_void_p)),
+                        ("children", C.POINTER(C.POINTER(_ArrowArray))), ("dictionary", C.POINTER(_ArrowArray)),
+                        ("release", C.c_void_p), ("private_data", C.c_void_p)]
+
+
+class _Batch(C.Structure):
+    _fields_ = [("array", C.POINTER(_ArrowArray)), ("schema", C.POINTER(_ArrowSchema))]
+
+
+class _Columns(C.Structure):
+    _fields_ = [("keys", C.POINTER(C.c_char_p)), ("n_keys", C.c_int), ("start", C.c_char_p), ("end", C.c_char_p)]
+
+
+class BioRangesError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        pyivx.lib()                                   # loads libivx_hip.so (and the HIP runtime) first
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.brh_last_error.restype = C.c_char_p
+    return _lib
+
+
+class _Exported:
+    """A pyarrow Table exported as one struct array (kept alive for the call)."""
+
+    def __init__(self, table):
+        self.batch = table.combine_chunks().to_batches()[0] if table.num_rows else pa.RecordBatch.from_pylist([], schema=table.schema)
+        self.arr, self.sch = _ArrowArray(), _ArrowSchema()
+        self.batch._export_to_c(C.addressof(self.arr), C.addressof(self.sch))
+        self.c = _Batch(C.pointer(self.arr), C.pointer(self.sch))
+
+    def close(self):
+        for obj in (self.arr, self.sch):
+            if obj.release:
+                C.CFUNCTYPE(None, C.c_void_p)(obj.release)(C.addressof(obj))
+
+
+def _cols(cols):
+    keys = cols[0] if isinstance(cols[0], (list, tuple)) else [cols[0]]
+    arr = (C.c_char_p * len(keys))(*[k.encode() for k in keys])
+    c = _Columns(arr, len(keys), cols[1].encode(), cols[2].encode())
+    c._keep = arr
+    return c
+
+
+def _out():
+    return _ArrowArray(), _ArrowSchema()
+
+
+def _import(a, s):
+    return pa.Array._import_from_c(C.addressof(a), C.addressof(s))
+
+
+class Session:
+    """create_bio_session() counterpart: owns the GPU context."""
+
+    def __init__(self, device=0):
+        self.h = C.c_void_p()
+        rc = lib().brh_session_create(C.c_int(device), C.byref(self.h))
+        if rc != 0:
+            raise BioRangesError(f"no usable gfx950 device (status {rc}); there is no CPU fallback")
+
+    def close(self):
+        if self.h:
+            lib().brh_session_free(self.h)
+            self.h = None
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise BioRangesError(lib().brh_last_error(self.h).decode())
+
+    # ---- count_overlaps / coverage: RangeTableFunction (table_function.rs:521-560)
+    def _count(self, left, right, cols_left, cols_right, strict, coverage):
+        L, R = _Exported(left), _Exported(right)
+        a, s = _out()
+        try:
+            self._chk(lib().brh_count_overlaps(self.h, L.c, _cols(cols_left), R.c, _cols(cols_right),
+                                               C.c_int(STRICT if strict else WEAK), C.c_int(int(coverage)), C.byref(a), C.byref(s)))
+        finally:
+            L.close(); R.close()
+        col = _import(a, s)
+        return right.append_column("coverage" if coverage else "count", col)
+
+    def count_overlaps(self, left, right, cols_left=DEFAULT_COLS, cols_right=DEFAULT_COLS, strict=False):
+        return self._count(left, right, cols_left, cols_right, strict, False)
+
+    def coverage(self, left, right, cols_left=DEFAULT_COLS, cols_right=DEFAULT_COLS, strict=False):
+        return self._count(left, right, cols_left, cols_right, strict, True)
+
+    # ---- nearest: NearestTableFunction (table_function.rs:286-367)
+    def nearest(self, left, right, k=1, overlap=True, compute_distance=True, cols_left=DEFAULT_COLS, cols_right=DEFAULT_COLS,
+                strict=False):
+        L, R = _Exported(left), _Exported(right)
+        (la, ls), (ra, rs), (da, ds) = _out(), _out(), _out()
+        try:
+            self._chk(lib().brh_nearest(self.h, L.c, _cols(cols_left), R.c, _cols(cols_right), C.c_int(STRICT if strict else WEAK),
+                                        C.c_uint32(int(k)), C.c_int(int(overlap)), C.c_int(int(compute_distance)),
+                                        C.byref(la), C.byref(ls), C.byref(ra), C.byref(rs), C.byref(da), C.byref(ds)))
+        finally:
+            L.close(); R.close()
+        li, ri = _import(la, ls), _import(ra, rs)
+        out = {}
+        for name in left.schema.names:                       # nearest.rs:57-78: left_*, right_*, distance
+            out["left_" + name] = pc.take(left.column(name), li)
+        for name in right.schema.names:
+            out["right_" + name] = pc.take(right.column(name), ri)
+        if compute_distance:
+            out["distance"] = _import(da, ds)
+        return pa.table(out)
+
+    # ---- IntervalJoinExec (the SQL range join), `build` = the SQL join's left table
+    def interval_join(self, build, probe, cols_build=DEFAULT_COLS, cols_probe=DEFAULT_COLS, join_type=JOIN_INNER,
+                      strict_predicate=False, nearest_algorithm=False):
+        B, P = _Exported(build), _Exported(probe)
+        (ba, bs), (pa_, ps) = _out(), _out()
+        try:
+            self._chk(lib().brh_interval_join(self.h, B.c, _cols(cols_build), P.c, _cols(cols_probe), C.c_int(join_type),
+                                              C.c_int(int(strict_predicate)), C.c_int(int(nearest_algorithm)),
+                                              C.byref(ba), C.byref(bs), C.byref(pa_), C.byref(ps)))
+        finally:
+            B.close(); P.close()
+        return _import(ba, bs), _import(pa_, ps)
+
+    def sql_range_join(self, build, probe, cols_build=DEFAULT_COLS, cols_probe=DEFAULT_COLS, strict_predicate=False,
+                       nearest_algorithm=False):
+        """SELECT * FROM build JOIN probe ON key = key AND range predicate  (build columns, then probe columns)."""
+        bi, pi = self.interval_join(build, probe, cols_build, cols_probe, JOIN_INNER, strict_predicate, nearest_algorithm)
+        cols = [pc.take(build.column(n), bi) for n in build.schema.names] + [pc.take(probe.column(n), pi) for n in probe.schema.names]
+        names = [f"l.{n}" for n in build.schema.names] + [f"r.{n}" for n in probe.schema.names]
+        return pa.table(cols, names=names)
+
+    # ---- overlap UDTF (overlap.rs:154-226): FROM right AS b, left AS a  => the user's RIGHT table is the build side
+    def overlap(self, left, right, mode="join", cols_left=DEFAULT_COLS, cols_right=DEFAULT_COLS, strict=False):
+        if mode == "left":                                   # LeftDistinct: RIGHT SEMI JOIN, left rows that have a match
+            _, pi = self.interval_join(right, left, cols_right, cols_left, JOIN_RIGHT_SEMI, strict)
+            return left.take(pi)
+        bi, pi = self.interval_join(right, left, cols_right, cols_left, JOIN_INNER, strict)
+        if mode == "left_all":                               # Inner projecting left only (overlap multiplicity kept)
+            return left.take(pi)
+        out = {"left_" + n: pc.take(left.column(n), pi) for n in left.schema.names}
+        out.update({"right_" + n: pc.take(right.column(n), bi) for n in right.schema.names})
+        return pa.table(out)
+
+    # ---- merge (table_function.rs:441-464)
+    def merge(self, table, min_dist=0, cols=DEFAULT_COLS, strict=False):
+        if min_dist < 0:
+            raise BioRangesError(f"merge() min_dist must be >= 0, got {min_dist}")          # table_function.rs:237
+        T = _Exported(table)
+        outs = [_out() for _ in range(4)]
+        try:
+            self._chk(lib().brh_merge(self.h, T.c, _cols(cols), C.c_int64(int(min_dist)), C.c_int(STRICT if strict else WEAK),
+                                      *[C.byref(x) for pair in outs for x in pair]))
+        finally:
+            T.close()
+        key = cols[0] if isinstance(cols[0], str) else cols[0][0]
+        return pa.table([_import(*o) for o in outs], names=[key, cols[1], cols[2], "n_intervals"])
+
+    # ---- subtract (table_function.rs:574-612); extra left columns are carried along (subtract.rs:501-527)
+    def subtract(self, left, right, cols_left=DEFAULT_COLS, cols_right=DEFAULT_COLS, strict=False):
+        L, R = _Exported(left), _Exported(right)
+        outs = [_out() for _ in range(4)]
+        try:
+            self._chk(lib().brh_subtract(self.h, L.c, _cols(cols_left), R.c, _cols(cols_right), C.c_int(STRICT if strict else WEAK),
+                                         *[C.byref(x) for pair in outs for x in pair]))
+        finally:
+            L.close(); R.close()
+        contig, start, end, row = [_import(*o) for o in outs]
+        key = cols_left[0] if isinstance(cols_left[0], str) else cols_left[0][0]
+        cols = []
+        for n in left.schema.names:
+            cols.append(contig if n == key else start if n == cols_left[1] else end if n == cols_left[2] else pc.take(left.column(n), row))
+        return pa.table(cols, names=left.schema.names)
+
+
+def check_position_column(table, column, as_i64=False):
+    """PosArray::resolve / resolve_i64 checks alone (no GPU): returns None or the error text."""
+    T = _Exported(table)
+    buf = C.create_string_buffer(512)
+    try:
+        rc = lib().brh_check_position_column(None, T.c, column.encode(), C.c_int(int(as_i64)), buf, C.c_int(512))
+    finally:
+        T.close()
+    return None if rc == 0 else buf.value.decode()

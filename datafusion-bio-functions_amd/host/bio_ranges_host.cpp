@@ -1,0 +1,450 @@
+// bio_ranges_host.cpp -- host-side operator mirror over the Arrow C Data Interface
+// (see include/bio_ranges_host.h).  Plain C++17; the only dependency is libivx_hip.so.
+#include "../../include/bio_ranges_host.h"
+#include "../../include/ivx.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <string_view>
+#include <unordered_map>
+#include <vector>
+
+struct brh_session {
+    ivx_ctx *ctx = nullptr;
+    std::string err;
+};
+
+namespace {
+
+int fail(brh_session *s, const std::string &m) { if (s) s->err = m; return 1; }
+
+int fail_ivx(brh_session *s, ivx_status st)
+{
+    return fail(s, std::string(ivx_last_error(s->ctx)) + " (ivx status " + std::to_string(st) + ")");
+}
+
+std::string column_list(const ArrowSchema *sch)
+{
+    std::string o = "[";
+    for (int64_t i = 0; i < sch->n_children; i++) {
+        if (i) o += ", ";
+        o += "\"" + std::string(sch->children[i]->name ? sch->children[i]->name : "") + "\"";
+    }
+    return o + "]";
+}
+
+int find_col(const ArrowSchema *sch, const char *name)
+{
+    for (int64_t i = 0; i < sch->n_children; i++)
+        if (sch->children[i]->name && !std::strcmp(sch->children[i]->name, name)) return (int)i;
+    return -1;
+}
+
+int64_t null_count(const ArrowArray *a)
+{
+    if (a->null_count >= 0) return a->null_count;
+    if (a->n_buffers < 1 || !a->buffers[0]) return 0;
+    const uint8_t *v = (const uint8_t *)a->buffers[0];
+    int64_t n = 0;
+    for (int64_t i = 0; i < a->length; i++) { int64_t j = i + a->offset; n += !((v[j >> 3] >> (j & 7)) & 1); }
+    return n;
+}
+
+// ---- ContigArray (array_utils.rs:10-24): Utf8 / LargeUtf8 / Utf8View
+struct StrCol {
+    int kind = 0;               // 0 Utf8, 1 LargeUtf8, 2 Utf8View
+    const ArrowArray *a = nullptr;
+    std::string_view at(int64_t i) const
+    {
+        const int64_t j = i + a->offset;
+        if (kind == 0) { const int32_t *o = (const int32_t *)a->buffers[1]; return {(const char *)a->buffers[2] + o[j], (size_t)(o[j + 1] - o[j])}; }
+        if (kind == 1) { const int64_t *o = (const int64_t *)a->buffers[1]; return {(const char *)a->buffers[2] + o[j], (size_t)(o[j + 1] - o[j])}; }
+        const uint8_t *v = (const uint8_t *)a->buffers[1] + 16 * j;
+        int32_t len; std::memcpy(&len, v, 4);
+        if (len <= 12) return {(const char *)v + 4, (size_t)len};
+        int32_t bi, off; std::memcpy(&bi, v + 8, 4); std::memcpy(&off, v + 12, 4);
+        return {(const char *)a->buffers[2 + bi] + off, (size_t)len};
+    }
+};
+
+int get_contig(brh_session *s, brh_batch t, const char *name, StrCol *out)
+{
+    const int c = find_col(t.schema, name);
+    if (c < 0) return fail(s, "contig column '" + std::string(name) + "' not found in batch with columns: " + column_list(t.schema));
+    const char *f = t.schema->children[c]->format;
+    out->a = t.array->children[c];
+    if (!std::strcmp(f, "u")) out->kind = 0;
+    else if (!std::strcmp(f, "U")) out->kind = 1;
+    else if (!std::strcmp(f, "vu")) out->kind = 2;
+    else return fail(s, "unsupported data type " + std::string(f) + " for contig column '" + name + "'; expected Utf8, LargeUtf8, or Utf8View");
+    return 0;
+}
+
+// ---- PosArray (array_utils.rs:26-172)
+struct PosCol { char fmt = 0; const ArrowArray *a = nullptr; };
+
+int get_pos(brh_session *s, brh_batch t, const char *name, const char *label, PosCol *out)
+{
+    const int c = find_col(t.schema, name);
+    if (c < 0) return fail(s, std::string(label) + " column '" + name + "' not found in batch with columns: " + column_list(t.schema));
+    const char *f = t.schema->children[c]->format;
+    if (std::strlen(f) != 1 || !std::strchr("ilIL", f[0]))
+        return fail(s, "unsupported data type " + std::string(f) + " for " + label + " column '" + name + "'; expected Int32, Int64, UInt32, or UInt64");
+    out->fmt = f[0]; out->a = t.array->children[c];
+    return 0;
+}
+
+// PosArray::resolve (array_utils.rs:66-135)
+int resolve_i32(brh_session *s, const PosCol &p, std::vector<int32_t> *out)
+{
+    if (null_count(p.a) > 0) return fail(s, "coordinate column contains null values; nearest requires non-null coordinates");
+    const int64_t n = p.a->length, o = p.a->offset;
+    out->resize((size_t)n);
+    char buf[160];
+    for (int64_t i = 0; i < n; i++) {
+        if (p.fmt == 'i') { (*out)[i] = ((const int32_t *)p.a->buffers[1])[o + i]; continue; }
+        bool ok; long long sv = 0; unsigned long long uv = 0;
+        if (p.fmt == 'l') { sv = ((const int64_t *)p.a->buffers[1])[o + i]; ok = sv >= INT32_MIN && sv <= INT32_MAX; }
+        else if (p.fmt == 'I') { uv = ((const uint32_t *)p.a->buffers[1])[o + i]; ok = uv <= (unsigned long long)INT32_MAX; sv = (long long)uv; }
+        else { uv = ((const uint64_t *)p.a->buffers[1])[o + i]; ok = uv <= (unsigned long long)INT32_MAX; sv = (long long)uv; }
+        if (!ok) {
+            if (p.fmt == 'l') std::snprintf(buf, sizeof buf, "coordinate value %lld at row %lld overflows i32 (max 2147483647)", sv, (long long)i);
+            else std::snprintf(buf, sizeof buf, "coordinate value %llu at row %lld overflows i32 (max 2147483647)", uv, (long long)i);
+            return fail(s, buf);
+        }
+        (*out)[i] = (int32_t)sv;
+    }
+    return 0;
+}
+
+// PosArray::resolve_i64 (array_utils.rs:137-172)
+int resolve_i64(brh_session *s, const PosCol &p, std::vector<int64_t> *out)
+{
+    if (null_count(p.a) > 0) return fail(s, "coordinate column contains null values; requires non-null coordinates");
+    const int64_t n = p.a->length, o = p.a->offset;
+    out->resize((size_t)n);
+    char buf[160];
+    for (int64_t i = 0; i < n; i++) {
+        switch (p.fmt) {
+        case 'i': (*out)[i] = ((const int32_t *)p.a->buffers[1])[o + i]; break;
+        case 'l': (*out)[i] = ((const int64_t *)p.a->buffers[1])[o + i]; break;
+        case 'I': (*out)[i] = ((const uint32_t *)p.a->buffers[1])[o + i]; break;
+        default: {
+            const uint64_t v = ((const uint64_t *)p.a->buffers[1])[o + i];
+            if (v > (uint64_t)INT64_MAX) {
+                std::snprintf(buf, sizeof buf, "coordinate value %llu at row %lld overflows i64 (max 9223372036854775807)", (unsigned long long)v, (long long)i);
+                return fail(s, buf);
+            }
+            (*out)[i] = (int64_t)v;
+        }
+        }
+    }
+    return 0;
+}
+
+// ---- key dictionary: ids in byte order of the (composite) key strings
+struct KeyDict {
+    std::vector<std::string> names;                 // id -> name
+    std::vector<std::vector<uint32_t>> ids;         // per table: row -> id
+};
+
+int build_keys(brh_session *s, const std::vector<std::pair<brh_batch, brh_columns>> &tables, KeyDict *kd)
+{
+    std::vector<std::vector<std::string>> composite(tables.size());
+    std::vector<std::vector<StrCol>> cols(tables.size());
+    for (size_t t = 0; t < tables.size(); t++) {
+        const brh_columns &c = tables[t].second;
+        if (c.n_keys < 1) return fail(s, "at least one key column is required");
+        cols[t].resize(c.n_keys);
+        for (int k = 0; k < c.n_keys; k++)
+            if (get_contig(s, tables[t].first, c.keys[k], &cols[t][k])) return 1;
+    }
+    std::unordered_map<std::string_view, uint32_t> seen;
+    std::vector<std::string_view> uniq;
+    auto key_of = [&](size_t t, int64_t i, std::string &scratch) -> std::string_view {
+        if (cols[t].size() == 1) return cols[t][0].at(i);
+        scratch.clear();
+        for (size_t k = 0; k < cols[t].size(); k++) { if (k) scratch.push_back('\x1f'); scratch.append(cols[t][k].at(i)); }
+        return scratch;
+    };
+    // pass 1: unique keys (composite keys are materialised once per table)
+    for (size_t t = 0; t < tables.size(); t++) {
+        const int64_t n = tables[t].first.array->length;
+        if (cols[t].size() > 1) {
+            composite[t].resize((size_t)n);
+            std::string scratch;
+            for (int64_t i = 0; i < n; i++) composite[t][i] = std::string(key_of(t, i, scratch));
+        }
+        for (int64_t i = 0; i < n; i++) {
+            std::string_view k = cols[t].size() > 1 ? std::string_view(composite[t][i]) : cols[t][0].at(i);
+            if (seen.emplace(k, 0).second) uniq.push_back(k);
+        }
+    }
+    std::sort(uniq.begin(), uniq.end());             // byte-lexicographic, as String::cmp (grouped_stream.rs:111)
+    for (uint32_t i = 0; i < uniq.size(); i++) seen[uniq[i]] = i;
+    kd->names.assign(uniq.begin(), uniq.end());
+    kd->ids.resize(tables.size());
+    for (size_t t = 0; t < tables.size(); t++) {
+        const int64_t n = tables[t].first.array->length;
+        kd->ids[t].resize((size_t)n);
+        for (int64_t i = 0; i < n; i++) {
+            std::string_view k = cols[t].size() > 1 ? std::string_view(composite[t][i]) : cols[t][0].at(i);
+            kd->ids[t][i] = seen[k];
+        }
+    }
+    return 0;
+}
+
+// ---- Arrow output helpers
+struct OutPriv { std::vector<void *> bufs; const void *ptrs[3]; char *fmt; };
+
+void release_array(ArrowArray *a)
+{
+    if (!a || !a->release) return;
+    OutPriv *p = (OutPriv *)a->private_data;
+    for (void *b : p->bufs) std::free(b);
+    delete p;
+    a->release = nullptr;
+}
+void release_schema(ArrowSchema *sc)
+{
+    if (!sc || !sc->release) return;
+    std::free((void *)sc->format); std::free((void *)sc->name);
+    sc->release = nullptr;
+}
+
+void make_schema(ArrowSchema *sc, const char *fmt, const char *name, bool nullable)
+{
+    std::memset(sc, 0, sizeof *sc);
+    sc->format = strdup(fmt); sc->name = strdup(name); sc->flags = nullable ? 2 : 0;   // ARROW_FLAG_NULLABLE
+    sc->release = release_schema;
+}
+
+// fixed-width column; validity (may be null) is one byte per row, converted to a bitmap
+template <typename T>
+void make_primitive(ArrowArray *a, const T *data, int64_t n, const uint8_t *valid)
+{
+    std::memset(a, 0, sizeof *a);
+    OutPriv *p = new OutPriv();
+    T *d = (T *)std::malloc((size_t)(n ? n : 1) * sizeof(T));
+    if (n) std::memcpy(d, data, (size_t)n * sizeof(T));
+    p->bufs.push_back(d);
+    uint8_t *bm = nullptr; int64_t nulls = 0;
+    if (valid) {
+        bm = (uint8_t *)std::calloc((size_t)(n + 7) / 8 + 1, 1);
+        for (int64_t i = 0; i < n; i++) { if (valid[i]) bm[i >> 3] |= (uint8_t)(1u << (i & 7)); else nulls++; }
+        p->bufs.push_back(bm);
+    }
+    p->ptrs[0] = nulls ? bm : nullptr; p->ptrs[1] = d;
+    a->length = n; a->null_count = nulls; a->n_buffers = 2; a->buffers = p->ptrs; a->private_data = p; a->release = release_array;
+}
+
+void make_utf8(ArrowArray *a, const std::vector<std::string> &names, const uint32_t *ids, int64_t n)
+{
+    std::memset(a, 0, sizeof *a);
+    OutPriv *p = new OutPriv();
+    int32_t *off = (int32_t *)std::malloc((size_t)(n + 1) * sizeof(int32_t));
+    size_t total = 0;
+    for (int64_t i = 0; i < n; i++) { off[i] = (int32_t)total; total += names[ids[i]].size(); }
+    off[n] = (int32_t)total;
+    char *data = (char *)std::malloc(total ? total : 1);
+    for (int64_t i = 0; i < n; i++) std::memcpy(data + off[i], names[ids[i]].data(), names[ids[i]].size());
+    p->bufs.push_back(off); p->bufs.push_back(data);
+    p->ptrs[0] = nullptr; p->ptrs[1] = off; p->ptrs[2] = data;
+    a->length = n; a->n_buffers = 3; a->buffers = p->ptrs; a->private_data = p; a->release = release_array;
+}
+
+struct Side32 { std::vector<int32_t> s, e; };
+int load_side32(brh_session *s, brh_batch t, const brh_columns &c, Side32 *o)
+{
+    PosCol ps, pe;
+    if (get_pos(s, t, c.start, "start", &ps) || get_pos(s, t, c.end, "end", &pe)) return 1;
+    return resolve_i32(s, ps, &o->s) || resolve_i32(s, pe, &o->e);
+}
+struct Side64 { std::vector<int64_t> s, e; };
+int load_side64(brh_session *s, brh_batch t, const brh_columns &c, Side64 *o)
+{
+    PosCol ps, pe;
+    if (get_pos(s, t, c.start, "start", &ps) || get_pos(s, t, c.end, "end", &pe)) return 1;
+    return resolve_i64(s, ps, &o->s) || resolve_i64(s, pe, &o->e);
+}
+
+struct IndexGuard { ivx_index *ix = nullptr; ~IndexGuard() { if (ix) ivx_index_free(ix); } };
+
+}  // namespace
+
+extern "C" int brh_session_create(int device_ordinal, brh_session **out)
+{
+    if (!out) return 1;
+    brh_session *s = new brh_session();
+    ivx_status st = ivx_ctx_create(device_ordinal, &s->ctx);
+    if (st != IVX_OK) { delete s; *out = nullptr; return (int)st; }   // no CPU fallback
+    *out = s;
+    return 0;
+}
+extern "C" void brh_session_free(brh_session *s) { if (s) { ivx_ctx_free(s->ctx); delete s; } }
+extern "C" const char *brh_last_error(const brh_session *s) { return s ? s->err.c_str() : "null session"; }
+
+extern "C" int brh_check_position_column(brh_session *s, brh_batch table, const char *column, int as_i64, char *errbuf, int errbuf_len)
+{
+    brh_session tmp;
+    brh_session *u = s ? s : &tmp;
+    PosCol p;
+    int rc = get_pos(u, table, column, "start", &p);
+    if (!rc) {
+        if (as_i64) { std::vector<int64_t> v; rc = resolve_i64(u, p, &v); }
+        else { std::vector<int32_t> v; rc = resolve_i32(u, p, &v); }
+    }
+    if (rc && errbuf && errbuf_len > 0) std::snprintf(errbuf, (size_t)errbuf_len, "%s", u->err.c_str());
+    return rc;
+}
+
+extern "C" int brh_count_overlaps(brh_session *s, brh_batch left, brh_columns lcols, brh_batch right, brh_columns rcols,
+                                  int filter_op, int coverage, ArrowArray *out, ArrowSchema *out_schema)
+{
+    if (!s) return 1;
+    KeyDict kd; Side32 L, R;
+    if (build_keys(s, {{left, lcols}, {right, rcols}}, &kd) || load_side32(s, left, lcols, &L) || load_side32(s, right, rcols, &R)) return 1;
+    const uint32_t nk = (uint32_t)std::max<size_t>(kd.names.size(), 1);
+    IndexGuard g;
+    ivx_status st = ivx_index_build(s->ctx, coverage ? IVX_KIND_COVERAGE : IVX_KIND_COUNT, IVX_MEM_HOST, kd.ids[0].data(),
+                                    L.s.data(), L.e.data(), L.s.size(), nk, &g.ix);
+    if (st != IVX_OK) return fail_ivx(s, st);
+    std::vector<int64_t> col(R.s.size());
+    st = (coverage ? ivx_probe_coverage : ivx_probe_count)(s->ctx, g.ix, IVX_MEM_HOST, kd.ids[1].data(), R.s.data(), R.e.data(),
+                                                           R.s.size(), filter_op == BRH_STRICT, col.data());
+    if (st != IVX_OK) return fail_ivx(s, st);
+    make_primitive<int64_t>(out, col.data(), (int64_t)col.size(), nullptr);
+    make_schema(out_schema, "l", coverage ? "coverage" : "count", false);      // count_overlaps.rs:60-66
+    return 0;
+}
+
+extern "C" int brh_nearest(brh_session *s, brh_batch left, brh_columns lcols, brh_batch right, brh_columns rcols,
+                           int filter_op, uint32_t k, int include_overlaps, int compute_distance,
+                           ArrowArray *left_idx, ArrowSchema *left_idx_schema, ArrowArray *right_idx, ArrowSchema *right_idx_schema,
+                           ArrowArray *distance, ArrowSchema *distance_schema)
+{
+    if (!s) return 1;
+    KeyDict kd; Side32 L, R;
+    if (build_keys(s, {{left, lcols}, {right, rcols}}, &kd) || load_side32(s, left, lcols, &L) || load_side32(s, right, rcols, &R)) return 1;
+    const uint32_t nk = (uint32_t)std::max<size_t>(kd.names.size(), 1);
+    IndexGuard g;
+    ivx_status st = ivx_index_build(s->ctx, IVX_KIND_NEAREST, IVX_MEM_HOST, kd.ids[0].data(), L.s.data(), L.e.data(), L.s.size(), nk, &g.ix);
+    if (st != IVX_OK) return fail_ivx(s, st);
+    const uint64_t cap = R.s.size() * (uint64_t)std::max<uint32_t>(k, 1);
+    std::vector<uint32_t> bi(cap ? cap : 1), pi(cap ? cap : 1);
+    std::vector<int64_t> di(compute_distance ? (cap ? cap : 1) : 0);
+    uint64_t rows = 0;
+    st = ivx_probe_nearest(s->ctx, g.ix, IVX_MEM_HOST, kd.ids[1].data(), R.s.data(), R.e.data(), R.s.size(), filter_op == BRH_STRICT, k,
+                           include_overlaps, bi.data(), pi.data(), compute_distance ? di.data() : nullptr, cap, &rows);
+    if (st != IVX_OK) return fail_ivx(s, st);
+    std::vector<uint8_t> valid(rows ? rows : 1);
+    for (uint64_t i = 0; i < rows; i++) { valid[i] = bi[i] != IVX_NULL_IDX; if (!valid[i]) bi[i] = 0; }   // nearest.rs:378-379
+    make_primitive<uint32_t>(left_idx, bi.data(), (int64_t)rows, valid.data());
+    make_schema(left_idx_schema, "I", "left_idx", true);
+    make_primitive<uint32_t>(right_idx, pi.data(), (int64_t)rows, nullptr);
+    make_schema(right_idx_schema, "I", "right_idx", false);
+    if (compute_distance && distance) {
+        make_primitive<int64_t>(distance, di.data(), (int64_t)rows, valid.data());
+        make_schema(distance_schema, "l", "distance", true);
+    }
+    return 0;
+}
+
+extern "C" int brh_interval_join(brh_session *s, brh_batch build, brh_columns bcols, brh_batch probe, brh_columns pcols,
+                                 int join_type, int strict_predicate, int nearest_algorithm,
+                                 ArrowArray *build_idx, ArrowSchema *build_idx_schema, ArrowArray *probe_idx, ArrowSchema *probe_idx_schema)
+{
+    if (!s) return 1;
+    KeyDict kd; Side32 B, P;
+    if (build_keys(s, {{build, bcols}, {probe, pcols}}, &kd) || load_side32(s, build, bcols, &B) || load_side32(s, probe, pcols, &P)) return 1;
+    if (strict_predicate) {                                       // `a.start < b.end AND a.end > b.start`: end - 1 on both sides
+        for (auto &v : B.e) v = (int32_t)((uint32_t)v - 1u);
+        for (auto &v : P.e) v = (int32_t)((uint32_t)v - 1u);
+    }
+    const uint32_t nk = (uint32_t)std::max<size_t>(kd.names.size(), 1);
+    IndexGuard g;
+    ivx_status st = ivx_index_build(s->ctx, nearest_algorithm ? IVX_KIND_NEAREST : IVX_KIND_OVERLAP, IVX_MEM_HOST, kd.ids[0].data(),
+                                    B.s.data(), B.e.data(), B.s.size(), nk, &g.ix);
+    if (st != IVX_OK) return fail_ivx(s, st);
+    const uint64_t np = P.s.size();
+    if (nearest_algorithm) {                                      // interval_join.rs:864-870, :1628-1635
+        std::vector<uint32_t> bi(np ? np : 1), pi(np ? np : 1);
+        uint64_t rows = 0;
+        st = ivx_probe_nearest(s->ctx, g.ix, IVX_MEM_HOST, kd.ids[1].data(), P.s.data(), P.e.data(), np, 0, 1, 1, bi.data(), pi.data(), nullptr, np, &rows);
+        if (st != IVX_OK) return fail_ivx(s, st);
+        std::vector<uint8_t> valid(rows ? rows : 1);
+        for (uint64_t i = 0; i < rows; i++) { valid[i] = bi[i] != IVX_NULL_IDX; if (!valid[i]) bi[i] = 0; }
+        make_primitive<uint32_t>(build_idx, bi.data(), (int64_t)rows, valid.data()); make_schema(build_idx_schema, "I", "build_idx", true);
+        make_primitive<uint32_t>(probe_idx, pi.data(), (int64_t)rows, nullptr); make_schema(probe_idx_schema, "I", "probe_idx", false);
+        return 0;
+    }
+    if (join_type == BRH_JOIN_RIGHT_SEMI || join_type == BRH_JOIN_RIGHT_ANTI) {      // :1014-1024, :1433-1447
+        std::vector<uint8_t> ex(np ? np : 1);
+        st = ivx_probe_exists(s->ctx, g.ix, IVX_MEM_HOST, kd.ids[1].data(), P.s.data(), P.e.data(), np, ex.data());
+        if (st != IVX_OK) return fail_ivx(s, st);
+        std::vector<uint32_t> pi;
+        const bool want = join_type == BRH_JOIN_RIGHT_SEMI;
+        for (uint64_t i = 0; i < np; i++) if ((ex[i] != 0) == want) pi.push_back((uint32_t)i);
+        make_primitive<uint32_t>(build_idx, nullptr, 0, nullptr); make_schema(build_idx_schema, "I", "build_idx", false);
+        make_primitive<uint32_t>(probe_idx, pi.data(), (int64_t)pi.size(), nullptr); make_schema(probe_idx_schema, "I", "probe_idx", false);
+        return 0;
+    }
+    uint64_t total = 0;
+    st = ivx_probe_overlap_count(s->ctx, g.ix, IVX_MEM_HOST, kd.ids[1].data(), P.s.data(), P.e.data(), np, nullptr, &total);
+    if (st != IVX_OK) return fail_ivx(s, st);
+    std::vector<uint32_t> bi(total ? total : 1), pi(total ? total : 1);
+    uint64_t written = 0;
+    st = ivx_probe_overlap_fill(s->ctx, g.ix, IVX_MEM_HOST, kd.ids[1].data(), P.s.data(), P.e.data(), np, bi.data(), pi.data(), total, &written);
+    if (st != IVX_OK) return fail_ivx(s, st);
+    make_primitive<uint32_t>(build_idx, bi.data(), (int64_t)written, nullptr); make_schema(build_idx_schema, "I", "build_idx", false);
+    make_primitive<uint32_t>(probe_idx, pi.data(), (int64_t)written, nullptr); make_schema(probe_idx_schema, "I", "probe_idx", false);
+    return 0;
+}
+
+extern "C" int brh_merge(brh_session *s, brh_batch table, brh_columns cols, int64_t min_dist, int filter_op,
+                         ArrowArray *contig, ArrowSchema *contig_schema, ArrowArray *start, ArrowSchema *start_schema,
+                         ArrowArray *end, ArrowSchema *end_schema, ArrowArray *n_intervals, ArrowSchema *n_schema)
+{
+    if (!s) return 1;
+    KeyDict kd; Side64 T;
+    if (build_keys(s, {{table, cols}}, &kd) || load_side64(s, table, cols, &T)) return 1;
+    const uint64_t n = T.s.size();
+    std::vector<uint32_t> ok(n ? n : 1); std::vector<int64_t> os(n ? n : 1), oe(n ? n : 1), on(n ? n : 1);
+    uint64_t m = 0;
+    ivx_status st = ivx_merge(s->ctx, IVX_MEM_HOST, kd.ids[0].data(), T.s.data(), T.e.data(), n, (uint32_t)std::max<size_t>(kd.names.size(), 1),
+                              min_dist, filter_op == BRH_STRICT, ok.data(), os.data(), oe.data(), on.data(), n, &m);
+    if (st != IVX_OK) return fail_ivx(s, st);
+    make_utf8(contig, kd.names, ok.data(), (int64_t)m); make_schema(contig_schema, "u", cols.keys[0], false);
+    make_primitive<int64_t>(start, os.data(), (int64_t)m, nullptr); make_schema(start_schema, "l", cols.start, false);   // merge.rs:43-48
+    make_primitive<int64_t>(end, oe.data(), (int64_t)m, nullptr); make_schema(end_schema, "l", cols.end, false);
+    make_primitive<int64_t>(n_intervals, on.data(), (int64_t)m, nullptr); make_schema(n_schema, "l", "n_intervals", false);
+    return 0;
+}
+
+extern "C" int brh_subtract(brh_session *s, brh_batch left, brh_columns lcols, brh_batch right, brh_columns rcols, int filter_op,
+                            ArrowArray *contig, ArrowSchema *contig_schema, ArrowArray *start, ArrowSchema *start_schema,
+                            ArrowArray *end, ArrowSchema *end_schema, ArrowArray *left_row, ArrowSchema *left_row_schema)
+{
+    if (!s) return 1;
+    KeyDict kd; Side64 L, R;
+    if (build_keys(s, {{left, lcols}, {right, rcols}}, &kd) || load_side64(s, left, lcols, &L) || load_side64(s, right, rcols, &R)) return 1;
+    const uint32_t nk = (uint32_t)std::max<size_t>(kd.names.size(), 1);
+    uint64_t m = 0;
+    ivx_status st = ivx_subtract(s->ctx, IVX_MEM_HOST, kd.ids[0].data(), L.s.data(), L.e.data(), L.s.size(), kd.ids[1].data(), R.s.data(), R.e.data(),
+                                 R.s.size(), nk, filter_op == BRH_STRICT, nullptr, nullptr, nullptr, nullptr, 0, &m);
+    if (st != IVX_OK) return fail_ivx(s, st);
+    std::vector<uint32_t> ok(m ? m : 1), orow(m ? m : 1); std::vector<int64_t> os(m ? m : 1), oe(m ? m : 1);
+    uint64_t m2 = 0;
+    st = ivx_subtract(s->ctx, IVX_MEM_HOST, kd.ids[0].data(), L.s.data(), L.e.data(), L.s.size(), kd.ids[1].data(), R.s.data(), R.e.data(),
+                      R.s.size(), nk, filter_op == BRH_STRICT, ok.data(), os.data(), oe.data(), orow.data(), m, &m2);
+    if (st != IVX_OK) return fail_ivx(s, st);
+    make_utf8(contig, kd.names, ok.data(), (int64_t)m2); make_schema(contig_schema, "u", lcols.keys[0], false);
+    make_primitive<int64_t>(start, os.data(), (int64_t)m2, nullptr); make_schema(start_schema, "l", lcols.start, false);   // subtract.rs:57-72
+    make_primitive<int64_t>(end, oe.data(), (int64_t)m2, nullptr); make_schema(end_schema, "l", lcols.end, false);
+    make_primitive<uint32_t>(left_row, orow.data(), (int64_t)m2, nullptr); make_schema(left_row_schema, "I", "left_row", false);
+    return 0;
+}

@@ -1,0 +1,113 @@
+/*
+ * bio_ranges_host.h -- host-side mirror of the reference's operator interface over the
+ * Arrow C Data Interface (libbio_ranges_hip.so, plain C++; no Arrow library needed).
+ *
+ * The reference's operators take Arrow RecordBatches and column-name triples
+ * (contig, start, end); this layer does what their host code does before and after
+ * the hot loop, then calls the HIP kernels through include/ivx.h:
+ *   - contig column access: Utf8 / LargeUtf8 / Utf8View   (R/src/array_utils.rs:10-24, :196-229)
+ *   - position columns: Int32 / Int64 / UInt32 / UInt64, null check and checked
+ *     narrowing with the reference's error text            (array_utils.rs:33-172, :231-295)
+ *   - key dictionary: contig (or several key columns) -> dense uint32 ids, assigned in
+ *     byte order of the names so merge/subtract emit groups like
+ *     StreamCollector::take_groups                          (R/src/grouped_stream.rs:105-113)
+ *   - output columns as Arrow arrays (count/coverage Int64; UInt32 index arrays with
+ *     validity for nearest; Utf8 + Int64 columns for merge/subtract).
+ * Gathering payload columns with the returned index arrays (`compute::take`) stays with
+ * the caller, exactly as in the reference (interval_join.rs:1655-1667, nearest.rs:469-482).
+ *
+ * Every function returns 0 on success; brh_last_error() gives the message
+ * (DataFusionError::Execution text).  Input batches are borrowed, outputs are
+ * released by the caller through the usual ArrowArray.release callback.
+ */
+#ifndef BIO_RANGES_HOST_H
+#define BIO_RANGES_HOST_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef ARROW_C_DATA_INTERFACE
+#define ARROW_C_DATA_INTERFACE
+struct ArrowSchema {
+    const char *format; const char *name; const char *metadata; int64_t flags; int64_t n_children;
+    struct ArrowSchema **children; struct ArrowSchema *dictionary;
+    void (*release)(struct ArrowSchema *); void *private_data;
+};
+struct ArrowArray {
+    int64_t length; int64_t null_count; int64_t offset; int64_t n_buffers; int64_t n_children;
+    const void **buffers; struct ArrowArray **children; struct ArrowArray *dictionary;
+    void (*release)(struct ArrowArray *); void *private_data;
+};
+#endif
+
+typedef struct brh_session brh_session;
+
+/* one table = one struct-typed ArrowArray + its ArrowSchema (RecordBatch export) */
+typedef struct { const struct ArrowArray *array; const struct ArrowSchema *schema; } brh_batch;
+
+/* column names: keys[0..n_keys) are the equi-key columns (the contig; more for multi-column
+ * joins such as contig+strand, R/tests/integration_test.rs:393-397), then start and end */
+typedef struct { const char *const *keys; int n_keys; const char *start; const char *end; } brh_columns;
+
+int  brh_session_create(int device_ordinal, brh_session **out);      /* fails without a gfx950 device */
+void brh_session_free(brh_session *s);
+const char *brh_last_error(const brh_session *s);
+
+/* FilterOp (R/src/filter_op.rs:4-10) */
+enum { BRH_WEAK = 0, BRH_STRICT = 1 };
+/* JoinType subset with real semantics in IntervalJoinExec (interval_join.rs:1014-1024) */
+enum { BRH_JOIN_INNER = 0, BRH_JOIN_RIGHT_SEMI = 1, BRH_JOIN_RIGHT_ANTI = 2 };
+
+/* count_overlaps('left','right') / coverage(...): CountOverlapsProvider (R/src/count_overlaps.rs:107-169),
+ * get_count_stream / get_stream (interval_tree.rs:155-280).  `left` is indexed, `right` streamed;
+ * out = the Int64 column ("count"/"coverage") to append to `right`. */
+int brh_count_overlaps(brh_session *s, brh_batch left, brh_columns lcols, brh_batch right, brh_columns rcols,
+                       int filter_op, int coverage, struct ArrowArray *out, struct ArrowSchema *out_schema);
+
+/* nearest('left','right',k,overlap,compute_distance): NearestProvider / get_nearest_stream
+ * (R/src/nearest.rs:127-166, :266-496).  Outputs: left_idx UInt32 (nullable), right_idx UInt32,
+ * distance Int64 (nullable; NULL pointers when compute_distance == 0). */
+int brh_nearest(brh_session *s, brh_batch left, brh_columns lcols, brh_batch right, brh_columns rcols,
+                int filter_op, uint32_t k, int include_overlaps, int compute_distance,
+                struct ArrowArray *left_idx, struct ArrowSchema *left_idx_schema,
+                struct ArrowArray *right_idx, struct ArrowSchema *right_idx_schema,
+                struct ArrowArray *distance, struct ArrowSchema *distance_schema);
+
+/* IntervalJoinExec (interval_join.rs:442-550, :1418-1677): `build` is the SQL join's left side.
+ * strict_predicate = the planner's `<`/`>` rewrite: both sides' END minus one (intervals.rs:85-115).
+ * nearest_algorithm != 0 = Algorithm::CoitreesNearest (one row per probe row, NULL build index when
+ * nothing is found).  Inner: (build_idx, probe_idx); RightSemi/RightAnti: probe_idx only
+ * (build_idx output left released/empty). */
+int brh_interval_join(brh_session *s, brh_batch build, brh_columns bcols, brh_batch probe, brh_columns pcols,
+                      int join_type, int strict_predicate, int nearest_algorithm,
+                      struct ArrowArray *build_idx, struct ArrowSchema *build_idx_schema,
+                      struct ArrowArray *probe_idx, struct ArrowSchema *probe_idx_schema);
+
+/* merge('table'[,min_dist]...): MergeProvider/MergeStream (R/src/merge.rs:84-112, :263-350).
+ * Outputs contig Utf8, start Int64, end Int64, n_intervals Int64. */
+int brh_merge(brh_session *s, brh_batch table, brh_columns cols, int64_t min_dist, int filter_op,
+              struct ArrowArray *contig, struct ArrowSchema *contig_schema,
+              struct ArrowArray *start, struct ArrowSchema *start_schema,
+              struct ArrowArray *end, struct ArrowSchema *end_schema,
+              struct ArrowArray *n_intervals, struct ArrowSchema *n_schema);
+
+/* subtract('left','right'): SubtractStream / SubtractStreamExtra (R/src/subtract.rs:354-462, :529-662).
+ * Outputs contig Utf8, start Int64, end Int64 and left_row UInt32 (the row of `left` each fragment
+ * came from, for the extra-columns take). */
+int brh_subtract(brh_session *s, brh_batch left, brh_columns lcols, brh_batch right, brh_columns rcols,
+                 int filter_op,
+                 struct ArrowArray *contig, struct ArrowSchema *contig_schema,
+                 struct ArrowArray *start, struct ArrowSchema *start_schema,
+                 struct ArrowArray *end, struct ArrowSchema *end_schema,
+                 struct ArrowArray *left_row, struct ArrowSchema *left_row_schema);
+
+/* the checks alone (no GPU): resolve a position column like PosArray::resolve / resolve_i64 would;
+ * 0 = fine, else the error text is set.  Used by the CPU-only tests. */
+int brh_check_position_column(brh_session *s_or_null, brh_batch table, const char *column, int as_i64,
+                              char *errbuf, int errbuf_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
