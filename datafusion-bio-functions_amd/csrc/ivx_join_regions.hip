@@ -206,7 +206,8 @@ constexpr u32 RP_HALO = 8;                 // slice cells past the region's last
 constexpr u32 RP_CCAP = 8192 + RP_HALO + 2;
 constexpr u32 RP_ECAP = 7424;              // entries staged per slice
 constexpr u32 RP_QW = 384;                 // pairs a wavefront stages in LDS before one coalesced write
-constexpr u32 RP_GRID = 256;
+constexpr u32 RP_GRID = 256;                // fill pass: one workgroup per CU (LDS-bound)
+constexpr u32 RP_VGRID = 512;               // row shares ("virtual workgroups"); the count pass runs two per CU
 
 struct Slice {
     const JoinIndexView *ix;
@@ -280,7 +281,7 @@ __device__ __forceinline__ void probe_row(const Slice &S, i32 qs, i32 qe, F &&f)
 // private output cursor and writes its pairs there: no atomics and no barriers in the hot loop.
 template <bool FILL>
 __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const u64 *__restrict__ pse, const u32 *__restrict__ prow,
-                                                        const u32 *__restrict__ offs, u32 nblk,
+                                                        const u32 *__restrict__ offs, u32 nblk, u32 vpb,
                                                         u64 *__restrict__ wave_tot,
                                                         u32 *__restrict__ ob, u32 *__restrict__ op, u64 cap, int dbg)
 {
@@ -293,10 +294,13 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
     const u32 tid = threadIdx.x, wv = tid / IVX_WAVE, ln = lane_id();
     const u32 nreg = ix.hdr[HDR_NREG];
     const u64 total_rows = offs[(u64)nreg * nblk];
-    u64 lo = total_rows * blockIdx.x / gridDim.x;
-    const u64 hi = total_rows * (blockIdx.x + 1) / gridDim.x;
-    u64 wcur = FILL ? wave_tot[(u64)blockIdx.x * RP_W + wv] : 0;     // FILL: output cursor, else pair count
-    const u64 wend = FILL ? wave_tot[(u64)blockIdx.x * RP_W + wv + 1] : 0;
+    const u32 nvb = gridDim.x * vpb;
+    u32 loaded_r = 0xFFFFFFFFu;                                       // region whose slice currently sits in LDS
+    for (u32 vb = blockIdx.x * vpb; vb < (blockIdx.x + 1) * vpb; vb++) {
+    u64 lo = total_rows * vb / nvb;
+    const u64 hi = total_rows * (vb + 1) / nvb;
+    u64 wcur = FILL ? wave_tot[(u64)vb * RP_W + wv] : 0;              // FILL: output cursor, else pair count
+    const u64 wend = FILL ? wave_tot[(u64)vb * RP_W + wv + 1] : 0;
     const bool fits = !FILL || wend <= cap;                           // capacity error: write nothing
     if (lo < hi) {
         u32 r;
@@ -317,7 +321,9 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
             const u64 rend = offs[(u64)(r + 1) * nblk];
             const u64 c_hi = hi < rend ? hi : rend;
             if (c_hi <= lo) continue;
-            // ---- stage the region's slice of the index in LDS
+            // ---- stage the region's slice of the index in LDS (unless the previous share left it there)
+            const bool reload = r != loaded_r;
+            loaded_r = r;
             __syncthreads();
             S.k = ix.rkey[r];
             S.origin = ix.origin[S.k]; S.span = ix.span[S.k];
@@ -333,7 +339,7 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
             const u32 ne = ix.binstart[S.lb + S.shi] - S.e0;
             const u32 nc = S.shi - S.slo + 1u;
             S.inlds = ne <= RP_ECAP && nc <= RP_CCAP;
-            if (S.inlds) {
+            if (S.inlds && reload) {
                 for (u32 c0 = 0; c0 < nc; c0 += RP_T * 4) {
                     u32 v[4];
 #pragma unroll
@@ -436,7 +442,8 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
     }
     if (!FILL) {
         const u64 tot = wave_sum(wcur);
-        if (ln == 0) wave_tot[(u64)blockIdx.x * RP_W + wv] = tot;
+        if (ln == 0) wave_tot[(u64)vb * RP_W + wv] = tot;
+    }
     }
 }
 
@@ -466,15 +473,15 @@ ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, int mod
     if (vec) hipLaunchKernelGGL(k_part_scatter<true>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, prow, dbg);
     else hipLaunchKernelGGL(k_part_scatter<false>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, prow, dbg);
     // pass 1: pairs per (workgroup, wavefront); exclusive scan = every wavefront's private output range
-    const u32 nwaves = RP_GRID * RP_W;
+    const u32 nwaves = RP_VGRID * RP_W;
     u64 *wave_tot;
     IVX_TRY(ctx->get_scratch(WS_T2, ((size_t)nwaves + 1) * sizeof(u64), (void **)&wave_tot));
     IVX_HIP(ctx, hipMemsetAsync(wave_tot + nwaves, 0, sizeof(u64), st));
-    hipLaunchKernelGGL(k_probe_regions<false>, dim3(RP_GRID), dim3(RP_T), 0, st, jv, (const u64 *)pse, (const u32 *)prow, (const u32 *)hist, nblk, wave_tot, ob, op, cap, dbg);
+    hipLaunchKernelGGL(k_probe_regions<false>, dim3(RP_VGRID), dim3(RP_T), 0, st, jv, (const u64 *)pse, (const u32 *)prow, (const u32 *)hist, nblk, 1u, wave_tot, ob, op, cap, dbg);
     IVX_TRY(ivx_scan_exclusive_u64(ctx, wave_tot, (u64)nwaves + 1));
     hipLaunchKernelGGL(k_publish_total, dim3(1), dim3(1), 0, st, (const u64 *)wave_tot, nwaves, (unsigned long long *)d_cursor);
     if (mode == JP_FILL)   // pass 2: same walk, pairs written at their final offsets
-        hipLaunchKernelGGL(k_probe_regions<true>, dim3(RP_GRID), dim3(RP_T), 0, st, jv, (const u64 *)pse, (const u32 *)prow, (const u32 *)hist, nblk, wave_tot, ob, op, cap, dbg);
+        hipLaunchKernelGGL(k_probe_regions<true>, dim3(RP_GRID), dim3(RP_T), 0, st, jv, (const u64 *)pse, (const u32 *)prow, (const u32 *)hist, nblk, RP_VGRID / RP_GRID, wave_tot, ob, op, cap, dbg);
     IVX_HIP(ctx, hipGetLastError());
     return IVX_OK;
 }
