@@ -8,18 +8,18 @@
 // index -- cell offsets and (start,end) of its entries -- in LDS and stream the
 // region's probe rows through it with coalesced reads:
 //
-//   k_part_hist     region histogram per workgroup (wave ballot match + LDS counters)
+//   k_part_hist     region histogram per workgroup (LDS counters, 16-byte row loads)
 //   scan            exclusive prefix over [region][workgroup]
 //   k_part_scatter  (qs,qe,row) records re-ordered through LDS, contiguous runs out
-//   k_probe_regions LDS-resident slice, two-phase (count, workgroup scan, write)
-//                   compaction: pairs go to an LDS queue that is flushed with ONE
-//                   global atomicAdd per ~1500 pairs; no LDS or global atomics
-//                   per pair.  Rows longer than the slice halo, regions whose
-//                   slice exceeds LDS and the long-interval levels fall back to
-//                   global reads inside the same kernel.
+//   k_probe_regions LDS-resident slice; matches are compacted with a wavefront
+//                   prefix sum into per-wavefront LDS staging and written with ONE
+//                   global atomicAdd per workgroup and round (~3000 pairs); no
+//                   LDS or global atomics per pair.  Rows longer than the slice
+//                   halo, regions whose slice exceeds LDS and the long-interval
+//                   levels fall back to global reads inside the same kernel.
 //
 // HBM traffic per probe row: 8 B (hist) + 12 B + 12 B (scatter) + 12 B (probe) +
-// 8 B per pair, all streaming.
+// 8 B per pair, all streaming (measured: profiles/r1_d_regions_pipeline_pmc.txt).
 #include "ivx_join.hpp"
 #include <cstdlib>
 #include <cstdlib>
@@ -274,22 +274,28 @@ __device__ __forceinline__ void probe_row(const Slice &S, i32 qs, i32 qe, F &&f)
     }
 }
 
-// Persistent workgroups, one per CU: workgroup b takes rows [T*b/G, T*(b+1)/G) of the partitioned
-// probe rows, region segment by region segment; inside a segment wavefront w owns wave batches
-// w, w+16, ... and never synchronises with the others.  FILL = false counts the pairs of every
-// (workgroup, wavefront) into wave_tot; FILL = true reads the scanned totals as each wavefront's
-// private output cursor and writes its pairs there: no atomics and no barriers in the hot loop.
+// Persistent workgroups: the partitioned probe rows are cut into equal row shares ("virtual
+// workgroups"), a workgroup walks its share region segment by region segment, and inside a segment
+// wavefront w owns batches w, w+16, ... of RP_WB rows.
+//   FILL = false (ivx_probe_overlap_count): wavefronts never synchronise; one atomicAdd of the
+//           wavefront's total at the end.
+//   FILL = true : single walk.  Each lane keeps its first three matches as 16-bit slice slots, a
+//           wavefront prefix sum (__shfl_up) turns the lanes' counts into slots of the wavefront's LDS
+//           staging buffer, and once per round ONE atomicAdd per workgroup reserves the output range
+//           of all 16 wavefronts; the staged pairs are then copied out with full-width stores.
 template <bool FILL>
 __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const u64 *__restrict__ pse, const u32 *__restrict__ prow,
                                                         const u32 *__restrict__ offs, u32 nblk, u32 vpb,
-                                                        u64 *__restrict__ wave_tot,
-                                                        u32 *__restrict__ ob, u32 *__restrict__ op, u64 cap, int dbg)
+                                                        u32 *__restrict__ ob, u32 *__restrict__ op, u64 cap,
+                                                        unsigned long long *cursor, int dbg)
 {
     __shared__ unsigned short s_off[RP_CCAP];
     __shared__ u64 s_ent[RP_ECAP];
     __shared__ u32 s_row[RP_ECAP];
     __shared__ u32 s_qb[FILL ? RP_W : 1][FILL ? RP_QW : 1];     // per-wavefront pair staging
     __shared__ u32 s_qp[FILL ? RP_W : 1][FILL ? RP_QW : 1];
+    __shared__ u32 s_wcnt[2][RP_W];                               // pairs staged by each wavefront, double-buffered by round
+    __shared__ unsigned long long s_base;
 
     const u32 tid = threadIdx.x, wv = tid / IVX_WAVE, ln = lane_id();
     const u32 nreg = ix.hdr[HDR_NREG];
@@ -299,9 +305,8 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
     for (u32 vb = blockIdx.x * vpb; vb < (blockIdx.x + 1) * vpb; vb++) {
     u64 lo = total_rows * vb / nvb;
     const u64 hi = total_rows * (vb + 1) / nvb;
-    u64 wcur = FILL ? wave_tot[(u64)vb * RP_W + wv] : 0;              // FILL: output cursor, else pair count
-    const u64 wend = FILL ? wave_tot[(u64)vb * RP_W + wv + 1] : 0;
-    const bool fits = !FILL || wend <= cap;                           // capacity error: write nothing
+    u64 wcur = 0;                                                     // count pass: pairs seen by this wavefront
+    u32 round = 0;
     if (lo < hi) {
         u32 r;
         {   // last region whose first row is <= lo
@@ -360,8 +365,10 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
             }
             __syncthreads();
 
-            // ---- wavefronts stream their batches independently; the next batch's rows are
-            //      in flight while the current one walks the LDS slice
+            // ---- every wavefront streams one batch of RP_WB rows per round; the next round's rows are in
+            //      flight while the current batch walks the LDS slice.  Count pass: no synchronisation at
+            //      all.  Fill pass: pairs are staged per wavefront in LDS, then ONE atomicAdd per workgroup
+            //      and round reserves the output range of all 16 wavefronts (about one atomic per 3000 pairs).
             u64 nx[RP_B]; u32 nxr[FILL ? RP_B : 1];
             u64 b0 = lo + (u64)wv * RP_WB;
 #pragma unroll
@@ -370,7 +377,7 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
                 nx[q] = i < c_hi ? pse[i] : 0;
                 if (FILL) nxr[q] = i < c_hi ? prow[i] : 0u;
             }
-            for (; b0 < c_hi; b0 += (u64)RP_W * RP_WB) {
+            for (u64 r0 = lo; r0 < c_hi; r0 += (u64)RP_W * RP_WB, b0 += (u64)RP_W * RP_WB, round++) {
                 i32 qs[RP_B], qe[RP_B]; u32 rowv[FILL ? RP_B : 1];
 #pragma unroll
                 for (int q = 0; q < RP_B; q++) { qs[q] = (i32)(u32)nx[q]; qe[q] = (i32)(u32)(nx[q] >> 32); if (FILL) rowv[q] = nxr[q]; }
@@ -407,15 +414,18 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
                     }
                 }
                 if (!FILL) { wcur += tsum; continue; }
-                // wavefront prefix sum over the lanes' pair counts -> each lane's slots in the wave's private range
+                // wavefront prefix sum over the lanes' pair counts
                 const u32 inc = wave_incl_scan(tsum);
                 const u32 wtot = __shfl(inc, IVX_WAVE - 1, IVX_WAVE);
-                if (fits && wtot) {
-                    const bool staged = wtot <= RP_QW;                   // stage in LDS, then one coalesced copy
+                const bool staged = wtot <= RP_QW;
+                u64 own = 0;                                              // rare: a batch too big for the staging buffer
+                if (!staged) { if (ln == 0) own = atomicAdd(cursor, (unsigned long long)wtot); own = __shfl(own, 0, IVX_WAVE); }
+                if (wtot) {
                     u32 at = inc - tsum;
+                    const bool direct_ok = !staged && own + wtot <= cap;
                     auto put = [&](u32 brow, u32 prow_id) {
                         if (staged) { s_qb[wv][at] = brow; s_qp[wv][at] = prow_id; }
-                        else { ob[wcur + at] = brow; op[wcur + at] = prow_id; }
+                        else if (direct_ok) { ob[own + at] = brow; op[own + at] = prow_id; }
                         at++;
                     };
 #pragma unroll
@@ -429,26 +439,35 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
                             probe_row(S, qs[q], qe[q], [&](u32 v, bool sl) { put(sl ? S.s_row[v] : v, rowv[q]); });
                         }
                     }
-                    if (staged) {
-                        __builtin_amdgcn_wave_barrier();
-                        if (!(dbg & 16)) for (u32 t = ln; t < wtot; t += IVX_WAVE) { ob[wcur + t] = s_qb[wv][t]; op[wcur + t] = s_qp[wv][t]; }
-                        __builtin_amdgcn_wave_barrier();
-                    }
                 }
-                wcur += wtot;
+                const u32 mine = staged ? wtot : 0u;
+                if (ln == 0) s_wcnt[round & 1][wv] = mine;
+                __syncthreads();
+                if (tid == 0) {
+                    u32 tot = 0;
+#pragma unroll
+                    for (int w = 0; w < RP_W; w++) tot += s_wcnt[round & 1][w];
+                    s_base = tot ? atomicAdd(cursor, (unsigned long long)tot) : 0ull;
+                }
+                __syncthreads();
+                if (mine) {
+                    u64 g = s_base;
+                    u32 tot = 0;
+#pragma unroll
+                    for (int w = 0; w < RP_W; w++) { const u32 c = s_wcnt[round & 1][w]; if (w < (int)wv) g += c; tot += c; }
+                    if (s_base + tot <= cap && !(dbg & 16))
+                        for (u32 t = ln; t < mine; t += IVX_WAVE) { ob[g + t] = s_qb[wv][t]; op[g + t] = s_qp[wv][t]; }
+                }
             }
             lo = c_hi;
         }
     }
     if (!FILL) {
         const u64 tot = wave_sum(wcur);
-        if (ln == 0) wave_tot[(u64)vb * RP_W + wv] = tot;
+        if (ln == 0 && tot) atomicAdd(cursor, (unsigned long long)tot);
     }
     }
 }
-
-// total pairs -> the caller's cursor word (read back by the host)
-__global__ void k_publish_total(const u64 *wave_tot, u32 nwaves, unsigned long long *cursor) { *cursor = wave_tot[nwaves]; }
 
 }  // namespace
 
@@ -472,16 +491,11 @@ ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, int mod
     IVX_TRY(ivx_scan_exclusive_u32(ctx, hist, nh));
     if (vec) hipLaunchKernelGGL(k_part_scatter<true>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, prow, dbg);
     else hipLaunchKernelGGL(k_part_scatter<false>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, prow, dbg);
-    // pass 1: pairs per (workgroup, wavefront); exclusive scan = every wavefront's private output range
-    const u32 nwaves = RP_VGRID * RP_W;
-    u64 *wave_tot;
-    IVX_TRY(ctx->get_scratch(WS_T2, ((size_t)nwaves + 1) * sizeof(u64), (void **)&wave_tot));
-    IVX_HIP(ctx, hipMemsetAsync(wave_tot + nwaves, 0, sizeof(u64), st));
-    hipLaunchKernelGGL(k_probe_regions<false>, dim3(RP_VGRID), dim3(RP_T), 0, st, jv, (const u64 *)pse, (const u32 *)prow, (const u32 *)hist, nblk, 1u, wave_tot, ob, op, cap, dbg);
-    IVX_TRY(ivx_scan_exclusive_u64(ctx, wave_tot, (u64)nwaves + 1));
-    hipLaunchKernelGGL(k_publish_total, dim3(1), dim3(1), 0, st, (const u64 *)wave_tot, nwaves, (unsigned long long *)d_cursor);
-    if (mode == JP_FILL)   // pass 2: same walk, pairs written at their final offsets
-        hipLaunchKernelGGL(k_probe_regions<true>, dim3(RP_GRID), dim3(RP_T), 0, st, jv, (const u64 *)pse, (const u32 *)prow, (const u32 *)hist, nblk, RP_VGRID / RP_GRID, wave_tot, ob, op, cap, dbg);
+    unsigned long long *cur = (unsigned long long *)d_cursor;
+    if (mode == JP_FILL)     // single walk: pairs staged per wavefront, one output reservation per workgroup and round
+        hipLaunchKernelGGL(k_probe_regions<true>, dim3(RP_GRID), dim3(RP_T), 0, st, jv, (const u64 *)pse, (const u32 *)prow, (const u32 *)hist, nblk, RP_VGRID / RP_GRID, ob, op, cap, cur, dbg);
+    else
+        hipLaunchKernelGGL(k_probe_regions<false>, dim3(RP_VGRID), dim3(RP_T), 0, st, jv, (const u64 *)pse, (const u32 *)prow, (const u32 *)hist, nblk, 1u, ob, op, cap, cur, dbg);
     IVX_HIP(ctx, hipGetLastError());
     return IVX_OK;
 }
