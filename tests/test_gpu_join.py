@@ -156,3 +156,43 @@ def test_device_pointers_match_host(ctx):
     got = (ob.cpu().numpy().view(np.uint32), op.cpu().numpy().view(np.uint32))
     assert (pair_set(*got) == pair_set(*want)).all()
     ctx.use_own_stream()
+
+
+def test_many_keys_all_operators(ctx):
+    # thousands of small contigs (scaffold-level assemblies): per-key tables no longer fit the LDS caches,
+    # the probe-region partition is unavailable (more keys than regions) and everything takes the general paths
+    nk = 5000
+    bk, bs, be = synth(120_000, 31, nkeys=nk, mean_len=400, span=200_000)
+    pk, ps, pe = synth(400_000, 32, nkeys=nk + 50, mean_len=150, span=200_000)
+    _check_join(ctx, bk, bs, be, pk, ps, pe, nk + 50)
+    ixc = ctx.build(pyivx.KIND_COUNT, bk, bs, be, n_keys=nk + 50)
+    assert (ctx.count_overlaps(ixc, pk, ps, pe) == orc.count_overlaps(bk, bs, be, pk, ps, pe)).all()
+    ixv = ctx.build(pyivx.KIND_COVERAGE, bk, bs, be, n_keys=nk + 50)
+    assert (ctx.coverage(ixv, pk, ps, pe, strict=True) == orc.coverage(bk, bs, be, pk, ps, pe, strict=True)).all()
+    ixn = ctx.build(pyivx.KIND_NEAREST, bk, bs, be, n_keys=nk + 50)
+    gb, gp, gd = ctx.nearest(ixn, pk, ps, pe, k=2)
+    wb, wp, wd = orc.nearest(bk, bs, be, pk, ps, pe, k=2)
+    assert (gb == wb).all() and (gp == wp).all() and (gd == wd).all()
+    k64, s64, e64 = bk, bs.astype(np.int64), be.astype(np.int64)
+    for g, w in zip(ctx.merge(k64, s64, e64, n_keys=nk), orc.merge(k64, s64, e64)):
+        assert len(g) == len(w) and (g == w).all()
+
+
+def test_unaligned_device_views(ctx):
+    # device columns that are not 16-byte aligned (views into larger buffers) take the scalar-load kernels
+    import torch
+    bk, bs, be = synth(30_000, 41, nkeys=5, mean_len=900, span=4_000_000)
+    pk, ps, pe = synth(600_001, 42, nkeys=5, mean_len=150, span=4_000_000)
+    dev = torch.device("cuda:0")
+    pad = lambda a: torch.from_numpy(np.concatenate([np.zeros(1, a.dtype), a]).view(np.int32)).to(dev)[1:]
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ix = ctx.build(pyivx.KIND_OVERLAP, bk, bs, be, n_keys=5)
+    dk, ds, de = pad(pk), pad(ps), pad(pe)
+    assert ds.data_ptr() % 16 != 0
+    total = ctx.overlap_count(ix, dk, ds, de)
+    ob, op = ctx.overlap_fill(ix, dk, ds, de, cap=total)
+    torch.cuda.synchronize()
+    want = orc.join(bk, bs, be, pk, ps, pe, threads=4)
+    got = (ob.cpu().numpy().view(np.uint32), op.cpu().numpy().view(np.uint32))
+    assert (pair_set(*got) == pair_set(*want)).all()
+    ctx.use_own_stream()
