@@ -27,8 +27,8 @@ sys.path.insert(0, os.path.join(ROOT, "datafusion-bio-functions_amd"))
 
 HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # HBM bytes per probe call from rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE, the gfx950 correction of
-# MI355X_MICROARCH.md "HBM"), summed over the pipeline's kernels: profiles/r1_d_regions_pipeline_pmc.txt
-PMC_TRAFFIC_BYTES = {"join_100Mx1M_24contigs": 5.916e9}
+# MI355X_MICROARCH.md "HBM"), summed over the pipeline's kernels: profiles/r1_e_regions_pipeline_pmc.txt
+PMC_TRAFFIC_BYTES = {"join_100Mx1M_24contigs": 5.039e9}
 
 WORKLOADS = {
     # name: (probe rows, build rows, contigs, config id in BASELINE.json.configs)
@@ -150,7 +150,7 @@ def main():
             "config": {"workload": args.workload, "probe_rows_per_gpu": n_probe, "build_rows_per_gpu": n_build,
                        "contigs": n_contigs, "pairs_per_gpu": pairs, "parallelism": f"partition-per-gpu x{world}",
                        "gather": bool(args.gather)},
-            "roofline": {"bound": "hbm", "kernel": "overlap probe pipeline: k_part_hist + k_part_scatter + k_probe_regions<count> + k_probe_regions<fill>", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+            "roofline": {"bound": "hbm", "kernel": "overlap probe pipeline: k_part_hist + k_part_scatter + k_probe_regions<fill>", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": PMC_TRAFFIC_BYTES.get(args.workload) if args.scaling == "weak" else None,
                          "kernel_ms": kern_ms, "algorithmic_bytes": alg_bytes,
