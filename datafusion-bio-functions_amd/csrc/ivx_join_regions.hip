@@ -200,12 +200,21 @@ __global__ __launch_bounds__(PA_T) void k_part_scatter(JoinIndexView ix, const u
 
 constexpr int RP_T = 1024;                 // one workgroup per CU (LDS-bound), 16 wavefronts
 constexpr int RP_W = RP_T / IVX_WAVE;
-constexpr int RP_B = 8;                    // probe rows per lane per wave batch
+#ifndef IVX_RP_B
+#define IVX_RP_B 8
+#endif
+#ifndef IVX_RP_QW
+#define IVX_RP_QW 384
+#endif
+#ifndef IVX_RP_ECAP
+#define IVX_RP_ECAP 7424
+#endif
+constexpr int RP_B = IVX_RP_B;             // probe rows per lane per wave batch
 constexpr u32 RP_WB = IVX_WAVE * RP_B;     // rows per wave batch
 constexpr u32 RP_HALO = 8;                 // slice cells past the region's last cell
 constexpr u32 RP_CCAP = 8192 + RP_HALO + 2;
-constexpr u32 RP_ECAP = 7424;              // entries staged per slice
-constexpr u32 RP_QW = 384;                 // pairs a wavefront stages in LDS before one coalesced write
+constexpr u32 RP_ECAP = IVX_RP_ECAP;       // entries staged per slice
+constexpr u32 RP_QW = IVX_RP_QW;           // pairs a wavefront stages in LDS before one coalesced write
 constexpr u32 RP_GRID = 256;                // fill pass: one workgroup per CU (LDS-bound)
 constexpr u32 RP_VGRID = 512;               // row shares ("virtual workgroups"); the count pass runs two per CU
 
@@ -274,198 +283,240 @@ __device__ __forceinline__ void probe_row(const Slice &S, i32 qs, i32 qe, F &&f)
     }
 }
 
+// ------------------------------------------------------------------ shared pieces of the probe kernels
+
+struct ProbeLds {
+    unsigned short *s_off; u64 *s_ent; u32 *s_row;
+    u32 (*s_qb)[RP_QW]; u32 (*s_qp)[RP_QW];      // per-wavefront pair staging (fill only)
+    u32 (*s_wcnt)[RP_W]; unsigned long long *s_base;
+};
+
+__device__ __forceinline__ void slice_init(const JoinIndexView &ix, Slice &S, const ProbeLds &L)
+{
+    S.ix = &ix; S.s_off = L.s_off; S.s_ent = L.s_ent; S.s_row = L.s_row;
+    S.sh0 = ix.hdr[HDR_SH0]; S.nlev = ix.hdr[HDR_NLEV];
+    S.upper = false;
+    for (u32 l = 1; l < S.nlev; l++) S.upper |= ix.hdr[HDR_LEVCNT + l] != 0;
+    S.lev0 = ix.hdr[HDR_LEVCNT] != 0;
+}
+
+// stage region r's slice of the index in LDS (all threads of the workgroup; barriers inside)
+__device__ __forceinline__ void slice_load(const JoinIndexView &ix, Slice &S, const ProbeLds &L, u32 r, bool reload)
+{
+    const u32 tid = threadIdx.x;
+    const u32 cs = ix.hdr[HDR_CS];
+    __syncthreads();
+    S.k = ix.rkey[r];
+    S.origin = ix.origin[S.k]; S.span = ix.span[S.k];
+    S.lb = ix.lbase[S.k];
+    const u32 cells0 = (S.span >> S.sh0) + 1u;
+    S.ncell0 = cells0;
+    const u32 rc0 = (r - ix.kreg[S.k]) << cs;
+    const u64 rc1w = (u64)rc0 + (1ull << cs);
+    const u32 rc1 = rc1w < cells0 ? (u32)rc1w : cells0;
+    S.slo = rc0 ? rc0 - 1u : 0u;
+    S.shi = rc1 + RP_HALO < cells0 ? rc1 + RP_HALO : cells0;
+    S.e0 = ix.binstart[S.lb + S.slo];
+    const u32 ne = ix.binstart[S.lb + S.shi] - S.e0;
+    const u32 nc = S.shi - S.slo + 1u;
+    S.inlds = ne <= RP_ECAP && nc <= RP_CCAP;
+    if (S.inlds && reload) {
+        for (u32 c0 = 0; c0 < nc; c0 += RP_T * 4) {
+            u32 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const u32 c = c0 + u * RP_T + tid; v[u] = c < nc ? ix.binstart[S.lb + S.slo + c] : 0u; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const u32 c = c0 + u * RP_T + tid; if (c < nc) L.s_off[c] = (unsigned short)(v[u] - S.e0); }
+        }
+        for (u32 j0 = 0; j0 < ne; j0 += RP_T * 4) {
+            ivx_ent x[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const u32 j = j0 + u * RP_T + tid; if (j < ne) x[u] = ix.ent[S.e0 + j]; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const u32 j = j0 + u * RP_T + tid;
+                if (j < ne) { L.s_ent[j] = (u64)(u32)x[u].s | ((u64)(u32)x[u].e << 32); L.s_row[j] = x[u].row; }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// One wave batch: RP_B rows per lane (ok[q] says whether the lane holds a row in slot q).
+// Count pass: returns the lane's pair count.  Fill pass: each lane keeps its first three matches as
+// 16-bit slice slots, a wavefront prefix sum (__shfl_up) turns the lanes' counts into positions of the
+// wavefront's LDS staging buffer; returns the wavefront's staged pair count (0 if it had to write
+// directly because the batch did not fit the staging buffer).
+template <bool FILL>
+__device__ __forceinline__ u32 batch_walk(const Slice &S, const ProbeLds &L, const i32 (&qs)[RP_B], const i32 (&qe)[RP_B],
+                                          const u32 (&rowv)[RP_B], u32 okmask, u32 wv,
+                                          u32 *ob, u32 *op, u64 cap, unsigned long long *cursor, int dbg)
+{
+    u32 tsum = 0;
+    u32 cnt[RP_B], p01[RP_B], p2[RP_B];
+    u32 rewalk = 0;                                           // bit q: more than 3 matches or a non-slot match
+#pragma unroll
+    for (int q = 0; q < RP_B; q++) {
+        const bool ok = (okmask >> q) & 1u;
+        if (!FILL) {
+            if (!ok) continue;
+            if (dbg & 4) tsum += (u32)(qs[q] ^ qe[q]) & 1u;
+            else probe_row(S, qs[q], qe[q], [&](u32, bool) { tsum++; });
+        } else {
+            u32 m = 0, a01 = 0, a2 = 0;
+            if (ok)
+                probe_row(S, qs[q], qe[q], [&](u32 v, bool sl) {
+                    if (!sl) rewalk |= 1u << q;
+                    if (m == 0) a01 = v; else if (m == 1) a01 |= v << 16; else if (m == 2) a2 = v;
+                    m++;
+                });
+            if (m > 3) rewalk |= 1u << q;
+            cnt[q] = m; p01[q] = a01; p2[q] = a2;
+            tsum += m;
+        }
+    }
+    if (!FILL) return tsum;
+    const u32 inc = wave_incl_scan(tsum);
+    const u32 wtot = __shfl(inc, IVX_WAVE - 1, IVX_WAVE);
+    const bool staged = wtot <= RP_QW;
+    u64 own = 0;                                              // rare: a batch too big for the staging buffer
+    if (!staged) { if (lane_id() == 0) own = atomicAdd(cursor, (unsigned long long)wtot); own = __shfl(own, 0, IVX_WAVE); }
+    if (wtot) {
+        u32 at = inc - tsum;
+        const bool direct_ok = !staged && own + wtot <= cap;
+        auto put = [&](u32 brow, u32 prow_id) {
+            if (staged) { L.s_qb[wv][at] = brow; L.s_qp[wv][at] = prow_id; }
+            else if (direct_ok) { ob[own + at] = brow; op[own + at] = prow_id; }
+            at++;
+        };
+#pragma unroll
+        for (int q = 0; q < RP_B; q++) {
+            if (cnt[q] == 0) continue;
+            if (!((rewalk >> q) & 1u)) {
+                put(S.s_row[p01[q] & 0xFFFFu], rowv[q]);
+                if (cnt[q] > 1) put(S.s_row[p01[q] >> 16], rowv[q]);
+                if (cnt[q] > 2) put(S.s_row[p2[q]], rowv[q]);
+            } else {
+                probe_row(S, qs[q], qe[q], [&](u32 v, bool sl) { put(sl ? S.s_row[v] : v, rowv[q]); });
+            }
+        }
+    }
+    return staged ? wtot : 0u;
+}
+
+// fill pass, end of a round: ONE atomicAdd per workgroup reserves the output range of all 16 wavefronts,
+// then every wavefront copies its staged pairs out with full-width stores (all threads call this)
+__device__ __forceinline__ void round_flush(const ProbeLds &L, u32 mine, u32 round, u32 wv,
+                                            u32 *ob, u32 *op, u64 cap, unsigned long long *cursor, int dbg)
+{
+    const u32 ln = lane_id();
+    if (ln == 0) L.s_wcnt[round & 1][wv] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 tot = 0;
+#pragma unroll
+        for (int w = 0; w < RP_W; w++) tot += L.s_wcnt[round & 1][w];
+        *L.s_base = tot ? atomicAdd(cursor, (unsigned long long)tot) : 0ull;
+    }
+    __syncthreads();
+    if (mine) {
+        const u64 base = *L.s_base;
+        u64 g = base;
+        u32 tot = 0;
+#pragma unroll
+        for (int w = 0; w < RP_W; w++) { const u32 c = L.s_wcnt[round & 1][w]; if (w < (int)wv) g += c; tot += c; }
+        if (base + tot <= cap && !(dbg & 16))
+            for (u32 t = ln; t < mine; t += IVX_WAVE) { ob[g + t] = L.s_qb[wv][t]; op[g + t] = L.s_qp[wv][t]; }
+    }
+}
+
+#define IVX_PROBE_LDS(FILL)                                                                          \
+    __shared__ unsigned short s_off[RP_CCAP];                                                        \
+    __shared__ u64 s_ent[RP_ECAP];                                                                   \
+    __shared__ u32 s_row[RP_ECAP];                                                                   \
+    __shared__ u32 s_qb[FILL ? RP_W : 1][RP_QW];                                                     \
+    __shared__ u32 s_qp[FILL ? RP_W : 1][RP_QW];                                                     \
+    __shared__ u32 s_wcnt[2][RP_W];                                                                  \
+    __shared__ unsigned long long s_base;                                                            \
+    ProbeLds L{s_off, s_ent, s_row, s_qb, s_qp, s_wcnt, &s_base};
+
+// ------------------------------------------------------------------ region-major probe (rows scattered by region)
 // Persistent workgroups: the partitioned probe rows are cut into equal row shares ("virtual
 // workgroups"), a workgroup walks its share region segment by region segment, and inside a segment
 // wavefront w owns batches w, w+16, ... of RP_WB rows.
 //   FILL = false (ivx_probe_overlap_count): wavefronts never synchronise; one atomicAdd of the
 //           wavefront's total at the end.
-//   FILL = true : single walk.  Each lane keeps its first three matches as 16-bit slice slots, a
-//           wavefront prefix sum (__shfl_up) turns the lanes' counts into slots of the wavefront's LDS
-//           staging buffer, and once per round ONE atomicAdd per workgroup reserves the output range
-//           of all 16 wavefronts; the staged pairs are then copied out with full-width stores.
+//   FILL = true : single walk, see batch_walk / round_flush.
 template <bool FILL>
 __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const u64 *__restrict__ pse, const u32 *__restrict__ prow,
                                                         const u32 *__restrict__ offs, u32 nblk, u32 vpb,
                                                         u32 *__restrict__ ob, u32 *__restrict__ op, u64 cap,
                                                         unsigned long long *cursor, int dbg)
 {
-    __shared__ unsigned short s_off[RP_CCAP];
-    __shared__ u64 s_ent[RP_ECAP];
-    __shared__ u32 s_row[RP_ECAP];
-    __shared__ u32 s_qb[FILL ? RP_W : 1][FILL ? RP_QW : 1];     // per-wavefront pair staging
-    __shared__ u32 s_qp[FILL ? RP_W : 1][FILL ? RP_QW : 1];
-    __shared__ u32 s_wcnt[2][RP_W];                               // pairs staged by each wavefront, double-buffered by round
-    __shared__ unsigned long long s_base;
-
-    const u32 tid = threadIdx.x, wv = tid / IVX_WAVE, ln = lane_id();
+    IVX_PROBE_LDS(FILL)
+    const u32 wv = threadIdx.x / IVX_WAVE, ln = lane_id();
     const u32 nreg = ix.hdr[HDR_NREG];
     const u64 total_rows = offs[(u64)nreg * nblk];
     const u32 nvb = gridDim.x * vpb;
     u32 loaded_r = 0xFFFFFFFFu;                                       // region whose slice currently sits in LDS
+    Slice S;
+    slice_init(ix, S, L);
     for (u32 vb = blockIdx.x * vpb; vb < (blockIdx.x + 1) * vpb; vb++) {
-    u64 lo = total_rows * vb / nvb;
-    const u64 hi = total_rows * (vb + 1) / nvb;
-    u64 wcur = 0;                                                     // count pass: pairs seen by this wavefront
-    u32 round = 0;
-    if (lo < hi) {
-        u32 r;
-        {   // last region whose first row is <= lo
-            u32 a = 0, b = nreg;
-            while (a < b) { const u32 m = (a + b + 1) >> 1; if (offs[(u64)m * nblk] <= lo) a = m; else b = m - 1; }
-            r = a;
-        }
-        Slice S;
-        S.ix = &ix; S.s_off = s_off; S.s_ent = s_ent; S.s_row = s_row;
-        S.sh0 = ix.hdr[HDR_SH0]; S.nlev = ix.hdr[HDR_NLEV];
-        const u32 cs = ix.hdr[HDR_CS];
-        S.upper = false;
-        for (u32 l = 1; l < S.nlev; l++) S.upper |= ix.hdr[HDR_LEVCNT + l] != 0;
-        S.lev0 = ix.hdr[HDR_LEVCNT] != 0;
-
-        for (; lo < hi; r++) {
-            const u64 rend = offs[(u64)(r + 1) * nblk];
-            const u64 c_hi = hi < rend ? hi : rend;
-            if (c_hi <= lo) continue;
-            // ---- stage the region's slice of the index in LDS (unless the previous share left it there)
-            const bool reload = r != loaded_r;
-            loaded_r = r;
-            __syncthreads();
-            S.k = ix.rkey[r];
-            S.origin = ix.origin[S.k]; S.span = ix.span[S.k];
-            S.lb = ix.lbase[S.k];
-            const u32 cells0 = (S.span >> S.sh0) + 1u;
-            S.ncell0 = cells0;
-            const u32 rc0 = (r - ix.kreg[S.k]) << cs;
-            const u64 rc1w = (u64)rc0 + (1ull << cs);
-            const u32 rc1 = rc1w < cells0 ? (u32)rc1w : cells0;
-            S.slo = rc0 ? rc0 - 1u : 0u;
-            S.shi = rc1 + RP_HALO < cells0 ? rc1 + RP_HALO : cells0;
-            S.e0 = ix.binstart[S.lb + S.slo];
-            const u32 ne = ix.binstart[S.lb + S.shi] - S.e0;
-            const u32 nc = S.shi - S.slo + 1u;
-            S.inlds = ne <= RP_ECAP && nc <= RP_CCAP;
-            if (S.inlds && reload) {
-                for (u32 c0 = 0; c0 < nc; c0 += RP_T * 4) {
-                    u32 v[4];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) { const u32 c = c0 + u * RP_T + tid; v[u] = c < nc ? ix.binstart[S.lb + S.slo + c] : 0u; }
-#pragma unroll
-                    for (int u = 0; u < 4; u++) { const u32 c = c0 + u * RP_T + tid; if (c < nc) s_off[c] = (unsigned short)(v[u] - S.e0); }
-                }
-                for (u32 j0 = 0; j0 < ne; j0 += RP_T * 4) {
-                    ivx_ent x[4];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) { const u32 j = j0 + u * RP_T + tid; if (j < ne) x[u] = ix.ent[S.e0 + j]; }
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        const u32 j = j0 + u * RP_T + tid;
-                        if (j < ne) { s_ent[j] = (u64)(u32)x[u].s | ((u64)(u32)x[u].e << 32); s_row[j] = x[u].row; }
-                    }
-                }
+        u64 lo = total_rows * vb / nvb;
+        const u64 hi = total_rows * (vb + 1) / nvb;
+        u64 wcur = 0;                                                 // count pass: pairs seen by this wavefront
+        u32 round = 0;
+        if (lo < hi) {
+            u32 r;
+            {   // last region whose first row is <= lo
+                u32 a = 0, b = nreg;
+                while (a < b) { const u32 m = (a + b + 1) >> 1; if (offs[(u64)m * nblk] <= lo) a = m; else b = m - 1; }
+                r = a;
             }
-            __syncthreads();
-
-            // ---- every wavefront streams one batch of RP_WB rows per round; the next round's rows are in
-            //      flight while the current batch walks the LDS slice.  Count pass: no synchronisation at
-            //      all.  Fill pass: pairs are staged per wavefront in LDS, then ONE atomicAdd per workgroup
-            //      and round reserves the output range of all 16 wavefronts (about one atomic per 3000 pairs).
-            u64 nx[RP_B]; u32 nxr[FILL ? RP_B : 1];
-            u64 b0 = lo + (u64)wv * RP_WB;
-#pragma unroll
-            for (int q = 0; q < RP_B; q++) {
-                const u64 i = b0 + (u64)q * IVX_WAVE + ln;
-                nx[q] = i < c_hi ? pse[i] : 0;
-                if (FILL) nxr[q] = i < c_hi ? prow[i] : 0u;
-            }
-            for (u64 r0 = lo; r0 < c_hi; r0 += (u64)RP_W * RP_WB, b0 += (u64)RP_W * RP_WB, round++) {
-                i32 qs[RP_B], qe[RP_B]; u32 rowv[FILL ? RP_B : 1];
-#pragma unroll
-                for (int q = 0; q < RP_B; q++) { qs[q] = (i32)(u32)nx[q]; qe[q] = (i32)(u32)(nx[q] >> 32); if (FILL) rowv[q] = nxr[q]; }
-                {
-                    const u64 b1 = b0 + (u64)RP_W * RP_WB;
-#pragma unroll
-                    for (int q = 0; q < RP_B; q++) {
-                        const u64 i = b1 + (u64)q * IVX_WAVE + ln;
-                        nx[q] = i < c_hi ? pse[i] : 0;
-                        if (FILL) nxr[q] = i < c_hi ? prow[i] : 0u;
-                    }
-                }
-                u32 tsum = 0;
-                u32 cnt[FILL ? RP_B : 1], p01[FILL ? RP_B : 1], p2[FILL ? RP_B : 1];   // first three matches as 16-bit slice slots
-                u32 rewalk = 0;                                           // bit q: more than 3 matches or a non-slot match
+            for (; lo < hi; r++) {
+                const u64 rend = offs[(u64)(r + 1) * nblk];
+                const u64 c_hi = hi < rend ? hi : rend;
+                if (c_hi <= lo) continue;
+                slice_load(ix, S, L, r, r != loaded_r);
+                loaded_r = r;
+                // every wavefront streams one batch of RP_WB rows per round; the next round's rows are in
+                // flight while the current batch walks the LDS slice
+                u64 nx[RP_B]; u32 nxr[RP_B];
+                u64 b0 = lo + (u64)wv * RP_WB;
 #pragma unroll
                 for (int q = 0; q < RP_B; q++) {
                     const u64 i = b0 + (u64)q * IVX_WAVE + ln;
-                    if (!FILL) {
-                        if (i >= c_hi) continue;
-                        if (dbg & 4) tsum += (u32)(qs[q] ^ qe[q]) & 1u;
-                        else probe_row(S, qs[q], qe[q], [&](u32, bool) { tsum++; });
-                    } else {
-                        u32 m = 0, a01 = 0, a2 = 0;
-                        if (i < c_hi)
-                            probe_row(S, qs[q], qe[q], [&](u32 v, bool sl) {
-                                if (!sl) rewalk |= 1u << q;
-                                if (m == 0) a01 = v; else if (m == 1) a01 |= v << 16; else if (m == 2) a2 = v;
-                                m++;
-                            });
-                        if (m > 3) rewalk |= 1u << q;
-                        cnt[q] = m; p01[q] = a01; p2[q] = a2;
-                        tsum += m;
-                    }
+                    nx[q] = i < c_hi ? pse[i] : 0;
+                    nxr[q] = (FILL && i < c_hi) ? prow[i] : 0u;
                 }
-                if (!FILL) { wcur += tsum; continue; }
-                // wavefront prefix sum over the lanes' pair counts
-                const u32 inc = wave_incl_scan(tsum);
-                const u32 wtot = __shfl(inc, IVX_WAVE - 1, IVX_WAVE);
-                const bool staged = wtot <= RP_QW;
-                u64 own = 0;                                              // rare: a batch too big for the staging buffer
-                if (!staged) { if (ln == 0) own = atomicAdd(cursor, (unsigned long long)wtot); own = __shfl(own, 0, IVX_WAVE); }
-                if (wtot) {
-                    u32 at = inc - tsum;
-                    const bool direct_ok = !staged && own + wtot <= cap;
-                    auto put = [&](u32 brow, u32 prow_id) {
-                        if (staged) { s_qb[wv][at] = brow; s_qp[wv][at] = prow_id; }
-                        else if (direct_ok) { ob[own + at] = brow; op[own + at] = prow_id; }
-                        at++;
-                    };
+                for (u64 r0 = lo; r0 < c_hi; r0 += (u64)RP_W * RP_WB, b0 += (u64)RP_W * RP_WB, round++) {
+                    i32 qs[RP_B], qe[RP_B]; u32 rowv[RP_B];
+                    u32 okmask = 0;
 #pragma unroll
                     for (int q = 0; q < RP_B; q++) {
-                        if (cnt[q] == 0) continue;
-                        if (!((rewalk >> q) & 1u)) {
-                            put(S.s_row[p01[q] & 0xFFFFu], rowv[q]);
-                            if (cnt[q] > 1) put(S.s_row[p01[q] >> 16], rowv[q]);
-                            if (cnt[q] > 2) put(S.s_row[p2[q]], rowv[q]);
-                        } else {
-                            probe_row(S, qs[q], qe[q], [&](u32 v, bool sl) { put(sl ? S.s_row[v] : v, rowv[q]); });
+                        qs[q] = (i32)(u32)nx[q]; qe[q] = (i32)(u32)(nx[q] >> 32); rowv[q] = nxr[q];
+                        if (b0 + (u64)q * IVX_WAVE + ln < c_hi) okmask |= 1u << q;
+                    }
+                    {
+                        const u64 b1 = b0 + (u64)RP_W * RP_WB;
+#pragma unroll
+                        for (int q = 0; q < RP_B; q++) {
+                            const u64 i = b1 + (u64)q * IVX_WAVE + ln;
+                            nx[q] = i < c_hi ? pse[i] : 0;
+                            nxr[q] = (FILL && i < c_hi) ? prow[i] : 0u;
                         }
                     }
+                    const u32 got = batch_walk<FILL>(S, L, qs, qe, rowv, okmask, wv, ob, op, cap, cursor, dbg);
+                    if (!FILL) { wcur += got; continue; }
+                    round_flush(L, got, round, wv, ob, op, cap, cursor, dbg);
                 }
-                const u32 mine = staged ? wtot : 0u;
-                if (ln == 0) s_wcnt[round & 1][wv] = mine;
-                __syncthreads();
-                if (tid == 0) {
-                    u32 tot = 0;
-#pragma unroll
-                    for (int w = 0; w < RP_W; w++) tot += s_wcnt[round & 1][w];
-                    s_base = tot ? atomicAdd(cursor, (unsigned long long)tot) : 0ull;
-                }
-                __syncthreads();
-                if (mine) {
-                    u64 g = s_base;
-                    u32 tot = 0;
-#pragma unroll
-                    for (int w = 0; w < RP_W; w++) { const u32 c = s_wcnt[round & 1][w]; if (w < (int)wv) g += c; tot += c; }
-                    if (s_base + tot <= cap && !(dbg & 16))
-                        for (u32 t = ln; t < mine; t += IVX_WAVE) { ob[g + t] = s_qb[wv][t]; op[g + t] = s_qp[wv][t]; }
-                }
+                lo = c_hi;
             }
-            lo = c_hi;
         }
-    }
-    if (!FILL) {
-        const u64 tot = wave_sum(wcur);
-        if (ln == 0 && tot) atomicAdd(cursor, (unsigned long long)tot);
-    }
+        if (!FILL) {
+            const u64 tot = wave_sum(wcur);
+            if (ln == 0 && tot) atomicAdd(cursor, (unsigned long long)tot);
+        }
     }
 }
 
