@@ -520,7 +520,228 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
     }
 }
 
+// ------------------------------------------------------------------ tile-local partition ("TLS") path
+//
+// The region-major scatter above writes every row to one of ~195 x (workgroups in flight) open streams in
+// pieces of ~40 rows, which costs DRAM page locality (k_part_scatter spends more than half of its time on
+// the stores), and it needs a histogram pass first.  Here every 10240-row tile of the probe side is
+// sorted by region INSIDE LDS and written back as one contiguous tile (full-line streaming stores, row
+// ids as 16-bit tile-local indices), plus a small region-major table of (offset, length) per (region,
+// tile).  The probe kernel then consumes, for each region, the pieces of all tiles: one piece of <= 64
+// rows per wavefront slot.  No histogram pass, 10 bytes per row written instead of 12.
+
+constexpr int TS_T = 1024;
+constexpr int TS_TILE = 10240;                    // ~52 rows per region and tile on 195 regions: one slot each, 5 % need two
+constexpr int TS_VEC = TS_TILE / 4;               // 16-byte row vectors per tile
+constexpr int TS_VPT = (TS_VEC + TS_T - 1) / TS_T;   // vectors per thread (3, the last one only for tid < 512)
+
+template <bool VEC>
+__global__ __launch_bounds__(TS_T) void k_tile_sort(JoinIndexView ix, const u32 *__restrict__ pkey, const i32 *__restrict__ ps,
+                                                    const i32 *__restrict__ pe, u64 n, u32 ntiles,
+                                                    u64 *__restrict__ tse, unsigned short *__restrict__ tidx,
+                                                    u32 *__restrict__ tp, u32 *__restrict__ tslots)
+{
+    __shared__ u64 l_se[TS_TILE];
+    __shared__ unsigned short l_idx[TS_TILE];
+    __shared__ u32 tcnt[PA_ND], dstart[PA_ND];
+    __shared__ u32 scan_lds[TS_T / IVX_WAVE + 1];
+    __shared__ i32 s_origin[KT_MAX];
+    __shared__ u32 s_last[KT_MAX], s_kreg[KT_MAX];
+    const u32 tid = threadIdx.x;
+    KeyTab kt;
+    keytab_load(ix, s_origin, s_last, s_kreg, kt);
+    for (u32 t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const u64 t0 = (u64)t * TS_TILE;
+        const u64 hi = t0 + TS_TILE < n ? t0 + TS_TILE : n;
+        if (tid < PA_ND) tcnt[tid] = 0;
+        __syncthreads();
+        u64 se[TS_VPT * 4]; u32 dig[TS_VPT * 4], lrank[TS_VPT * 4];
+#pragma unroll
+        for (int v = 0; v < TS_VPT; v++) {
+            const u32 vi = v * TS_T + tid;
+            u32 k4[4]; i32 s4[4], e4[4];
+            if (vi < TS_VEC) load4<VEC>(pkey, ps, pe, t0 + (u64)vi * 4, hi, k4, s4, e4);
+            else { for (int j = 0; j < 4; j++) { k4[j] = 0xFFFFFFFFu; s4[j] = 0; e4[j] = 0; } }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                se[v * 4 + j] = (u64)(u32)s4[j] | ((u64)(u32)e4[j] << 32);
+                const u32 d = region_of(ix, kt, k4[j], s4[j]);
+                dig[v * 4 + j] = d;
+                lrank[v * 4 + j] = d != NO_REGION ? atomicAdd(&tcnt[d], 1u) : 0u;
+            }
+        }
+        __syncthreads();
+        u32 tot;
+        const u32 mine = tid < PA_ND ? tcnt[tid] : 0u;
+        const u32 ds = block_excl_scan<u32, TS_T>(mine, scan_lds, &tot);
+        if (tid < PA_ND) {
+            dstart[tid] = ds;
+            tp[(u64)tid * ntiles + t] = ds | (mine << 16);            // piece of region tid inside tile t
+            tslots[(u64)tid * ntiles + t] = (mine + IVX_WAVE - 1) / IVX_WAVE;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < TS_VPT; v++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const u32 d = dig[v * 4 + j];
+                if (d != NO_REGION) {
+                    const u32 pos = dstart[d] + lrank[v * 4 + j];
+                    l_se[pos] = se[v * 4 + j];
+                    l_idx[pos] = (unsigned short)((v * TS_T + tid) * 4 + j);
+                }
+            }
+        }
+        __syncthreads();
+        for (u32 j = tid; j < tot; j += TS_T) { tse[t0 + j] = l_se[j]; tidx[t0 + j] = l_idx[j]; }
+    }
+}
+
+// Probe over tile-sorted rows.  The work list is the sequence of 64-row slots of all (region, tile)
+// pieces in region-major order; `sp` is the exclusive prefix of slots per piece.  Every workgroup takes
+// an equal share of the slots; inside a region segment each wavefront owns a contiguous run of slots and
+// keeps a 64-entry window of the piece table in registers (one coalesced load), so locating a slot's
+// piece is a ballot + popcount.
+template <bool FILL>
+__global__ __launch_bounds__(RP_T) void k_probe_tls(JoinIndexView ix, const u64 *__restrict__ tse, const unsigned short *__restrict__ tidx,
+                                                    const u32 *__restrict__ tp, const u32 *__restrict__ sp, u32 ntiles, u32 vpb,
+                                                    u32 *__restrict__ ob, u32 *__restrict__ op, u64 cap,
+                                                    unsigned long long *cursor, int dbg)
+{
+    IVX_PROBE_LDS(FILL)
+    const u32 wv = threadIdx.x / IVX_WAVE, ln = lane_id();
+    const u32 nreg = ix.hdr[HDR_NREG];
+    const u32 nent = nreg * ntiles;                                   // pieces (region-major)
+    const u64 total_slots = sp[nent];
+    const u32 nvb = gridDim.x * vpb;
+    u32 loaded_r = 0xFFFFFFFFu;
+    Slice S;
+    slice_init(ix, S, L);
+    for (u32 vb = blockIdx.x * vpb; vb < (blockIdx.x + 1) * vpb; vb++) {
+        u32 lo = (u32)(total_slots * vb / nvb);
+        const u32 hi = (u32)(total_slots * (vb + 1) / nvb);
+        u64 wcur = 0;
+        u32 round = 0;
+        if (lo >= hi) continue;
+        u32 e;                                                        // piece holding slot lo: last e with sp[e] <= lo
+        {
+            u32 a = 0, b = nent;
+            while (a < b) { const u32 m = (a + b + 1) >> 1; if (sp[m] <= lo) a = m; else b = m - 1; }
+            e = a;
+        }
+        while (lo < hi) {
+            const u32 r = e / ntiles;                                 // region of the segment
+            const u32 eend = (r + 1) * ntiles;
+            const u32 seg_hi = sp[eend] < hi ? sp[eend] : hi;
+            if (seg_hi <= lo) { e = eend; continue; }
+            slice_load(ix, S, L, r, r != loaded_r);
+            loaded_r = r;
+            // contiguous run of slots per wavefront, the same number of rounds for all of them
+            const u32 seg_n = seg_hi - lo;
+            const u32 chunk = ((seg_n + RP_W - 1) / RP_W + RP_B - 1) / RP_B * RP_B;
+            const u32 rounds = chunk / RP_B;
+            const u32 ws0 = lo + wv * chunk < seg_hi ? lo + wv * chunk : seg_hi;
+            const u32 ws1 = ws0 + chunk < seg_hi ? ws0 + chunk : seg_hi;
+            // piece-table window: lane i holds sp/tp of piece wbase + i
+            u32 wbase = e;
+            if (ws0 < ws1) {
+                u32 a = e, b = eend - 1;
+                while (a < b) { const u32 m = (a + b + 1) >> 1; if (sp[m] <= ws0) a = m; else b = m - 1; }
+                wbase = a;
+            }
+            u32 spv = wbase + ln <= nent ? sp[wbase + ln] : 0xFFFFFFFFu;
+            u32 tpv = wbase + ln < nent ? tp[wbase + ln] : 0u;
+            auto locate = [&](u32 s, u32 &tile, u32 &beg, u32 &len, u32 &sub) {
+                for (;;) {
+                    const u32 c = (u32)__popcll(__ballot(spv <= s));   // pieces of the window that start at or before slot s
+                    if (c == IVX_WAVE && wbase + IVX_WAVE - 1 < eend - 1) {   // may lie beyond the window: slide it
+                        wbase += IVX_WAVE - 1;
+                        spv = wbase + ln <= nent ? sp[wbase + ln] : 0xFFFFFFFFu;
+                        tpv = wbase + ln < nent ? tp[wbase + ln] : 0u;
+                        continue;
+                    }
+                    const u32 i = __builtin_amdgcn_readfirstlane(c - 1);
+                    const u32 pv = __builtin_amdgcn_readlane(tpv, i);
+                    sub = s - __builtin_amdgcn_readlane(spv, i);
+                    tile = wbase + i - r * ntiles;
+                    beg = pv & 0xFFFFu; len = pv >> 16;
+                    return;
+                }
+            };
+            u64 nx[RP_B]; u32 nxr[RP_B]; u32 nok = 0;
+            auto issue = [&](u32 s0) {                                // loads of the RP_B slots starting at s0
+                nok = 0;
+#pragma unroll
+                for (int q = 0; q < RP_B; q++) {
+                    const u32 s = s0 + q;
+                    nx[q] = 0; nxr[q] = 0;
+                    if (s < ws1) {
+                        u32 tile, beg, len, sub;
+                        locate(s, tile, beg, len, sub);
+                        const u32 off = sub * IVX_WAVE + ln;
+                        if (off < len) {
+                            const u64 at = (u64)tile * TS_TILE + beg + off;
+                            nx[q] = tse[at];
+                            if (FILL) nxr[q] = tile * (u32)TS_TILE + tidx[at];
+                            nok |= 1u << q;
+                        }
+                    }
+                }
+            };
+            issue(ws0);
+            for (u32 rd = 0; rd < rounds; rd++, round++) {
+                i32 qs[RP_B], qe[RP_B]; u32 rowv[RP_B];
+                const u32 okmask = nok;
+#pragma unroll
+                for (int q = 0; q < RP_B; q++) { qs[q] = (i32)(u32)nx[q]; qe[q] = (i32)(u32)(nx[q] >> 32); rowv[q] = nxr[q]; }
+                issue(ws0 + (rd + 1) * RP_B);
+                const u32 got = batch_walk<FILL>(S, L, qs, qe, rowv, okmask, wv, ob, op, cap, cursor, dbg);
+                if (!FILL) { wcur += got; continue; }
+                round_flush(L, got, round, wv, ob, op, cap, cursor, dbg);
+            }
+            lo = seg_hi;
+            e = eend;
+            if (lo < hi) {                                            // next segment starts at the first piece with slots
+                u32 a = e, b = nent;
+                while (a < b) { const u32 m = (a + b + 1) >> 1; if (sp[m] <= lo) a = m; else b = m - 1; }
+                e = a;
+            }
+        }
+        if (!FILL) {
+            const u64 tot = wave_sum(wcur);
+            if (ln == 0 && tot) atomicAdd(cursor, (unsigned long long)tot);
+        }
+    }
+}
+
 }  // namespace
+
+static ivx_status probe_tls(ivx_ctx *ctx, const JoinIndexView &jv, int mode,
+                            const u32 *key, const i32 *s, const i32 *e, u64 n,
+                            u32 *ob, u32 *op, u64 cap, u64 *d_cursor, int dbg)
+{
+    hipStream_t st = ctx->stream;
+    const u32 ntiles = (u32)((n + TS_TILE - 1) / TS_TILE);
+    const u64 nent = (u64)PA_ND * ntiles;
+    u64 *tse; unsigned short *tidx; u32 *tp, *sp;
+    IVX_TRY(ctx->get_scratch(WS_T0, (u64)ntiles * TS_TILE * sizeof(u64), (void **)&tse));
+    IVX_TRY(ctx->get_scratch(WS_T1, (u64)ntiles * TS_TILE * sizeof(unsigned short), (void **)&tidx));
+    IVX_TRY(ctx->get_scratch(WS_T2, nent * sizeof(u32), (void **)&tp));
+    IVX_TRY(ctx->get_scratch(WS_SORTHIST, (nent + 1) * sizeof(u32), (void **)&sp));
+    IVX_HIP(ctx, hipMemsetAsync(sp + nent, 0, sizeof(u32), st));
+    const bool vec = (((uintptr_t)key | (uintptr_t)s | (uintptr_t)e) & 15) == 0;
+    const u32 grid = ntiles < 256 ? ntiles : 256;                    // one workgroup per CU (LDS-bound), tiles strided
+    if (vec) hipLaunchKernelGGL(k_tile_sort<true>, dim3(grid), dim3(TS_T), 0, st, jv, key, s, e, n, ntiles, tse, tidx, tp, sp);
+    else hipLaunchKernelGGL(k_tile_sort<false>, dim3(grid), dim3(TS_T), 0, st, jv, key, s, e, n, ntiles, tse, tidx, tp, sp);
+    IVX_TRY(ivx_scan_exclusive_u32(ctx, sp, nent + 1));
+    unsigned long long *cur = (unsigned long long *)d_cursor;
+    if (mode == JP_FILL)
+        hipLaunchKernelGGL(k_probe_tls<true>, dim3(RP_GRID), dim3(RP_T), 0, st, jv, (const u64 *)tse, (const unsigned short *)tidx, (const u32 *)tp, (const u32 *)sp, ntiles, RP_VGRID / RP_GRID, ob, op, cap, cur, dbg);
+    else
+        hipLaunchKernelGGL(k_probe_tls<false>, dim3(RP_VGRID), dim3(RP_T), 0, st, jv, (const u64 *)tse, (const unsigned short *)tidx, (const u32 *)tp, (const u32 *)sp, ntiles, 1u, ob, op, cap, cur, dbg);
+    IVX_HIP(ctx, hipGetLastError());
+    return IVX_OK;
+}
 
 ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, int mode,
                                   const u32 *key, const i32 *s, const i32 *e, u64 n,
@@ -528,6 +749,10 @@ ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, int mod
 {
     if (n == 0) return IVX_OK;
     hipStream_t st = ctx->stream;
+    {
+        const char *f = getenv("IVX_JOIN_TLS");
+        if (f && atoi(f)) return probe_tls(ctx, jv, mode, key, s, e, n, ob, op, cap, d_cursor, getenv("IVX_DBG") ? atoi(getenv("IVX_DBG")) : 0);
+    }
     const u32 nblk = (u32)((n + PA_CHUNK - 1) / PA_CHUNK);
     u32 *hist; u64 *pse; u32 *prow;
     const u64 nh = (u64)256 * nblk + 1;

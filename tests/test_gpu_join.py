@@ -28,15 +28,16 @@ def _check_join(ctx, bk, bs, be, pk, ps, pe, nkeys):
     assert total == len(want_b)
     assert (per_row.astype(np.uint64) == want_cnt).all()
     # both probe paths: gathers straight from the index, and region-partitioned through LDS
-    for path in ("direct", "regions"):
+    for path, tls in (("direct", "0"), ("regions", "0"), ("regions", "1")):
         os.environ["IVX_JOIN_PATH"] = path
+        os.environ["IVX_JOIN_TLS"] = tls              # regions: region-major scatter (0) or tile-local sort (1)
         try:
-            assert ctx.overlap_count(ix, pk, ps, pe) == total, path
+            assert ctx.overlap_count(ix, pk, ps, pe) == total, (path, tls)
             ob, op = ctx.overlap_fill(ix, pk, ps, pe, cap=total)
         finally:
-            del os.environ["IVX_JOIN_PATH"]
-        assert len(ob) == total, path
-        assert (pair_set(ob, op) == pair_set(want_b, want_p)).all(), path
+            del os.environ["IVX_JOIN_PATH"], os.environ["IVX_JOIN_TLS"]
+        assert len(ob) == total, (path, tls)
+        assert (pair_set(ob, op) == pair_set(want_b, want_p)).all(), (path, tls)
     ex = ctx.exists(ix, pk, ps, pe)
     assert (ex == (want_cnt > 0)).all()
     ix.free()
