@@ -203,18 +203,19 @@ constexpr int RP_W = RP_T / IVX_WAVE;
 #ifndef IVX_RP_B
 #define IVX_RP_B 8
 #endif
-#ifndef IVX_RP_QW
-#define IVX_RP_QW 384
+#ifndef IVX_RP_RING
+#define IVX_RP_RING 512
 #endif
 #ifndef IVX_RP_ECAP
-#define IVX_RP_ECAP 7424
+#define IVX_RP_ECAP 6144
 #endif
 constexpr int RP_B = IVX_RP_B;             // probe rows per lane per wave batch
 constexpr u32 RP_WB = IVX_WAVE * RP_B;     // rows per wave batch
 constexpr u32 RP_HALO = 8;                 // slice cells past the region's last cell
 constexpr u32 RP_CCAP = 8192 + RP_HALO + 2;
 constexpr u32 RP_ECAP = IVX_RP_ECAP;       // entries staged per slice
-constexpr u32 RP_QW = IVX_RP_QW;           // pairs a wavefront stages in LDS before one coalesced write
+constexpr u32 RP_RING = IVX_RP_RING;       // per-wavefront ring of staged pairs: two consecutive rounds must fit (power of two)
+constexpr u32 RP_NSLOT = 4;                // rounds whose reservation state is kept (see round_publish)
 constexpr u32 RP_GRID = 256;                // fill pass: one workgroup per CU (LDS-bound)
 constexpr u32 RP_VGRID = 512;               // row shares ("virtual workgroups"); the count pass runs two per CU
 
@@ -287,8 +288,12 @@ __device__ __forceinline__ void probe_row(const Slice &S, i32 qs, i32 qe, F &&f)
 
 struct ProbeLds {
     unsigned short *s_off; u64 *s_ent; u32 *s_row;
-    u32 (*s_qb)[RP_QW]; u32 (*s_qp)[RP_QW];      // per-wavefront pair staging (fill only)
-    u32 (*s_wcnt)[RP_W]; unsigned long long *s_base;
+    // fill pass only
+    u64 (*s_q)[RP_RING];                          // per-wavefront ring of staged (build row, probe row) pairs
+    u32 *s_wpos;                                  // per-wavefront ring write position (running, never reset)
+    u32 (*s_wcnt)[RP_W];                          // [RP_NSLOT] pairs each wavefront staged in a round
+    unsigned long long *s_base;                   // [RP_NSLOT] output position reserved for the round
+    u32 *s_arrive, *s_ready;                      // [RP_NSLOT] wavefronts arrived / round tag once s_base is valid
 };
 
 __device__ __forceinline__ void slice_init(const JoinIndexView &ix, Slice &S, const ProbeLds &L)
@@ -342,91 +347,99 @@ __device__ __forceinline__ void slice_load(const JoinIndexView &ix, Slice &S, co
     __syncthreads();
 }
 
-// One wave batch: RP_B rows per lane (ok[q] says whether the lane holds a row in slot q).
-// Count pass: returns the lane's pair count.  Fill pass: each lane keeps its first three matches as
-// 16-bit slice slots, a wavefront prefix sum (__shfl_up) turns the lanes' counts into positions of the
-// wavefront's LDS staging buffer; returns the wavefront's staged pair count (0 if it had to write
-// directly because the batch did not fit the staging buffer).
+// One wave batch: RP_B rows per lane (bit q of okmask says whether the lane holds a row in slot q).
+// Count pass: returns the lane's pair count.
+// Fill pass: every match takes the next slot of the wavefront's LDS staging buffer with an LDS atomic on
+// the wavefront's own running counter (lanes of one instruction are serialised by the LDS unit and get
+// distinct slots), so no per-row match stash, prefix sum or second walk is needed.  Returns the
+// wavefront's staged pair count (0 if the batch did not fit the buffer and was written directly).
 template <bool FILL>
 __device__ __forceinline__ u32 batch_walk(const Slice &S, const ProbeLds &L, const i32 (&qs)[RP_B], const i32 (&qe)[RP_B],
-                                          const u32 (&rowv)[RP_B], u32 okmask, u32 wv,
+                                          const u32 (&rowv)[RP_B], u32 okmask, u32 wv, u32 ring_tail, u32 &ring_start,
                                           u32 *ob, u32 *op, u64 cap, unsigned long long *cursor, int dbg)
 {
-    u32 tsum = 0;
-    u32 cnt[RP_B], p01[RP_B], p2[RP_B];
-    u32 rewalk = 0;                                           // bit q: more than 3 matches or a non-slot match
-#pragma unroll
-    for (int q = 0; q < RP_B; q++) {
-        const bool ok = (okmask >> q) & 1u;
-        if (!FILL) {
-            if (!ok) continue;
-            if (dbg & 4) tsum += (u32)(qs[q] ^ qe[q]) & 1u;
-            else probe_row(S, qs[q], qe[q], [&](u32, bool) { tsum++; });
-        } else {
-            u32 m = 0, a01 = 0, a2 = 0;
-            if (ok)
-                probe_row(S, qs[q], qe[q], [&](u32 v, bool sl) {
-                    if (!sl) rewalk |= 1u << q;
-                    if (m == 0) a01 = v; else if (m == 1) a01 |= v << 16; else if (m == 2) a2 = v;
-                    m++;
-                });
-            if (m > 3) rewalk |= 1u << q;
-            cnt[q] = m; p01[q] = a01; p2[q] = a2;
-            tsum += m;
-        }
-    }
-    if (!FILL) return tsum;
-    const u32 inc = wave_incl_scan(tsum);
-    const u32 wtot = __shfl(inc, IVX_WAVE - 1, IVX_WAVE);
-    const bool staged = wtot <= RP_QW;
-    u64 own = 0;                                              // rare: a batch too big for the staging buffer
-    if (!staged) { if (lane_id() == 0) own = atomicAdd(cursor, (unsigned long long)wtot); own = __shfl(own, 0, IVX_WAVE); }
-    if (wtot) {
-        u32 at = inc - tsum;
-        const bool direct_ok = !staged && own + wtot <= cap;
-        auto put = [&](u32 brow, u32 prow_id) {
-            if (staged) { L.s_qb[wv][at] = brow; L.s_qp[wv][at] = prow_id; }
-            else if (direct_ok) { ob[own + at] = brow; op[own + at] = prow_id; }
-            at++;
-        };
+    if (!FILL) {
+        u32 tsum = 0;
 #pragma unroll
         for (int q = 0; q < RP_B; q++) {
-            if (cnt[q] == 0) continue;
-            if (!((rewalk >> q) & 1u)) {
-                put(S.s_row[p01[q] & 0xFFFFu], rowv[q]);
-                if (cnt[q] > 1) put(S.s_row[p01[q] >> 16], rowv[q]);
-                if (cnt[q] > 2) put(S.s_row[p2[q]], rowv[q]);
-            } else {
-                probe_row(S, qs[q], qe[q], [&](u32 v, bool sl) { put(sl ? S.s_row[v] : v, rowv[q]); });
-            }
+            if (!((okmask >> q) & 1u)) continue;
+            if (dbg & 4) tsum += (u32)(qs[q] ^ qe[q]) & 1u;
+            else probe_row(S, qs[q], qe[q], [&](u32, bool) { tsum++; });
         }
+        return tsum;
     }
-    return staged ? wtot : 0u;
+    u32 *cp = &L.s_wpos[wv];
+    const u32 base = __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    ring_start = base;
+#pragma unroll
+    for (int q = 0; q < RP_B; q++) {
+        if (!((okmask >> q) & 1u)) continue;
+        probe_row(S, qs[q], qe[q], [&](u32 v, bool sl) {
+            const u32 pos = __hip_atomic_fetch_add(cp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (pos - ring_tail < RP_RING && !(dbg & 64))
+                L.s_q[wv][pos & (RP_RING - 1)] = (u64)(sl ? S.s_row[v] : v) | ((u64)rowv[q] << 32);
+        });
+    }
+    const u32 wtot = __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - base;
+    if (base + wtot - ring_tail <= RP_RING) return wtot;
+    // rare: this round and the previous one do not fit the ring together -- reserve the batch's output
+    // range directly and walk again (the previous round's pairs were never overwritten)
+    u64 own = 0;
+    if (lane_id() == 0) own = atomicAdd(cursor, (unsigned long long)wtot);
+    own = __shfl(own, 0, IVX_WAVE);
+    const bool direct_ok = own + wtot <= cap;
+#pragma unroll
+    for (int q = 0; q < RP_B; q++) {
+        if (!((okmask >> q) & 1u)) continue;
+        probe_row(S, qs[q], qe[q], [&](u32 v, bool sl) {
+            const u32 pos = __hip_atomic_fetch_add(cp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - base - wtot;
+            if (direct_ok) { ob[own + pos] = sl ? S.s_row[v] : v; op[own + pos] = rowv[q]; }
+        });
+    }
+    ring_start = base + 2 * wtot;
+    return 0u;
 }
 
-// fill pass, end of a round: ONE atomicAdd per workgroup reserves the output range of all 16 wavefronts,
-// then every wavefront copies its staged pairs out with full-width stores (all threads call this)
-__device__ __forceinline__ void round_flush(const ProbeLds &L, u32 mine, u32 round, u32 wv,
-                                            u32 *ob, u32 *op, u64 cap, unsigned long long *cursor, int dbg)
+// Fill pass, output reservation without workgroup barriers.  Wavefronts run the rounds of a workgroup
+// independently: after its batch of round r a wavefront publishes its staged count and "arrives"; the
+// wavefront that arrives LAST adds the 16 counts, reserves the round's output range with ONE global
+// atomicAdd and publishes the base with the round's tag.  Nobody waits for that: a wavefront copies the
+// pairs of round r out only after it has walked round r+1 (round_copy_out), when the base has long
+// arrived.  Every wavefront waits for round r-1's tag before it starts round r+1, so wavefronts are never
+// more than one round apart and RP_NSLOT = 4 reservation slots cannot be overwritten while still read.
+__device__ __forceinline__ void round_publish(const ProbeLds &L, u32 mine, u32 round, u32 wv, unsigned long long *cursor)
 {
-    const u32 ln = lane_id();
-    if (ln == 0) L.s_wcnt[round & 1][wv] = mine;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        u32 tot = 0;
+    if (lane_id() != 0) return;
+    const u32 sl = round % RP_NSLOT;
+    L.s_wcnt[sl][wv] = mine;
+    const u32 before = __hip_atomic_fetch_add(&L.s_arrive[sl], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (before != RP_W - 1) return;
+    u32 tot = 0;
 #pragma unroll
-        for (int w = 0; w < RP_W; w++) tot += L.s_wcnt[round & 1][w];
-        *L.s_base = tot ? atomicAdd(cursor, (unsigned long long)tot) : 0ull;
-    }
-    __syncthreads();
-    if (mine) {
-        const u64 base = *L.s_base;
-        u64 g = base;
-        u32 tot = 0;
+    for (int w = 0; w < RP_W; w++) tot += L.s_wcnt[sl][w];
+    L.s_base[sl] = tot ? atomicAdd(cursor, (unsigned long long)tot) : 0ull;
+    __hip_atomic_store(&L.s_arrive[sl], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_store(&L.s_ready[sl], round + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// wait for round `round`'s reservation, then copy this wavefront's `mine` staged pairs (ring positions
+// start, start+1, ...) to their place in the output with full-width stores
+__device__ __forceinline__ void round_copy_out(const ProbeLds &L, u32 mine, u32 start, u32 round, u32 wv,
+                                               u32 *ob, u32 *op, u64 cap, int dbg)
+{
+    const u32 sl = round % RP_NSLOT;
+    while (__hip_atomic_load(&L.s_ready[sl], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != round + 1u)
+        __builtin_amdgcn_s_sleep(1);
+    if (!mine) return;
+    const u64 base = L.s_base[sl];
+    u64 g = base;
+    u32 tot = 0;
 #pragma unroll
-        for (int w = 0; w < RP_W; w++) { const u32 c = L.s_wcnt[round & 1][w]; if (w < (int)wv) g += c; tot += c; }
-        if (base + tot <= cap && !(dbg & 16))
-            for (u32 t = ln; t < mine; t += IVX_WAVE) { ob[g + t] = L.s_qb[wv][t]; op[g + t] = L.s_qp[wv][t]; }
+    for (int w = 0; w < RP_W; w++) { const u32 c = L.s_wcnt[sl][w]; if (w < (int)wv) g += c; tot += c; }
+    if (base + tot > cap || (dbg & 16)) return;
+    for (u32 t = lane_id(); t < mine; t += IVX_WAVE) {
+        const u64 x = L.s_q[wv][(start + t) & (RP_RING - 1)];
+        ob[g + t] = (u32)x; op[g + t] = (u32)(x >> 32);
     }
 }
 
@@ -434,11 +447,14 @@ __device__ __forceinline__ void round_flush(const ProbeLds &L, u32 mine, u32 rou
     __shared__ unsigned short s_off[RP_CCAP];                                                        \
     __shared__ u64 s_ent[RP_ECAP];                                                                   \
     __shared__ u32 s_row[RP_ECAP];                                                                   \
-    __shared__ u32 s_qb[FILL ? RP_W : 1][RP_QW];                                                     \
-    __shared__ u32 s_qp[FILL ? RP_W : 1][RP_QW];                                                     \
-    __shared__ u32 s_wcnt[2][RP_W];                                                                  \
-    __shared__ unsigned long long s_base;                                                            \
-    ProbeLds L{s_off, s_ent, s_row, s_qb, s_qp, s_wcnt, &s_base};
+    __shared__ u64 s_q[FILL ? RP_W : 1][RP_RING];                                                    \
+    __shared__ u32 s_wpos[RP_W];                                                                     \
+    __shared__ u32 s_wcnt[RP_NSLOT][RP_W];                                                           \
+    __shared__ unsigned long long s_base[RP_NSLOT];                                                  \
+    __shared__ u32 s_arrive[RP_NSLOT], s_ready[RP_NSLOT];                                            \
+    if (threadIdx.x < RP_W) s_wpos[threadIdx.x] = 0;                                                 \
+    if (threadIdx.x < RP_NSLOT) { s_arrive[threadIdx.x] = 0; s_ready[threadIdx.x] = 0; }             \
+    ProbeLds L{s_off, s_ent, s_row, s_q, s_wpos, s_wcnt, s_base, s_arrive, s_ready};
 
 // ------------------------------------------------------------------ region-major probe (rows scattered by region)
 // Persistent workgroups: the partitioned probe rows are cut into equal row shares ("virtual
@@ -446,7 +462,7 @@ __device__ __forceinline__ void round_flush(const ProbeLds &L, u32 mine, u32 rou
 // wavefront w owns batches w, w+16, ... of RP_WB rows.
 //   FILL = false (ivx_probe_overlap_count): wavefronts never synchronise; one atomicAdd of the
 //           wavefront's total at the end.
-//   FILL = true : single walk, see batch_walk / round_flush.
+//   FILL = true : single walk, see batch_walk / round_publish / round_copy_out.
 template <bool FILL>
 __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const u64 *__restrict__ pse, const u32 *__restrict__ prow,
                                                         const u32 *__restrict__ offs, u32 nblk, u32 vpb,
@@ -461,11 +477,12 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
     u32 loaded_r = 0xFFFFFFFFu;                                       // region whose slice currently sits in LDS
     Slice S;
     slice_init(ix, S, L);
+    u32 round = 0;                                                    // fill pass: rounds of this workgroup so far
+    u32 pend_mine = 0, pend_start = 0;                                // the previous round's staged pairs (ring range)
     for (u32 vb = blockIdx.x * vpb; vb < (blockIdx.x + 1) * vpb; vb++) {
         u64 lo = total_rows * vb / nvb;
         const u64 hi = total_rows * (vb + 1) / nvb;
         u64 wcur = 0;                                                 // count pass: pairs seen by this wavefront
-        u32 round = 0;
         if (lo < hi) {
             u32 r;
             {   // last region whose first row is <= lo
@@ -489,7 +506,7 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
                     nx[q] = i < c_hi ? pse[i] : 0;
                     nxr[q] = (FILL && i < c_hi) ? prow[i] : 0u;
                 }
-                for (u64 r0 = lo; r0 < c_hi; r0 += (u64)RP_W * RP_WB, b0 += (u64)RP_W * RP_WB, round++) {
+                for (u64 r0 = lo; r0 < c_hi; r0 += (u64)RP_W * RP_WB, b0 += (u64)RP_W * RP_WB) {
                     i32 qs[RP_B], qe[RP_B]; u32 rowv[RP_B];
                     u32 okmask = 0;
 #pragma unroll
@@ -506,9 +523,14 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
                             nxr[q] = (FILL && i < c_hi) ? prow[i] : 0u;
                         }
                     }
-                    const u32 got = batch_walk<FILL>(S, L, qs, qe, rowv, okmask, wv, ob, op, cap, cursor, dbg);
+                    u32 start = 0;
+                    const u32 got = batch_walk<FILL>(S, L, qs, qe, rowv, okmask, wv, pend_start, start, ob, op, cap, cursor, dbg);
                     if (!FILL) { wcur += got; continue; }
-                    round_flush(L, got, round, wv, ob, op, cap, cursor, dbg);
+                    if (!(dbg & 32)) {
+                        round_publish(L, got, round, wv, cursor);
+                        if (round) round_copy_out(L, pend_mine, pend_start, round - 1, wv, ob, op, cap, dbg);
+                    }
+                    pend_mine = got; pend_start = start; round++;
                 }
                 lo = c_hi;
             }
@@ -518,230 +540,10 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
             if (ln == 0 && tot) atomicAdd(cursor, (unsigned long long)tot);
         }
     }
-}
-
-// ------------------------------------------------------------------ tile-local partition ("TLS") path
-//
-// The region-major scatter above writes every row to one of ~195 x (workgroups in flight) open streams in
-// pieces of ~40 rows, which costs DRAM page locality (k_part_scatter spends more than half of its time on
-// the stores), and it needs a histogram pass first.  Here every 10240-row tile of the probe side is
-// sorted by region INSIDE LDS and written back as one contiguous tile (full-line streaming stores, row
-// ids as 16-bit tile-local indices), plus a small region-major table of (offset, length) per (region,
-// tile).  The probe kernel then consumes, for each region, the pieces of all tiles: one piece of <= 64
-// rows per wavefront slot.  No histogram pass, 10 bytes per row written instead of 12.
-
-constexpr int TS_T = 1024;
-constexpr int TS_TILE = 10240;                    // ~52 rows per region and tile on 195 regions: one slot each, 5 % need two
-constexpr int TS_VEC = TS_TILE / 4;               // 16-byte row vectors per tile
-constexpr int TS_VPT = (TS_VEC + TS_T - 1) / TS_T;   // vectors per thread (3, the last one only for tid < 512)
-
-template <bool VEC>
-__global__ __launch_bounds__(TS_T) void k_tile_sort(JoinIndexView ix, const u32 *__restrict__ pkey, const i32 *__restrict__ ps,
-                                                    const i32 *__restrict__ pe, u64 n, u32 ntiles,
-                                                    u64 *__restrict__ tse, unsigned short *__restrict__ tidx,
-                                                    u32 *__restrict__ tp, u32 *__restrict__ tslots)
-{
-    __shared__ u64 l_se[TS_TILE];
-    __shared__ unsigned short l_idx[TS_TILE];
-    __shared__ u32 tcnt[PA_ND], dstart[PA_ND];
-    __shared__ u32 scan_lds[TS_T / IVX_WAVE + 1];
-    __shared__ i32 s_origin[KT_MAX];
-    __shared__ u32 s_last[KT_MAX], s_kreg[KT_MAX];
-    const u32 tid = threadIdx.x;
-    KeyTab kt;
-    keytab_load(ix, s_origin, s_last, s_kreg, kt);
-    for (u32 t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const u64 t0 = (u64)t * TS_TILE;
-        const u64 hi = t0 + TS_TILE < n ? t0 + TS_TILE : n;
-        if (tid < PA_ND) tcnt[tid] = 0;
-        __syncthreads();
-        u64 se[TS_VPT * 4]; u32 dig[TS_VPT * 4], lrank[TS_VPT * 4];
-#pragma unroll
-        for (int v = 0; v < TS_VPT; v++) {
-            const u32 vi = v * TS_T + tid;
-            u32 k4[4]; i32 s4[4], e4[4];
-            if (vi < TS_VEC) load4<VEC>(pkey, ps, pe, t0 + (u64)vi * 4, hi, k4, s4, e4);
-            else { for (int j = 0; j < 4; j++) { k4[j] = 0xFFFFFFFFu; s4[j] = 0; e4[j] = 0; } }
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                se[v * 4 + j] = (u64)(u32)s4[j] | ((u64)(u32)e4[j] << 32);
-                const u32 d = region_of(ix, kt, k4[j], s4[j]);
-                dig[v * 4 + j] = d;
-                lrank[v * 4 + j] = d != NO_REGION ? atomicAdd(&tcnt[d], 1u) : 0u;
-            }
-        }
-        __syncthreads();
-        u32 tot;
-        const u32 mine = tid < PA_ND ? tcnt[tid] : 0u;
-        const u32 ds = block_excl_scan<u32, TS_T>(mine, scan_lds, &tot);
-        if (tid < PA_ND) {
-            dstart[tid] = ds;
-            tp[(u64)tid * ntiles + t] = ds | (mine << 16);            // piece of region tid inside tile t
-            tslots[(u64)tid * ntiles + t] = (mine + IVX_WAVE - 1) / IVX_WAVE;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int v = 0; v < TS_VPT; v++) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const u32 d = dig[v * 4 + j];
-                if (d != NO_REGION) {
-                    const u32 pos = dstart[d] + lrank[v * 4 + j];
-                    l_se[pos] = se[v * 4 + j];
-                    l_idx[pos] = (unsigned short)((v * TS_T + tid) * 4 + j);
-                }
-            }
-        }
-        __syncthreads();
-        for (u32 j = tid; j < tot; j += TS_T) { tse[t0 + j] = l_se[j]; tidx[t0 + j] = l_idx[j]; }
-    }
-}
-
-// Probe over tile-sorted rows.  The work list is the sequence of 64-row slots of all (region, tile)
-// pieces in region-major order; `sp` is the exclusive prefix of slots per piece.  Every workgroup takes
-// an equal share of the slots; inside a region segment each wavefront owns a contiguous run of slots and
-// keeps a 64-entry window of the piece table in registers (one coalesced load), so locating a slot's
-// piece is a ballot + popcount.
-template <bool FILL>
-__global__ __launch_bounds__(RP_T) void k_probe_tls(JoinIndexView ix, const u64 *__restrict__ tse, const unsigned short *__restrict__ tidx,
-                                                    const u32 *__restrict__ tp, const u32 *__restrict__ sp, u32 ntiles, u32 vpb,
-                                                    u32 *__restrict__ ob, u32 *__restrict__ op, u64 cap,
-                                                    unsigned long long *cursor, int dbg)
-{
-    IVX_PROBE_LDS(FILL)
-    const u32 wv = threadIdx.x / IVX_WAVE, ln = lane_id();
-    const u32 nreg = ix.hdr[HDR_NREG];
-    const u32 nent = nreg * ntiles;                                   // pieces (region-major)
-    const u64 total_slots = sp[nent];
-    const u32 nvb = gridDim.x * vpb;
-    u32 loaded_r = 0xFFFFFFFFu;
-    Slice S;
-    slice_init(ix, S, L);
-    for (u32 vb = blockIdx.x * vpb; vb < (blockIdx.x + 1) * vpb; vb++) {
-        u32 lo = (u32)(total_slots * vb / nvb);
-        const u32 hi = (u32)(total_slots * (vb + 1) / nvb);
-        u64 wcur = 0;
-        u32 round = 0;
-        if (lo >= hi) continue;
-        u32 e;                                                        // piece holding slot lo: last e with sp[e] <= lo
-        {
-            u32 a = 0, b = nent;
-            while (a < b) { const u32 m = (a + b + 1) >> 1; if (sp[m] <= lo) a = m; else b = m - 1; }
-            e = a;
-        }
-        while (lo < hi) {
-            const u32 r = e / ntiles;                                 // region of the segment
-            const u32 eend = (r + 1) * ntiles;
-            const u32 seg_hi = sp[eend] < hi ? sp[eend] : hi;
-            if (seg_hi <= lo) { e = eend; continue; }
-            slice_load(ix, S, L, r, r != loaded_r);
-            loaded_r = r;
-            // contiguous run of slots per wavefront, the same number of rounds for all of them
-            const u32 seg_n = seg_hi - lo;
-            const u32 chunk = ((seg_n + RP_W - 1) / RP_W + RP_B - 1) / RP_B * RP_B;
-            const u32 rounds = chunk / RP_B;
-            const u32 ws0 = lo + wv * chunk < seg_hi ? lo + wv * chunk : seg_hi;
-            const u32 ws1 = ws0 + chunk < seg_hi ? ws0 + chunk : seg_hi;
-            // piece-table window: lane i holds sp/tp of piece wbase + i
-            u32 wbase = e;
-            if (ws0 < ws1) {
-                u32 a = e, b = eend - 1;
-                while (a < b) { const u32 m = (a + b + 1) >> 1; if (sp[m] <= ws0) a = m; else b = m - 1; }
-                wbase = a;
-            }
-            u32 spv = wbase + ln <= nent ? sp[wbase + ln] : 0xFFFFFFFFu;
-            u32 tpv = wbase + ln < nent ? tp[wbase + ln] : 0u;
-            auto locate = [&](u32 s, u32 &tile, u32 &beg, u32 &len, u32 &sub) {
-                for (;;) {
-                    const u32 c = (u32)__popcll(__ballot(spv <= s));   // pieces of the window that start at or before slot s
-                    if (c == IVX_WAVE && wbase + IVX_WAVE - 1 < eend - 1) {   // may lie beyond the window: slide it
-                        wbase += IVX_WAVE - 1;
-                        spv = wbase + ln <= nent ? sp[wbase + ln] : 0xFFFFFFFFu;
-                        tpv = wbase + ln < nent ? tp[wbase + ln] : 0u;
-                        continue;
-                    }
-                    const u32 i = __builtin_amdgcn_readfirstlane(c - 1);
-                    const u32 pv = __builtin_amdgcn_readlane(tpv, i);
-                    sub = s - __builtin_amdgcn_readlane(spv, i);
-                    tile = wbase + i - r * ntiles;
-                    beg = pv & 0xFFFFu; len = pv >> 16;
-                    return;
-                }
-            };
-            u64 nx[RP_B]; u32 nxr[RP_B]; u32 nok = 0;
-            auto issue = [&](u32 s0) {                                // loads of the RP_B slots starting at s0
-                nok = 0;
-#pragma unroll
-                for (int q = 0; q < RP_B; q++) {
-                    const u32 s = s0 + q;
-                    nx[q] = 0; nxr[q] = 0;
-                    if (s < ws1) {
-                        u32 tile, beg, len, sub;
-                        locate(s, tile, beg, len, sub);
-                        const u32 off = sub * IVX_WAVE + ln;
-                        if (off < len) {
-                            const u64 at = (u64)tile * TS_TILE + beg + off;
-                            nx[q] = tse[at];
-                            if (FILL) nxr[q] = tile * (u32)TS_TILE + tidx[at];
-                            nok |= 1u << q;
-                        }
-                    }
-                }
-            };
-            issue(ws0);
-            for (u32 rd = 0; rd < rounds; rd++, round++) {
-                i32 qs[RP_B], qe[RP_B]; u32 rowv[RP_B];
-                const u32 okmask = nok;
-#pragma unroll
-                for (int q = 0; q < RP_B; q++) { qs[q] = (i32)(u32)nx[q]; qe[q] = (i32)(u32)(nx[q] >> 32); rowv[q] = nxr[q]; }
-                issue(ws0 + (rd + 1) * RP_B);
-                const u32 got = batch_walk<FILL>(S, L, qs, qe, rowv, okmask, wv, ob, op, cap, cursor, dbg);
-                if (!FILL) { wcur += got; continue; }
-                round_flush(L, got, round, wv, ob, op, cap, cursor, dbg);
-            }
-            lo = seg_hi;
-            e = eend;
-            if (lo < hi) {                                            // next segment starts at the first piece with slots
-                u32 a = e, b = nent;
-                while (a < b) { const u32 m = (a + b + 1) >> 1; if (sp[m] <= lo) a = m; else b = m - 1; }
-                e = a;
-            }
-        }
-        if (!FILL) {
-            const u64 tot = wave_sum(wcur);
-            if (ln == 0 && tot) atomicAdd(cursor, (unsigned long long)tot);
-        }
-    }
+    if (FILL && round && !(dbg & 32)) round_copy_out(L, pend_mine, pend_start, round - 1, wv, ob, op, cap, dbg);
 }
 
 }  // namespace
-
-static ivx_status probe_tls(ivx_ctx *ctx, const JoinIndexView &jv, int mode,
-                            const u32 *key, const i32 *s, const i32 *e, u64 n,
-                            u32 *ob, u32 *op, u64 cap, u64 *d_cursor, int dbg)
-{
-    hipStream_t st = ctx->stream;
-    const u32 ntiles = (u32)((n + TS_TILE - 1) / TS_TILE);
-    const u64 nent = (u64)PA_ND * ntiles;
-    u64 *tse; unsigned short *tidx; u32 *tp, *sp;
-    IVX_TRY(ctx->get_scratch(WS_T0, (u64)ntiles * TS_TILE * sizeof(u64), (void **)&tse));
-    IVX_TRY(ctx->get_scratch(WS_T1, (u64)ntiles * TS_TILE * sizeof(unsigned short), (void **)&tidx));
-    IVX_TRY(ctx->get_scratch(WS_T2, nent * sizeof(u32), (void **)&tp));
-    IVX_TRY(ctx->get_scratch(WS_SORTHIST, (nent + 1) * sizeof(u32), (void **)&sp));
-    IVX_HIP(ctx, hipMemsetAsync(sp + nent, 0, sizeof(u32), st));
-    const bool vec = (((uintptr_t)key | (uintptr_t)s | (uintptr_t)e) & 15) == 0;
-    const u32 grid = ntiles < 256 ? ntiles : 256;                    // one workgroup per CU (LDS-bound), tiles strided
-    if (vec) hipLaunchKernelGGL(k_tile_sort<true>, dim3(grid), dim3(TS_T), 0, st, jv, key, s, e, n, ntiles, tse, tidx, tp, sp);
-    else hipLaunchKernelGGL(k_tile_sort<false>, dim3(grid), dim3(TS_T), 0, st, jv, key, s, e, n, ntiles, tse, tidx, tp, sp);
-    IVX_TRY(ivx_scan_exclusive_u32(ctx, sp, nent + 1));
-    unsigned long long *cur = (unsigned long long *)d_cursor;
-    if (mode == JP_FILL)
-        hipLaunchKernelGGL(k_probe_tls<true>, dim3(RP_GRID), dim3(RP_T), 0, st, jv, (const u64 *)tse, (const unsigned short *)tidx, (const u32 *)tp, (const u32 *)sp, ntiles, RP_VGRID / RP_GRID, ob, op, cap, cur, dbg);
-    else
-        hipLaunchKernelGGL(k_probe_tls<false>, dim3(RP_VGRID), dim3(RP_T), 0, st, jv, (const u64 *)tse, (const unsigned short *)tidx, (const u32 *)tp, (const u32 *)sp, ntiles, 1u, ob, op, cap, cur, dbg);
-    IVX_HIP(ctx, hipGetLastError());
-    return IVX_OK;
-}
 
 ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, int mode,
                                   const u32 *key, const i32 *s, const i32 *e, u64 n,
@@ -749,10 +551,6 @@ ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, int mod
 {
     if (n == 0) return IVX_OK;
     hipStream_t st = ctx->stream;
-    {
-        const char *f = getenv("IVX_JOIN_TLS");
-        if (f && atoi(f)) return probe_tls(ctx, jv, mode, key, s, e, n, ob, op, cap, d_cursor, getenv("IVX_DBG") ? atoi(getenv("IVX_DBG")) : 0);
-    }
     const u32 nblk = (u32)((n + PA_CHUNK - 1) / PA_CHUNK);
     u32 *hist; u64 *pse; u32 *prow;
     const u64 nh = (u64)256 * nblk + 1;

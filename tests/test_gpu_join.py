@@ -28,16 +28,15 @@ def _check_join(ctx, bk, bs, be, pk, ps, pe, nkeys):
     assert total == len(want_b)
     assert (per_row.astype(np.uint64) == want_cnt).all()
     # both probe paths: gathers straight from the index, and region-partitioned through LDS
-    for path, tls in (("direct", "0"), ("regions", "0"), ("regions", "1")):
+    for path in ("direct", "regions"):
         os.environ["IVX_JOIN_PATH"] = path
-        os.environ["IVX_JOIN_TLS"] = tls              # regions: region-major scatter (0) or tile-local sort (1)
         try:
-            assert ctx.overlap_count(ix, pk, ps, pe) == total, (path, tls)
+            assert ctx.overlap_count(ix, pk, ps, pe) == total, path
             ob, op = ctx.overlap_fill(ix, pk, ps, pe, cap=total)
         finally:
-            del os.environ["IVX_JOIN_PATH"], os.environ["IVX_JOIN_TLS"]
-        assert len(ob) == total, (path, tls)
-        assert (pair_set(ob, op) == pair_set(want_b, want_p)).all(), (path, tls)
+            del os.environ["IVX_JOIN_PATH"]
+        assert len(ob) == total, path
+        assert (pair_set(ob, op) == pair_set(want_b, want_p)).all(), path
     ex = ctx.exists(ix, pk, ps, pe)
     assert (ex == (want_cnt > 0)).all()
     ix.free()
@@ -124,6 +123,18 @@ def test_join_regions_dense_slices_fall_back(ctx):
     ps = rng.integers(0, 2_000_000, 400_000).astype(np.int32); pe = ps + 50
     z = np.zeros
     _check_join(ctx, z(len(bs), np.uint32), bs, be, z(len(ps), np.uint32), ps, pe, 1)
+
+
+def test_join_regions_staging_ring_overflow(ctx):
+    # long probe rows: a wavefront batch yields several thousand pairs, far more than its LDS staging ring
+    # holds, so those batches reserve their output directly; short rows after them use the ring again
+    rng = np.random.default_rng(17)
+    nb = 20_000
+    bs = rng.integers(0, 20_000_000, nb).astype(np.int32); be = bs + rng.integers(0, 400, nb).astype(np.int32)
+    ps = rng.integers(0, 20_000_000, 300_000).astype(np.int32)
+    pe = ps + np.where(np.arange(len(ps)) < 150_000, 6000, 50).astype(np.int32)
+    z = np.zeros
+    _check_join(ctx, z(nb, np.uint32), bs, be, z(len(ps), np.uint32), ps, pe, 1)
 
 
 def test_capacity_error(ctx):

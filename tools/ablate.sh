@@ -1,0 +1,7 @@
+#!/bin/bash
+# ablation of the fill probe inside ONE session: tools/ablate.sh "0 16 4 20" [env...]
+BITS=$1; shift
+for b in $BITS; do
+  echo "== IVX_DBG=$b"
+  tools/prof_stats.sh abl_$b IVX_DBG=$b "$@" 2>&1 | grep -E "k_part|k_probe"
+done
