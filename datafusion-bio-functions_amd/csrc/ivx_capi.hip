@@ -359,6 +359,12 @@ ivx_status ivx_merge_device(ivx_ctx *ctx, const u32 *key, const i64 *s, const i6
 ivx_status ivx_subtract_device(ivx_ctx *ctx, const u32 *lkey, const i64 *ls, const i64 *le, u64 nl,
                                const u32 *rkey, const i64 *rs, const i64 *re, u64 nr, u32 nkeys, int strict,
                                u32 *ok, i64 *os, i64 *oe, u32 *orow, u64 cap, u64 *n_out);
+ivx_status ivx_cluster_device(ivx_ctx *ctx, const u32 *key, const i64 *s, const i64 *e, u64 n, u32 nkeys,
+                              i64 min_dist, int strict, const i64 *key_base,
+                              u32 *ok, i64 *os, i64 *oe, u32 *orow, i64 *oc, i64 *ocs, i64 *oce, u64 *key_clusters, u64 *m);
+ivx_status ivx_complement_device(ivx_ctx *ctx, const u32 *key, const i64 *s, const i64 *e, u64 n,
+                                 const u32 *vkey, const i64 *vs, const i64 *ve, u64 nv, u32 nkeys, int strict,
+                                 u32 *ok, i64 *os, i64 *oe, u64 cap, u64 *n_out);
 
 static ivx_status per_row_i64(ivx_ctx *ctx, const ivx_index *ix, int kind, int mem, const u32 *key, const i32 *start,
                               const i32 *end, u64 n, int strict, i64 *out)
@@ -499,6 +505,92 @@ extern "C" ivx_status ivx_subtract(ivx_ctx *ctx, int mem,
         IVX_TRY(copy_out(ctx, mem, out_start, os, m));
         IVX_TRY(copy_out(ctx, mem, out_end, oe, m));
         IVX_TRY(copy_out(ctx, mem, out_row, orow, m));
+    }
+    if (mem == IVX_MEM_HOST) IVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return IVX_OK;
+}
+
+extern "C" ivx_status ivx_cluster(ivx_ctx *ctx, int mem, const uint32_t *key, const int64_t *start, const int64_t *end, uint64_t n,
+                                  uint32_t n_keys, int64_t min_dist, int strict, const int64_t *key_base,
+                                  uint32_t *out_key, int64_t *out_start, int64_t *out_end, uint32_t *out_row,
+                                  int64_t *out_cluster, int64_t *out_cluster_start, int64_t *out_cluster_end,
+                                  uint64_t *key_clusters, uint64_t *n_clusters)
+{
+    if (!ctx) return IVX_ERR_INVALID;
+    if (!n_clusters) return ctx->fail(IVX_ERR_INVALID, "null n_clusters");
+    *n_clusters = 0;
+    if (mem != IVX_MEM_HOST && mem != IVX_MEM_DEVICE) return ctx->fail(IVX_ERR_INVALID, "bad mem");
+    if (n && (!start || !end)) return ctx->fail(IVX_ERR_INVALID, "null coordinate column");
+    if (min_dist < 0) return ctx->fail(IVX_ERR_INVALID, "cluster() min_dist must be >= 0, got " + std::to_string(min_dist));   // table_function.rs:237
+    if (n >= 0xFFFFFFFFull) return ctx->fail(IVX_ERR_INVALID, "cluster: more than 2^32-1 rows in one call");
+    if (!key || n_keys == 0) n_keys = 1;
+    IVX_HIP(ctx, hipSetDevice(ctx->device));
+    const u32 *dk; const i64 *ds, *de, *dbase; u32 *ok, *orow; i64 *os, *oe, *oc, *ocs, *oce; u64 *okc;
+    IVX_TRY(stage_in(ctx, mem, WS_IN_KEY, key, n, &dk));
+    IVX_TRY(stage_in(ctx, mem, WS_IN_START, start, n, &ds));
+    IVX_TRY(stage_in(ctx, mem, WS_IN_END, end, n, &de));
+    IVX_TRY(stage_in(ctx, mem, WS_IN2_KEY, key_base, (u64)n_keys, &dbase));
+    IVX_TRY(stage_out(ctx, mem, WS_OUT_A, out_key, n, &ok));
+    IVX_TRY(stage_out(ctx, mem, WS_OUT_B, out_start, n, &os));
+    IVX_TRY(stage_out(ctx, mem, WS_OUT_C, out_end, n, &oe));
+    IVX_TRY(stage_out(ctx, mem, WS_OUT_D, out_row, n, &orow));
+    IVX_TRY(stage_out(ctx, mem, WS_OUT_E, out_cluster, n, &oc));
+    IVX_TRY(stage_out(ctx, mem, WS_OUT_F, out_cluster_start, n, &ocs));
+    IVX_TRY(stage_out(ctx, mem, WS_OUT_G, out_cluster_end, n, &oce));
+    IVX_TRY(stage_out(ctx, mem, WS_OUT_H, key_clusters, (u64)n_keys, &okc));
+    u64 m = 0;
+    {
+        KernelTimer t(ctx);
+        IVX_TRY(ivx_cluster_device(ctx, dk, ds, de, n, n_keys, min_dist, strict, dbase, ok, os, oe, orow, oc, ocs, oce, okc, &m));
+    }
+    *n_clusters = m;
+    IVX_TRY(copy_out(ctx, mem, out_key, ok, n));
+    IVX_TRY(copy_out(ctx, mem, out_start, os, n));
+    IVX_TRY(copy_out(ctx, mem, out_end, oe, n));
+    IVX_TRY(copy_out(ctx, mem, out_row, orow, n));
+    IVX_TRY(copy_out(ctx, mem, out_cluster, oc, n));
+    IVX_TRY(copy_out(ctx, mem, out_cluster_start, ocs, n));
+    IVX_TRY(copy_out(ctx, mem, out_cluster_end, oce, n));
+    IVX_TRY(copy_out(ctx, mem, key_clusters, okc, (u64)n_keys));
+    if (mem == IVX_MEM_HOST) IVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return IVX_OK;
+}
+
+extern "C" ivx_status ivx_complement(ivx_ctx *ctx, int mem, const uint32_t *key, const int64_t *start, const int64_t *end, uint64_t n,
+                                     const uint32_t *vkey, const int64_t *vstart, const int64_t *vend, uint64_t nv,
+                                     uint32_t n_keys, int strict, uint32_t *out_key, int64_t *out_start, int64_t *out_end,
+                                     uint64_t cap, uint64_t *n_out)
+{
+    if (!ctx) return IVX_ERR_INVALID;
+    if (!n_out) return ctx->fail(IVX_ERR_INVALID, "null n_out");
+    *n_out = 0;
+    if (mem != IVX_MEM_HOST && mem != IVX_MEM_DEVICE) return ctx->fail(IVX_ERR_INVALID, "bad mem");
+    if ((n && (!start || !end)) || (nv && (!vstart || !vend))) return ctx->fail(IVX_ERR_INVALID, "null coordinate column");
+    if (n >= 0xFFFFFFFFull || nv >= 0xFFFFFFFFull) return ctx->fail(IVX_ERR_INVALID, "complement: more than 2^32-1 rows in one call");
+    if ((key == nullptr) != (vkey == nullptr) && n && nv) return ctx->fail(IVX_ERR_INVALID, "complement: key given for one side only");
+    if (n_keys == 0 || (!key && !vkey)) n_keys = 1;
+    IVX_HIP(ctx, hipSetDevice(ctx->device));
+    const u32 *dk, *dvk; const i64 *ds, *de, *dvs, *dve; u32 *ok; i64 *os, *oe;
+    IVX_TRY(stage_in(ctx, mem, WS_IN_KEY, key, n, &dk));
+    IVX_TRY(stage_in(ctx, mem, WS_IN_START, start, n, &ds));
+    IVX_TRY(stage_in(ctx, mem, WS_IN_END, end, n, &de));
+    IVX_TRY(stage_in(ctx, mem, WS_IN2_KEY, vkey, nv, &dvk));
+    IVX_TRY(stage_in(ctx, mem, WS_IN2_START, vstart, nv, &dvs));
+    IVX_TRY(stage_in(ctx, mem, WS_IN2_END, vend, nv, &dve));
+    IVX_TRY(stage_out(ctx, mem, WS_OUT_A, out_key, cap, &ok));
+    IVX_TRY(stage_out(ctx, mem, WS_OUT_B, out_start, cap, &os));
+    IVX_TRY(stage_out(ctx, mem, WS_OUT_C, out_end, cap, &oe));
+    u64 m = 0;
+    {
+        KernelTimer t(ctx);
+        ivx_status st = ivx_complement_device(ctx, dk, ds, de, n, dvk, dvs, dve, nv, n_keys, strict, ok, os, oe, cap, &m);
+        *n_out = m;
+        if (st != IVX_OK) return st;
+    }
+    if (cap) {
+        IVX_TRY(copy_out(ctx, mem, out_key, ok, m));
+        IVX_TRY(copy_out(ctx, mem, out_start, os, m));
+        IVX_TRY(copy_out(ctx, mem, out_end, oe, m));
     }
     if (mem == IVX_MEM_HOST) IVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return IVX_OK;

@@ -17,7 +17,7 @@ typedef int64_t i64;
 // ---------------------------------------------------------------- context
 struct ivx_buf { void *p = nullptr; size_t cap = 0; };
 
-enum { IVX_NSCRATCH = 48, IVX_NPIN = 4 };
+enum { IVX_NSCRATCH = 56, IVX_NPIN = 4 };
 
 struct ivx_ctx {
     int device = 0;
@@ -57,7 +57,7 @@ struct ivx_ctx {
 // scratch slot ids (one per concurrent use inside a call)
 enum {
     WS_IN_KEY = 0, WS_IN_START, WS_IN_END, WS_IN2_KEY, WS_IN2_START, WS_IN2_END,   // staged host inputs
-    WS_OUT_A, WS_OUT_B, WS_OUT_C, WS_OUT_D,                                         // staged host outputs
+    WS_OUT_A, WS_OUT_B, WS_OUT_C, WS_OUT_D, WS_OUT_E, WS_OUT_F, WS_OUT_G, WS_OUT_H,     // staged host outputs
     WS_SCAN0, WS_SCAN1, WS_SCAN2,                                                   // scan partials
     WS_GRID0, WS_GRID1, WS_GRID2,                                                   // key stats + cell cursors
     WS_SORTHIST,                                                                    // radix-sort histograms

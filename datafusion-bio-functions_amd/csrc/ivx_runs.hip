@@ -115,11 +115,10 @@ __global__ __launch_bounds__(RT) void k_emit_runs(const u32 *__restrict__ ks, co
 
 }  // namespace
 
-ivx_status ivx_merge_runs(ivx_ctx *ctx, const u32 *ks, const i64 *ss, const i64 *es, u64 n,
-                          i64 min_dist, int strict, const ivx_runs_out &out, u64 *m)
+// states -> scan -> heads -> scan -> runs; leaves st / ha (n entries each) in WS_T5 / WS_T6
+static ivx_status sweep(ivx_ctx *ctx, const u32 *ks, const i64 *ss, const i64 *es, u64 n,
+                        i64 min_dist, int strict, const ivx_runs_out &out, const MState **st_out, const HeadAcc **ha_out, u64 *m)
 {
-    *m = 0;
-    if (n == 0) return IVX_OK;
     hipStream_t stq = ctx->stream;
     MState *st; HeadAcc *ha;
     IVX_TRY(ctx->get_scratch(WS_T5, n * sizeof(MState), (void **)&st));
@@ -133,7 +132,86 @@ ivx_status ivx_merge_runs(ivx_ctx *ctx, const u32 *ks, const i64 *ss, const i64 
     hipLaunchKernelGGL(k_emit_runs, dim3(grid), dim3(RT), 0, stq, ks, ss, (const MState *)st, (const HeadAcc *)ha, n, out, d_m);
     IVX_HIP(ctx, hipGetLastError());
     IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 2, d_m, sizeof(u64), hipMemcpyDeviceToHost, stq));
-    IVX_HIP(ctx, hipStreamSynchronize(stq));
+    *st_out = st; *ha_out = ha;
+    (void)m;
+    return IVX_OK;
+}
+
+ivx_status ivx_merge_runs(ivx_ctx *ctx, const u32 *ks, const i64 *ss, const i64 *es, u64 n,
+                          i64 min_dist, int strict, const ivx_runs_out &out, u64 *m)
+{
+    *m = 0;
+    if (n == 0) return IVX_OK;
+    const MState *st; const HeadAcc *ha;
+    IVX_TRY(sweep(ctx, ks, ss, es, n, min_dist, strict, out, &st, &ha, m));
+    IVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *m = ctx->h_scalars[2];
+    return IVX_OK;
+}
+
+namespace {
+
+// kfirst[k] = runs before key k's first run, klast[k] = runs up to and including its last one
+__global__ __launch_bounds__(RT) void k_key_runs(const u32 *__restrict__ ks, const HeadAcc *__restrict__ ha, u64 n, u32 nkeys,
+                                                 u32 *kfirst, u32 *klast)
+{
+    const u64 i = (u64)blockIdx.x * RT + threadIdx.x;
+    if (i >= n) return;
+    const u32 k = ks[i];
+    if (k >= nkeys) return;                                   // reported by the sort's key check
+    if (i == 0 || ks[i - 1] != k) kfirst[k] = ha[i].heads - 1;
+    if (i + 1 == n || ks[i + 1] != k) klast[k] = ha[i].heads;
+}
+
+__global__ __launch_bounds__(RT) void k_key_clusters(const u32 *__restrict__ kfirst, const u32 *__restrict__ klast, u32 nkeys, u64 *out)
+{
+    const u32 k = blockIdx.x * RT + threadIdx.x;
+    if (k < nkeys) out[k] = (u64)(klast[k] - kfirst[k]);
+}
+
+__global__ __launch_bounds__(RT) void k_cluster_rows(const u32 *__restrict__ ks, const i64 *__restrict__ ss, const HeadAcc *__restrict__ ha,
+                                                     const i64 *__restrict__ run_end, u64 n, u32 nkeys,
+                                                     const u32 *__restrict__ kfirst, const i64 *__restrict__ key_base, ivx_cluster_out out)
+{
+    const u64 i = (u64)blockIdx.x * RT + threadIdx.x;
+    if (i >= n) return;
+    const HeadAcc h = ha[i];
+    const u32 rid = h.heads - 1;
+    if (out.cluster) {
+        const u32 k = ks[i];
+        out.cluster[i] = (key_base && k < nkeys) ? key_base[k] + (i64)(rid - kfirst[k]) : (i64)rid;
+    }
+    if (out.start) out.start[i] = ss[h.last_head];
+    if (out.end) out.end[i] = run_end[rid];
+}
+
+}  // namespace
+
+ivx_status ivx_cluster_rows(ivx_ctx *ctx, const u32 *ks, const i64 *ss, const i64 *es, u64 n, u32 nkeys,
+                            i64 min_dist, int strict, const i64 *key_base, const ivx_cluster_out &out, u64 *m)
+{
+    *m = 0;
+    hipStream_t stq = ctx->stream;
+    u32 *kfirst, *klast;
+    IVX_TRY(ctx->get_scratch(WS_T8, (size_t)nkeys * sizeof(u32), (void **)&kfirst));
+    IVX_TRY(ctx->get_scratch(WS_T9, (size_t)nkeys * sizeof(u32), (void **)&klast));
+    IVX_HIP(ctx, hipMemsetAsync(kfirst, 0, (size_t)nkeys * sizeof(u32), stq));
+    IVX_HIP(ctx, hipMemsetAsync(klast, 0, (size_t)nkeys * sizeof(u32), stq));
+    if (n) {
+        i64 *run_end;
+        IVX_TRY(ctx->get_scratch(WS_T7, n * sizeof(i64), (void **)&run_end));
+        const MState *st; const HeadAcc *ha;
+        const ivx_runs_out ro{nullptr, nullptr, run_end, nullptr};
+        IVX_TRY(sweep(ctx, ks, ss, es, n, min_dist, strict, ro, &st, &ha, m));
+        const u32 grid = (u32)((n + RT - 1) / RT);
+        hipLaunchKernelGGL(k_key_runs, dim3(grid), dim3(RT), 0, stq, ks, ha, n, nkeys, kfirst, klast);
+        hipLaunchKernelGGL(k_cluster_rows, dim3(grid), dim3(RT), 0, stq, ks, ss, ha, (const i64 *)run_end, n, nkeys,
+                           (const u32 *)kfirst, key_base, out);
+    }
+    if (out.key_clusters)
+        hipLaunchKernelGGL(k_key_clusters, dim3((nkeys + RT - 1) / RT), dim3(RT), 0, stq, (const u32 *)kfirst, (const u32 *)klast, nkeys, out.key_clusters);
+    IVX_HIP(ctx, hipGetLastError());
+    IVX_HIP(ctx, hipStreamSynchronize(stq));
+    *m = n ? ctx->h_scalars[2] : 0;
     return IVX_OK;
 }

@@ -25,3 +25,12 @@ struct ivx_runs_out {
 // Uses scratch WS_T5..WS_T7 and WS_SCAN*.
 ivx_status ivx_merge_runs(ivx_ctx *ctx, const u32 *ks, const i64 *ss, const i64 *es, u64 n,
                           i64 min_dist, int strict, const ivx_runs_out &out, u64 *m);
+
+// cluster(): the same sweep, but every sorted row gets the id and the extent of its run
+// (cluster.rs:598-661).  Ids count runs in order from 0, or from key_base[key] for the first run
+// of each key when key_base is given ([nkeys], device; ClusterIdCoordinator offsets,
+// cluster.rs:396-417).  key_clusters (nullable, [nkeys], device) receives the runs per key.
+// Uses scratch WS_T5..WS_T9.
+struct ivx_cluster_out { i64 *cluster; i64 *start; i64 *end; u64 *key_clusters; };
+ivx_status ivx_cluster_rows(ivx_ctx *ctx, const u32 *ks, const i64 *ss, const i64 *es, u64 n, u32 nkeys,
+                            i64 min_dist, int strict, const i64 *key_base, const ivx_cluster_out &out, u64 *m);

@@ -5,6 +5,9 @@
 //   a8 MergeStream sweep (merge.rs:282-350)       -> two scans (ivx_runs.hpp)
 //   a9 SubtractStream sweep (subtract.rs:390-462, :575-655) -> per-left-row binary searches over
 //      the right side's "gap heads" + count/scan/fill.
+//   f1 cluster (cluster.rs:443-477, :598-661)     -> the merge scans + one per-row pass (ivx_runs.hpp)
+//   f2 complement (complement.rs:297-357, :394-465) -> merge, then per view interval two binary
+//      searches over the merged runs + count/scan/fill by output row (see the complement section).
 //
 // subtract without the serial cursor.  For one left row [ls,le) the reference
 // walks the rights of the contig in (start,end) order with cursor = ls:
@@ -227,6 +230,163 @@ ivx_status keyflag(ivx_ctx *ctx, const char *what)
     return IVX_OK;
 }
 
+// ---------------------------------------------------------------- complement
+//
+// For one view interval [vs,ve) the reference walks the merged runs of the contig with cursor = vs:
+// runs with me <= vs are skipped, the walk stops at the first ms >= ve, a run emits [cursor, max(ms,vs))
+// if that is non-empty and sets cursor = min(me,ve); finally [cursor, ve) if cursor < ve
+// (complement.rs:320-356).  Merged runs satisfy ms[j] > me[j-1] (strict: >=), and for well-formed
+// input me ascends too, so the runs a view touches are the contiguous range
+//     a = first run with me > vs,   b = first run with ms >= ve        (two binary searches)
+// and its output is: a head [vs, ms[a]) if ms[a] > vs, the non-empty gaps [me[j-1], ms[j]) for
+// a < j < b -- a property of the merged list alone, counted with a prefix sum G -- and a tail
+// [min(me[b-1],ve), ve).  Output rows are then filled one thread per ROW (binary search for the view),
+// so one chromosome-wide view is as parallel as a million small ones.  If the merged ends do not
+// ascend (input rows with end < start), every view walks its contig serially instead: same answers as
+// the reference for any input, speed only matters for sane data.
+
+__global__ __launch_bounds__(ST) void k_mark_keys(const u32 *__restrict__ key, u64 n, u32 nkeys, u32 *flag, u32 *bad)
+{
+    const u64 i = (u64)blockIdx.x * ST + threadIdx.x;
+    if (i >= n) return;
+    const u32 k = key ? key[i] : 0u;
+    if (k >= nkeys) { *bad = 1; return; }
+    flag[k] = 1;
+}
+
+// need[k] = key has input rows but no view row: gets the implicit view [0, i64::MAX) (complement.rs:401-403)
+__global__ __launch_bounds__(ST) void k_need_implicit(const u32 *__restrict__ has_in, const u32 *__restrict__ has_view, u32 nkeys, u32 *need)
+{
+    const u32 k = blockIdx.x * ST + threadIdx.x;
+    if (k > nkeys) return;
+    need[k] = (k < nkeys && has_in[k] && !has_view[k]) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(ST) void k_views_gather(const u32 *__restrict__ vkey, const i64 *__restrict__ vs, const i64 *__restrict__ ve, u64 nv,
+                                                     const u32 *__restrict__ has_in, const u32 *__restrict__ has_view, const u32 *__restrict__ ioff,
+                                                     u32 nkeys, u32 *wk, i64 *ws, i64 *we)
+{
+    const u64 i = (u64)blockIdx.x * ST + threadIdx.x;
+    if (i < nv) { wk[i] = vkey ? vkey[i] : 0u; ws[i] = vs[i]; we[i] = ve[i]; }
+    if (i < nkeys && has_in[i] && !has_view[i]) { const u64 at = nv + ioff[i]; wk[at] = (u32)i; ws[at] = 0; we[at] = INT64_MAX; }
+}
+
+// per merged run: gap flag (a non-empty gap in front of it inside its key) and the regularity check
+__global__ __launch_bounds__(ST) void k_run_gaps(const u32 *__restrict__ mk, const i64 *__restrict__ ms, const i64 *__restrict__ me, u64 m,
+                                                 u32 *gflag, u32 *irregular)
+{
+    const u64 j = (u64)blockIdx.x * ST + threadIdx.x;
+    if (j > m) return;
+    if (j == m) { gflag[j] = 0; return; }
+    const bool same = j > 0 && mk[j] == mk[j - 1];
+    gflag[j] = (same && ms[j] > me[j - 1]) ? 1u : 0u;
+    if (same && me[j] < me[j - 1]) *irregular = 1;
+}
+
+__global__ __launch_bounds__(ST) void k_gap_index(const u32 *__restrict__ G, u64 m, u32 *cg)
+{
+    const u64 j = (u64)blockIdx.x * ST + threadIdx.x;
+    if (j < m && G[j + 1] != G[j]) cg[G[j]] = (u32)j;
+}
+
+__global__ __launch_bounds__(ST) void k_view_flags(const u32 *__restrict__ wk, u64 nw, const u32 *__restrict__ has_in, u32 *f)
+{
+    const u64 i = (u64)blockIdx.x * ST + threadIdx.x;
+    if (i > nw) return;
+    f[i] = (i < nw && has_in[wk[i]]) ? 1u : 0u;
+}
+
+struct CompRuns { const u32 *mk; const i64 *ms, *me; u32 m; const u32 *G; const u32 *cg; };
+
+// the reference's loop for one view, verbatim; emit(start,end) per output row; returns the row count
+template <class F>
+__device__ __forceinline__ u64 view_walk_serial(const CompRuns &R, u32 k, i64 vs, i64 ve, F &&emit)
+{
+    const u32 lo = lex_rank(R.mk, R.ms, R.m, k, INT64_MIN, false), hi = lex_rank(R.mk, R.ms, R.m, k, INT64_MAX, true);
+    u64 rows = 0;
+    i64 cursor = vs;
+    for (u32 j = lo; j < hi; j++) {
+        if (R.me[j] <= vs) continue;
+        if (R.ms[j] >= ve) break;
+        const i64 is = R.ms[j] > vs ? R.ms[j] : vs, ie = R.me[j] < ve ? R.me[j] : ve;
+        if (is > cursor) { emit(rows, cursor, is); rows++; }
+        cursor = ie;
+    }
+    if (cursor < ve) { emit(rows, cursor, ve); rows++; }
+    return rows;
+}
+
+// count pass: one thread per view (sorted order i); results stored at the view's OUTPUT position:
+// views of keys with input rows first, then view-only keys (complement.rs:431-456), both in (key,start,end) order
+__global__ __launch_bounds__(ST) void k_comp_count(const u32 *__restrict__ wk, const i64 *__restrict__ ws, const i64 *__restrict__ we, u64 nw,
+                                                   const u32 *__restrict__ has_in, const u32 *__restrict__ A, CompRuns R, int irregular,
+                                                   u64 *cnt, u32 *inv, u32 *pa, u32 *pb)
+{
+    const u64 i = (u64)blockIdx.x * ST + threadIdx.x;
+    if (i > nw) return;
+    if (i == nw) { cnt[nw] = 0; return; }
+    const u32 k = wk[i];
+    const bool in = has_in[k] != 0;
+    const u32 totalA = A[nw];
+    const u32 pos = in ? A[i] : totalA + ((u32)i - A[i]);
+    inv[pos] = (u32)i;
+    const i64 vs = ws[i], ve = we[i];
+    u64 c; u32 a = 0, b = 0;
+    if (!in) c = 1;                                                     // the whole view, as it is
+    else if (irregular) c = view_walk_serial(R, k, vs, ve, [](u64, i64, i64) {});
+    else {
+        a = lex_rank(R.mk, R.me, R.m, k, vs, true);                     // first run with me > vs
+        b = lex_rank(R.mk, R.ms, R.m, k, ve, false);                    // first run with ms >= ve
+        if (a >= b) { b = a; c = vs < ve ? 1 : 0; }
+        else c = (R.ms[a] > vs ? 1u : 0u) + (u64)(R.G[b] - R.G[a + 1]) + (R.me[b - 1] < ve ? 1u : 0u);
+    }
+    cnt[pos] = c; pa[pos] = a; pb[pos] = b;
+}
+
+__global__ __launch_bounds__(ST) void k_comp_fill_rows(const u32 *__restrict__ wk, const i64 *__restrict__ ws, const i64 *__restrict__ we, u32 nw,
+                                                       const u32 *__restrict__ has_in, CompRuns R, const u64 *__restrict__ offs,
+                                                       const u32 *__restrict__ inv, const u32 *__restrict__ pa, const u32 *__restrict__ pb,
+                                                       u64 total, u32 *ok, i64 *os, i64 *oe)
+{
+    const u64 o = (u64)blockIdx.x * ST + threadIdx.x;
+    if (o >= total) return;
+    u32 lo = 0, hi = nw;                                               // last view position with offs <= o
+    while (lo < hi) { const u32 mid = lo + ((hi - lo) >> 1); if (offs[mid] <= o) lo = mid + 1; else hi = mid; }
+    const u32 pos = lo - 1, i = inv[pos];
+    const u32 k = wk[i];
+    const i64 vs = ws[i], ve = we[i];
+    i64 s0, e0;
+    if (!has_in[k]) { s0 = vs; e0 = ve; }
+    else {
+        const u32 a = pa[pos], b = pb[pos];
+        u64 r = o - offs[pos];
+        if (a >= b) { s0 = vs; e0 = ve; }
+        else {
+            const u32 head = R.ms[a] > vs ? 1u : 0u;
+            const u32 inter = R.G[b] - R.G[a + 1];
+            if (head && r == 0) { s0 = vs; e0 = R.ms[a]; }
+            else if (r - head < inter) { const u32 j = R.cg[R.G[a + 1] + (u32)(r - head)]; s0 = R.me[j - 1]; e0 = R.ms[j]; }
+            else { s0 = R.me[b - 1]; e0 = ve; }                          // me[b-1] < ve here
+        }
+    }
+    if (ok) ok[o] = k;
+    if (os) os[o] = s0;
+    if (oe) oe[o] = e0;
+}
+
+__global__ __launch_bounds__(ST) void k_comp_fill_serial(const u32 *__restrict__ wk, const i64 *__restrict__ ws, const i64 *__restrict__ we, u32 nw,
+                                                         const u32 *__restrict__ has_in, CompRuns R, const u64 *__restrict__ offs,
+                                                         const u32 *__restrict__ inv, u32 *ok, i64 *os, i64 *oe)
+{
+    const u32 pos = blockIdx.x * ST + threadIdx.x;
+    if (pos >= nw) return;
+    const u32 i = inv[pos], k = wk[i];
+    const u64 at = offs[pos];
+    auto put = [&](u64 r, i64 a, i64 b) { if (ok) ok[at + r] = k; if (os) os[at + r] = a; if (oe) oe[at + r] = b; };
+    if (!has_in[k]) put(0, ws[i], we[i]);
+    else view_walk_serial(R, k, ws[i], we[i], put);
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------ device entry points
@@ -304,6 +464,118 @@ ivx_status ivx_subtract_device(ivx_ctx *ctx, const u32 *lkey, const i64 *ls, con
     hipLaunchKernelGGL(k_sub_fill, dim3(grid1(nl)), dim3(ST), 0, st, (const u32 *)lk, (const i64 *)lsv, (const i64 *)lev, (const u32 *)lrow, nl, strict,
                        (const u32 *)hk, (const i64 *)hrs, (const i64 *)hpm, (const u32 *)hj, (u32)nh, (const u32 *)rk, (const i64 *)rsv, (const SegMax64 *)sm, (u32)nr,
                        (const u64 *)cnt, cap, ok, os, oe, orow);
+    IVX_HIP(ctx, hipGetLastError());
+    return IVX_OK;
+}
+
+ivx_status ivx_cluster_device(ivx_ctx *ctx, const u32 *key, const i64 *s, const i64 *e, u64 n, u32 nkeys,
+                              i64 min_dist, int strict, const i64 *key_base,
+                              u32 *ok, i64 *os, i64 *oe, u32 *orow, i64 *oc, i64 *ocs, i64 *oce, u64 *key_clusters, u64 *m)
+{
+    *m = 0;
+    IVX_HIP(ctx, hipMemsetAsync(ctx->d_scalars + 8, 0, sizeof(u64), ctx->stream));
+    // the sorted rows ARE output columns; scratch only for the ones the caller did not ask for
+    u32 *ks = ok, *rows = orow; i64 *ss = os, *es = oe;
+    if (n) {
+        if (!ks) IVX_TRY(ctx->get_scratch(WS_T0, n * sizeof(u32), (void **)&ks));
+        if (!ss) IVX_TRY(ctx->get_scratch(WS_T1, n * sizeof(i64), (void **)&ss));
+        if (!es) IVX_TRY(ctx->get_scratch(WS_T2, n * sizeof(i64), (void **)&es));
+        IVX_TRY(sort64(ctx, WS_SA0, WS_SB0, key, s, e, n, nkeys, ks, ss, es, rows));
+    }
+    const ivx_cluster_out co{oc, ocs, oce, key_clusters};
+    IVX_TRY(ivx_cluster_rows(ctx, ks, ss, es, n, nkeys, min_dist, strict, key_base, co, m));
+    return keyflag(ctx, "cluster: key id >= n_keys");
+}
+
+ivx_status ivx_complement_device(ivx_ctx *ctx, const u32 *key, const i64 *s, const i64 *e, u64 n,
+                                 const u32 *vkey, const i64 *vs, const i64 *ve, u64 nv, u32 nkeys, int strict,
+                                 u32 *ok, i64 *os, i64 *oe, u64 cap, u64 *n_out)
+{
+    *n_out = 0;
+    hipStream_t st = ctx->stream;
+    IVX_HIP(ctx, hipMemsetAsync(ctx->d_scalars + 8, 0, 2 * sizeof(u64), st));
+    u32 *bad = (u32 *)(ctx->d_scalars + 8), *irregular = (u32 *)(ctx->d_scalars + 9);
+
+    // which keys have input rows / view rows; implicit views for input keys without one
+    u32 *has_in, *has_view, *need;
+    IVX_TRY(ctx->get_scratch(WS_GRID0, (size_t)nkeys * sizeof(u32), (void **)&has_in));
+    IVX_TRY(ctx->get_scratch(WS_GRID1, (size_t)nkeys * sizeof(u32), (void **)&has_view));
+    IVX_TRY(ctx->get_scratch(WS_GRID2, ((size_t)nkeys + 1) * sizeof(u32), (void **)&need));
+    IVX_HIP(ctx, hipMemsetAsync(has_in, 0, (size_t)nkeys * sizeof(u32), st));
+    IVX_HIP(ctx, hipMemsetAsync(has_view, 0, (size_t)nkeys * sizeof(u32), st));
+    if (n) hipLaunchKernelGGL(k_mark_keys, dim3(grid1(n)), dim3(ST), 0, st, key, n, nkeys, has_in, bad);
+    if (nv) hipLaunchKernelGGL(k_mark_keys, dim3(grid1(nv)), dim3(ST), 0, st, vkey, nv, nkeys, has_view, bad);
+    hipLaunchKernelGGL(k_need_implicit, dim3(grid1((u64)nkeys + 1)), dim3(ST), 0, st, (const u32 *)has_in, (const u32 *)has_view, nkeys, need);
+    IVX_TRY(ivx_scan_exclusive_u32(ctx, need, (u64)nkeys + 1));
+    IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 4, need + nkeys, sizeof(u32), hipMemcpyDeviceToHost, st));
+    IVX_TRY(keyflag(ctx, "complement: key id >= n_keys"));                  // synchronises
+    const u64 nw = nv + *(u32 *)(ctx->h_scalars + 4);
+    if (nw >= 0xFFFFFFFFull) return ctx->fail(IVX_ERR_INVALID, "complement: more than 2^32-1 view rows");
+    if (nw == 0) return IVX_OK;
+
+    // merged runs of the input: sort, then the merge sweep with min_dist = 0 (complement.rs:297-317)
+    u32 *mk; i64 *ms, *me; u64 m = 0;
+    const u64 na = n ? n : 1;
+    IVX_TRY(ctx->get_scratch(WS_T3, na * sizeof(u32), (void **)&mk));
+    IVX_TRY(ctx->get_scratch(WS_T4, na * sizeof(i64), (void **)&ms));
+    IVX_TRY(ctx->get_scratch(WS_T7, na * sizeof(i64), (void **)&me));
+    if (n) {
+        u32 *ks; i64 *ss, *es;
+        IVX_TRY(ctx->get_scratch(WS_T0, n * sizeof(u32), (void **)&ks));
+        IVX_TRY(ctx->get_scratch(WS_T1, n * sizeof(i64), (void **)&ss));
+        IVX_TRY(ctx->get_scratch(WS_T2, n * sizeof(i64), (void **)&es));
+        IVX_TRY(sort64(ctx, WS_SA0, WS_SB0, key, s, e, n, nkeys, ks, ss, es, nullptr));
+        const ivx_runs_out ro{mk, ms, me, nullptr};
+        IVX_TRY(ivx_merge_runs(ctx, ks, ss, es, n, 0, strict, ro, &m));
+    }
+    u32 *G, *cg;
+    IVX_TRY(ctx->get_scratch(WS_T5, (m + 1) * sizeof(u32), (void **)&G));       // the sweep's scratch is free again
+    IVX_TRY(ctx->get_scratch(WS_T6, (m + 1) * sizeof(u32), (void **)&cg));
+    hipLaunchKernelGGL(k_run_gaps, dim3(grid1(m + 1)), dim3(ST), 0, st, (const u32 *)mk, (const i64 *)ms, (const i64 *)me, m, G, irregular);
+    IVX_TRY(ivx_scan_exclusive_u32(ctx, G, m + 1));
+    if (m) hipLaunchKernelGGL(k_gap_index, dim3(grid1(m)), dim3(ST), 0, st, (const u32 *)G, m, cg);
+
+    // views (+ implicit ones) sorted by (key, start, end): the per-contig view_bounds order
+    u32 *uk, *wk; i64 *us, *ue, *ws, *we;
+    IVX_TRY(ctx->get_scratch(WS_RA0, nw * sizeof(u32), (void **)&uk));
+    IVX_TRY(ctx->get_scratch(WS_RA1, nw * sizeof(i64), (void **)&us));
+    IVX_TRY(ctx->get_scratch(WS_RA2, nw * sizeof(i64), (void **)&ue));
+    const u64 gmax = nv > nkeys ? nv : nkeys;
+    hipLaunchKernelGGL(k_views_gather, dim3(grid1(gmax)), dim3(ST), 0, st, vkey, vs, ve, nv, (const u32 *)has_in, (const u32 *)has_view,
+                       (const u32 *)need, nkeys, uk, us, ue);
+    IVX_TRY(ctx->get_scratch(WS_T0, nw * sizeof(u32), (void **)&wk));            // the sorted input rows are dead by now
+    IVX_TRY(ctx->get_scratch(WS_T1, nw * sizeof(i64), (void **)&ws));
+    IVX_TRY(ctx->get_scratch(WS_T2, nw * sizeof(i64), (void **)&we));
+    IVX_TRY(sort64(ctx, WS_SA0, WS_SB0, uk, us, ue, nw, nkeys, wk, ws, we, nullptr));
+
+    u32 *A, *inv, *pa, *pb; u64 *cnt;
+    IVX_TRY(ctx->get_scratch(WS_T8, (nw + 1) * sizeof(u32), (void **)&A));
+    IVX_TRY(ctx->get_scratch(WS_T9, nw * sizeof(u32), (void **)&inv));
+    IVX_TRY(ctx->get_scratch(WS_RB0, nw * sizeof(u32), (void **)&pa));
+    IVX_TRY(ctx->get_scratch(WS_RB1, nw * sizeof(u32), (void **)&pb));
+    IVX_TRY(ctx->get_scratch(WS_RB2, (nw + 1) * sizeof(u64), (void **)&cnt));
+    hipLaunchKernelGGL(k_view_flags, dim3(grid1(nw + 1)), dim3(ST), 0, st, (const u32 *)wk, nw, (const u32 *)has_in, A);
+    IVX_TRY(ivx_scan_exclusive_u32(ctx, A, nw + 1));
+    IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 9, irregular, sizeof(u64), hipMemcpyDeviceToHost, st));
+    IVX_HIP(ctx, hipStreamSynchronize(st));
+    const int irr = *(u32 *)(ctx->h_scalars + 9) != 0;
+    const CompRuns R{mk, ms, me, (u32)m, G, cg};
+    hipLaunchKernelGGL(k_comp_count, dim3(grid1(nw + 1)), dim3(ST), 0, st, (const u32 *)wk, (const i64 *)ws, (const i64 *)we, nw,
+                       (const u32 *)has_in, (const u32 *)A, R, irr, cnt, inv, pa, pb);
+    IVX_TRY(ivx_scan_exclusive_u64(ctx, cnt, nw + 1));
+    IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 5, cnt + nw, sizeof(u64), hipMemcpyDeviceToHost, st));
+    IVX_HIP(ctx, hipStreamSynchronize(st));
+    const u64 total = ctx->h_scalars[5];
+    *n_out = total;
+    if (cap == 0 && !ok && !os && !oe) return IVX_OK;                       // count only
+    if (total > cap) return ctx->fail(IVX_ERR_CAPACITY, "complement: output buffers too small");
+    if (total == 0) return IVX_OK;
+    if (irr)
+        hipLaunchKernelGGL(k_comp_fill_serial, dim3(grid1(nw)), dim3(ST), 0, st, (const u32 *)wk, (const i64 *)ws, (const i64 *)we, (u32)nw,
+                           (const u32 *)has_in, R, (const u64 *)cnt, (const u32 *)inv, ok, os, oe);
+    else
+        hipLaunchKernelGGL(k_comp_fill_rows, dim3(grid1(total)), dim3(ST), 0, st, (const u32 *)wk, (const i64 *)ws, (const i64 *)we, (u32)nw,
+                           (const u32 *)has_in, R, (const u64 *)cnt, (const u32 *)inv, (const u32 *)pa, (const u32 *)pb, total, ok, os, oe);
     IVX_HIP(ctx, hipGetLastError());
     return IVX_OK;
 }

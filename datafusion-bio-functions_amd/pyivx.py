@@ -25,6 +25,7 @@ SYMBOLS = [
     "ivx_ctx_last_kernel_ms", "ivx_version", "ivx_index_build", "ivx_index_free", "ivx_index_rows",
     "ivx_index_device_bytes", "ivx_probe_overlap_count", "ivx_probe_overlap_fill", "ivx_probe_exists",
     "ivx_probe_count", "ivx_probe_coverage", "ivx_probe_nearest", "ivx_merge", "ivx_subtract",
+    "ivx_cluster", "ivx_complement",
 ]
 
 
@@ -301,3 +302,69 @@ class Ctx:
         self._chk(lib().ivx_subtract(self.h, *args, _ptr(ok), _ptr(os_), _ptr(oe), _ptr(orow), C.c_uint64(cap), C.byref(m2)))
         m2 = m2.value
         return ok[:m2], os_[:m2], oe[:m2], orow[:m2]
+
+    # ---- f1, f2 ----
+    def cluster(self, key, start, end, n_keys=None, min_dist=0, strict=False, key_base=None, rows=True):
+        """-> dict(key, start, end, row, cluster, cluster_start, cluster_end [rows sorted by (key,start,end,row)],
+                   key_clusters[n_keys], n_clusters); rows=False only counts the clusters per key."""
+        key, s, e, n, mem = _cols(key, start, end, np.int64)
+        if n_keys is None:
+            n_keys = 1 if key is None else (int(key.max()) + 1 if n else 1)
+        cap = max(n, 1)
+        if mem == MEM_DEVICE:
+            import torch
+            dev = s.device
+            mk = lambda dt, m=cap: torch.empty(m, dtype=dt, device=dev)
+            i32, i64 = torch.int32, torch.int64
+            if key_base is not None:
+                key_base = torch.as_tensor(key_base, dtype=torch.int64, device=dev).contiguous()
+        else:
+            mk = lambda dt, m=cap: np.empty(m, dt)
+            i32, i64 = np.uint32, np.int64
+            if key_base is not None:
+                key_base = np.ascontiguousarray(key_base, np.int64)
+        out = {}
+        if rows:
+            out = dict(key=mk(i32), start=mk(i64), end=mk(i64), row=mk(i32), cluster=mk(i64), cluster_start=mk(i64), cluster_end=mk(i64))
+        kc = mk(i64, max(n_keys, 1))
+        m = C.c_uint64(0)
+        g = lambda name: _ptr(out[name]) if rows else None
+        self._chk(lib().ivx_cluster(self.h, C.c_int(mem), _ptr(key), _ptr(s), _ptr(e), C.c_uint64(n), C.c_uint32(n_keys),
+                                     C.c_int64(int(min_dist)), C.c_int(int(strict)), _ptr(key_base) if key_base is not None else None,
+                                     g("key"), g("start"), g("end"), g("row"), g("cluster"), g("cluster_start"), g("cluster_end"),
+                                     _ptr(kc), C.byref(m)))
+        out = {k_: v[:n] for k_, v in out.items()}
+        out["key_clusters"] = kc[:n_keys]
+        out["n_clusters"] = m.value
+        return out
+
+    def complement(self, key, start, end, vkey=None, vstart=None, vend=None, n_keys=None, strict=False):
+        """-> (key, start, end); without view rows every key gets the implicit view [0, i64::MAX)."""
+        key, s, e, n, mem = _cols(key, start, end, np.int64)
+        if vstart is None:
+            nv, vk, vs, ve = 0, None, None, None
+        else:
+            vk, vs, ve, nv, mem2 = _cols(vkey, vstart, vend, np.int64)
+            assert mem == mem2
+        if n_keys is None:
+            mx = 0
+            for k_, n_ in ((key, n), (vk, nv)):
+                if k_ is not None and n_:
+                    mx = max(mx, int(k_.max()))
+            n_keys = mx + 1
+        args = (C.c_int(mem), _ptr(key), _ptr(s), _ptr(e), C.c_uint64(n), _ptr(vk), _ptr(vs), _ptr(ve), C.c_uint64(nv),
+                C.c_uint32(n_keys), C.c_int(int(strict)))
+        m = C.c_uint64(0)
+        self._chk(lib().ivx_complement(self.h, *args, None, None, None, C.c_uint64(0), C.byref(m)))
+        cap = max(m.value, 1)
+        if mem == MEM_DEVICE:
+            import torch
+            dev = s.device
+            ok = torch.empty(cap, dtype=torch.int32, device=dev); os_ = torch.empty(cap, dtype=torch.int64, device=dev)
+            oe = torch.empty(cap, dtype=torch.int64, device=dev)
+        else:
+            ok = np.empty(cap, np.uint32); os_ = np.empty(cap, np.int64); oe = np.empty(cap, np.int64)
+        m2 = C.c_uint64(0)
+        self._chk(lib().ivx_complement(self.h, *args, _ptr(ok), _ptr(os_), _ptr(oe), C.c_uint64(cap), C.byref(m2)))
+        m2 = m2.value
+        return ok[:m2], os_[:m2], oe[:m2]

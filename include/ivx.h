@@ -175,6 +175,36 @@ ivx_status ivx_subtract(ivx_ctx *ctx, int mem,
                         uint32_t *out_key, int64_t *out_start, int64_t *out_end, uint32_t *out_row,
                         uint64_t cap, uint64_t *n_out);
 
+/* ---- f1: ClusterStream / ClusterStreamExtra (cluster.rs:443-477, :598-661, :813-884) and the
+ *      ClusterIdCoordinator offsets (cluster.rs:380-420).  Output has exactly n rows, sorted by
+ *      (key, start, end, input row): the sorted row itself (out_key/out_start/out_end, and
+ *      out_row = its input row for the extra-columns `take`), the id of its cluster and the
+ *      cluster's extent.  Any output may be NULL.  Ids count clusters from 0 in output order
+ *      (keys ascending = contig names in byte order); a caller that holds only some of the
+ *      contigs (one DataFusion partition, one GPU of a sharded job) passes key_base[n_keys] =
+ *      the global id of each key's first cluster, computed from everybody's key_clusters
+ *      (out, [n_keys], clusters per key) -- call once with the row outputs NULL to get them.
+ *      *n_clusters = clusters in this call. */
+ivx_status ivx_cluster(ivx_ctx *ctx, int mem,
+                       const uint32_t *key /* nullable */, const int64_t *start, const int64_t *end, uint64_t n,
+                       uint32_t n_keys, int64_t min_dist, int strict, const int64_t *key_base /* nullable */,
+                       uint32_t *out_key, int64_t *out_start, int64_t *out_end, uint32_t *out_row,
+                       int64_t *out_cluster, int64_t *out_cluster_start, int64_t *out_cluster_end,
+                       uint64_t *key_clusters /* nullable */, uint64_t *n_clusters);
+
+/* ---- f2: ComplementStream (complement.rs:297-357, :394-465).  Input rows are merged per key
+ *      (strict: start < cur_end, else <=), gaps are emitted against the key's view intervals
+ *      (vkey/vstart/vend, nv rows; sorted per key, not merged); a key with input rows and no
+ *      view row gets the implicit view [0, INT64_MAX).  Output order as the reference: keys
+ *      with input rows ascending, then keys that only have view rows (their views, whole).
+ *      Passing cap = 0 with NULL outputs only counts. */
+ivx_status ivx_complement(ivx_ctx *ctx, int mem,
+                          const uint32_t *key /* nullable */, const int64_t *start, const int64_t *end, uint64_t n,
+                          const uint32_t *vkey /* nullable */, const int64_t *vstart, const int64_t *vend, uint64_t nv,
+                          uint32_t n_keys, int strict,
+                          uint32_t *out_key, int64_t *out_start, int64_t *out_end,
+                          uint64_t cap, uint64_t *n_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -587,6 +587,104 @@ uint64_t orc_subtract(const uint32_t *lkey, const int64_t *ls, const int64_t *le
     return w;
 }
 
+/* ---------------------------------------------------- f1: cluster */
+
+uint64_t orc_cluster(const uint32_t *key, const int64_t *s, const int64_t *e, uint64_t n, uint32_t nkeys,
+                     int64_t min_dist, int strict, const int64_t *key_base,
+                     uint32_t *out_key, int64_t *out_s, int64_t *out_e, uint32_t *out_row,
+                     int64_t *out_cluster, int64_t *out_cs, int64_t *out_ce, uint64_t *key_clusters)
+{
+    groups_t g;
+    iv64_t *v = sorted_groups64(key, s, e, n, &g);        /* FullBatchCollector order (start,end,row) */
+    if (key_clusters) for (uint32_t k = 0; k < nkeys; k++) key_clusters[k] = 0;
+    int64_t next_id = 0;                                   /* cluster.rs:398: contigs in name order */
+    uint64_t total = 0;
+    for (uint32_t k = 0; k < g.nkeys; k++) {
+        uint64_t lo = g.off[k], hi = g.off[k + 1];
+        if (lo == hi) continue;
+        int64_t id = key_base ? key_base[k] : next_id;    /* set_group_cluster_base, :571-580 */
+        uint64_t nclu = 0;
+        uint64_t i = lo;
+        while (i < hi) {                                   /* one pending cluster, :638-661 */
+            int64_t cs = v[i].s, ce = v[i].e;
+            uint64_t j = i + 1;
+            for (; j < hi; j++) {
+                int64_t boundary = sat_add64(ce, min_dist);
+                int mergec = strict ? (v[j].s < boundary) : (v[j].s <= boundary);
+                if (!mergec) break;
+                if (v[j].e > ce) ce = v[j].e;
+            }
+            for (uint64_t r = i; r < j; r++) {             /* flush_pending_cluster, :554-569 */
+                if (out_key) out_key[r] = k;
+                if (out_s) out_s[r] = v[r].s;
+                if (out_e) out_e[r] = v[r].e;
+                if (out_row) out_row[r] = (uint32_t)v[r].row;
+                if (out_cluster) out_cluster[r] = id;
+                if (out_cs) out_cs[r] = cs;
+                if (out_ce) out_ce[r] = ce;
+            }
+            id++; nclu++;
+            i = j;
+        }
+        if (key_clusters && k < nkeys) key_clusters[k] = nclu;
+        next_id += (int64_t)nclu;
+        total += nclu;
+    }
+    free(v); groups_free(&g);
+    return total;
+}
+
+/* ---------------------------------------------------- f2: complement */
+
+uint64_t orc_complement(const uint32_t *key, const int64_t *s, const int64_t *e, uint64_t n,
+                        const uint32_t *vkey, const int64_t *vs, const int64_t *ve, uint64_t nv,
+                        int strict, uint32_t *out_key, int64_t *out_s, int64_t *out_e, uint64_t cap)
+{
+    groups_t g, gv;
+    iv64_t *v = sorted_groups64(key, s, e, n, &g);
+    iv64_t *w = sorted_groups64(vkey, vs, ve, nv, &gv);   /* view_bounds: per contig, sorted (start,end) */
+    uint64_t o = 0;
+#define EMIT(k_, s_, e_) do { if (o < cap) { if (out_key) out_key[o] = (k_); if (out_s) out_s[o] = (s_); \
+        if (out_e) out_e[o] = (e_); } o++; } while (0)
+    iv64_t *m = (iv64_t *)malloc((n ? n : 1) * sizeof(iv64_t));
+    for (uint32_t k = 0; k < g.nkeys; k++) {
+        uint64_t lo = g.off[k], hi = g.off[k + 1];
+        if (lo == hi) continue;                            /* only contigs with input rows, :397 */
+        uint64_t nm = 0;                                   /* merge_intervals, :297-317 */
+        int64_t cs = v[lo].s, ce = v[lo].e;
+        for (uint64_t i = lo + 1; i < hi; i++) {
+            int mergec = strict ? (v[i].s < ce) : (v[i].s <= ce);
+            if (mergec) { if (v[i].e > ce) ce = v[i].e; }
+            else { m[nm].s = cs; m[nm].e = ce; nm++; cs = v[i].s; ce = v[i].e; }
+        }
+        m[nm].s = cs; m[nm].e = ce; nm++;
+        iv64_t implicit = { 0, INT64_MAX, 0 };             /* :401-403 */
+        const iv64_t *views = &implicit; uint64_t nviews = 1;
+        if (k < gv.nkeys && gv.off[k + 1] > gv.off[k]) { views = w + gv.off[k]; nviews = gv.off[k + 1] - gv.off[k]; }
+        for (uint64_t q = 0; q < nviews; q++) {            /* emit_contig_complement, :320-356 */
+            int64_t view_start = views[q].s, view_end = views[q].e;
+            int64_t cursor = view_start;
+            for (uint64_t j = 0; j < nm; j++) {
+                if (m[j].e <= view_start) continue;
+                if (m[j].s >= view_end) break;
+                int64_t is = m[j].s > view_start ? m[j].s : view_start;
+                int64_t ie = m[j].e < view_end ? m[j].e : view_end;
+                if (is > cursor) EMIT(k, cursor, is);
+                cursor = ie;
+            }
+            if (cursor < view_end) EMIT(k, cursor, view_end);
+        }
+    }
+    for (uint32_t k = 0; k < gv.nkeys; k++) {              /* EmitTrailingGaps, :431-456 */
+        if (gv.off[k + 1] == gv.off[k]) continue;
+        if (k < g.nkeys && g.off[k + 1] > g.off[k]) continue;
+        for (uint64_t q = gv.off[k]; q < gv.off[k + 1]; q++) EMIT(k, w[q].s, w[q].e);
+    }
+#undef EMIT
+    free(m); free(v); free(w); groups_free(&g); groups_free(&gv);
+    return o;
+}
+
 int64_t orc_check_i32(const int64_t *v, uint64_t n)
 {
     for (uint64_t i = 0; i < n; i++)

@@ -105,6 +105,30 @@ uint64_t orc_subtract(const uint32_t *lkey, const int64_t *ls, const int64_t *le
                       uint32_t *out_key, int64_t *out_s, int64_t *out_e, uint32_t *out_row,
                       uint64_t cap);
 
+/* ---- f1: cluster (cluster.rs:443-477 count, :598-661 emit, :380-420 global ids)
+ * Rows come out sorted by (key, start, end, row); row r of the output gets the
+ * id of its cluster (clusters numbered in output order: keys ascending = contig
+ * names in byte order, cluster.rs:396-417), and the cluster's extent.
+ * key_base (nullable, [nkeys]) overrides the id of each key's first cluster --
+ * what ClusterIdCoordinator hands a partition that holds only some contigs.
+ * key_clusters (nullable, [nkeys]) receives the clusters per key.  Returns the
+ * cluster count. */
+uint64_t orc_cluster(const uint32_t *key, const int64_t *s, const int64_t *e, uint64_t n, uint32_t nkeys,
+                     int64_t min_dist, int strict, const int64_t *key_base,
+                     uint32_t *out_key, int64_t *out_s, int64_t *out_e, uint32_t *out_row,
+                     int64_t *out_cluster, int64_t *out_cs, int64_t *out_ce, uint64_t *key_clusters);
+
+/* ---- f2: complement (complement.rs:297-357 merge + gaps, :394-465 driver) ----
+ * Input rows merged per key (strict: s < cur_end, else s <= cur_end; no
+ * min_dist), gaps emitted against the key's view intervals (sorted by
+ * (start,end), NOT merged); a key with input rows and no view row gets the
+ * implicit view [0, INT64_MAX).  Keys with input rows come first (ascending),
+ * then keys that only have view rows (ascending), whose views are emitted
+ * whole.  Returns rows; writes at most cap. */
+uint64_t orc_complement(const uint32_t *key, const int64_t *s, const int64_t *e, uint64_t n,
+                        const uint32_t *vkey, const int64_t *vs, const int64_t *ve, uint64_t nv,
+                        int strict, uint32_t *out_key, int64_t *out_s, int64_t *out_e, uint64_t cap);
+
 /* array_utils.rs:33-66, :90-104: checked i64 -> i32; returns -1 when all fit,
  * else the first offending row (the reference reports value and row). */
 int64_t orc_check_i32(const int64_t *v, uint64_t n);

@@ -169,6 +169,39 @@ def subtract(lkey, ls, le, rkey, rs, re, strict=False):
     return ok, os_, oe, orow
 
 
+def cluster(key, s, e, min_dist=0, strict=False, n_keys=None, key_base=None):
+    """-> dict(key u32, start i64, end i64, row u32, cluster i64, cluster_start i64, cluster_end i64,
+               key_clusters u64[n_keys], n_clusters) -- rows sorted by (key, start, end, row)."""
+    L = lib()
+    key, s, e = _k(key), _c64(s), _c64(e)
+    n = len(key)
+    nk = int(n_keys if n_keys is not None else (int(key.max()) + 1 if n else 0))
+    ok = np.empty(n, np.uint32); os_ = np.empty(n, np.int64); oe = np.empty(n, np.int64); orow = np.empty(n, np.uint32)
+    oc = np.empty(n, np.int64); ocs = np.empty(n, np.int64); oce = np.empty(n, np.int64)
+    kc = np.zeros(max(nk, 1), np.uint64)
+    kb = None if key_base is None else _c64(key_base)
+    L.orc_cluster.restype = C.c_uint64
+    tot = L.orc_cluster(_p(key), _p(s), _p(e), C.c_uint64(n), C.c_uint32(nk), C.c_int64(int(min_dist)), C.c_int(int(strict)),
+                        _p(kb) if kb is not None else None, _p(ok), _p(os_), _p(oe), _p(orow), _p(oc), _p(ocs), _p(oce), _p(kc))
+    return dict(key=ok, start=os_, end=oe, row=orow, cluster=oc, cluster_start=ocs, cluster_end=oce,
+                key_clusters=kc[:nk], n_clusters=int(tot))
+
+
+def complement(key, s, e, vkey=None, vs=None, ve=None, strict=False):
+    """-> (key u32, start i64, end i64); no view rows = implicit [0, i64::MAX) per key."""
+    L = lib()
+    key, s, e = _k(key), _c64(s), _c64(e)
+    if vkey is None:
+        vkey, vs, ve = np.empty(0, np.uint32), np.empty(0, np.int64), np.empty(0, np.int64)
+    vkey, vs, ve = _k(vkey), _c64(vs), _c64(ve)
+    L.orc_complement.restype = C.c_uint64
+    args = (_p(key), _p(s), _p(e), C.c_uint64(len(key)), _p(vkey), _p(vs), _p(ve), C.c_uint64(len(vkey)), C.c_int(int(strict)))
+    m = L.orc_complement(*args, None, None, None, C.c_uint64(0))
+    ok = np.empty(m, np.uint32); os_ = np.empty(m, np.int64); oe = np.empty(m, np.int64)
+    L.orc_complement(*args, _p(ok), _p(os_), _p(oe), C.c_uint64(m))
+    return ok, os_, oe
+
+
 def check_i32(v):
     v = _c64(v)
     return int(lib().orc_check_i32(_p(v), C.c_uint64(len(v))))

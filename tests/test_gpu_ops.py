@@ -257,6 +257,116 @@ def test_subtract_empty_sides(ctx):
     assert len(got[0]) == 0
 
 
+CLUSTER_COLS = ("key", "start", "end", "row", "cluster", "cluster_start", "cluster_end")
+
+
+def _same_cluster(got, want):
+    for c in CLUSTER_COLS:
+        assert len(got[c]) == len(want[c]) and (np.asarray(got[c]).astype(np.int64) == want[c].astype(np.int64)).all(), c
+    assert got["n_clusters"] == want["n_clusters"]
+    assert (np.asarray(got["key_clusters"]).astype(np.uint64) == want["key_clusters"]).all()
+
+
+def test_cluster_golden(ctx, golden):
+    for case in golden.cases("cluster"):
+        rows = golden.rows(case["input"])
+        names, ((k, s, e),) = encode_keys(rows)
+        c = ctx.cluster(k, s, e, n_keys=max(len(names), 1), min_dist=case["min_dist"], strict=case["strict"])
+        got = [[names[a], int(b), int(cc), int(d), int(f), int(g)] for a, b, cc, d, f, g in
+               zip(c["key"], c["start"], c["end"], c["cluster"], c["cluster_start"], c["cluster_end"])]
+        assert got == case["expect"], case["name"]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_cluster_random(ctx, seed):
+    nk = [1, 7, 40][seed % 3]
+    k, s, e = synth(200_000, 170 + seed, nkeys=nk, mean_len=[20, 300][seed % 2], span=3_000_000, dtype=np.int64)
+    if seed >= 3:
+        e[::29] = s[::29] - 4                              # inverted rows
+        s[::31] = s[1::31][: len(s[::31])]                 # duplicate starts: the row index breaks ties
+    md = [0, 0, 5, 1000, 0, 37][seed]
+    for strict in (False, True):
+        _same_cluster(ctx.cluster(k, s, e, n_keys=nk + 2, min_dist=md, strict=strict),
+                      orc.cluster(k, s, e, min_dist=md, strict=strict, n_keys=nk + 2))
+
+
+def test_cluster_sharded_ids_match_single_run(ctx):
+    # two "partitions" holding disjoint contigs: counts first, exclusive scan over the keys in
+    # order (what ClusterIdCoordinator does, cluster.rs:396-417), then ids with key_base
+    nk = 9
+    k, s, e = synth(50_000, 5, nkeys=nk, mean_len=200, span=2_000_000, dtype=np.int64)
+    full = ctx.cluster(k, s, e, n_keys=nk)
+    parts = [np.isin(k, [0, 3, 4, 8]), np.isin(k, [1, 2, 5, 6, 7])]
+    counts = np.zeros(nk, np.int64)
+    for sel in parts:
+        counts += np.asarray(ctx.cluster(k[sel], s[sel], e[sel], n_keys=nk, rows=False)["key_clusters"]).astype(np.int64)
+    base = np.concatenate([[0], np.cumsum(counts)[:-1]])
+    for sel in parts:
+        part = ctx.cluster(k[sel], s[sel], e[sel], n_keys=nk, key_base=base)
+        want = np.isin(full["key"], np.unique(k[sel]))
+        for c in ("key", "start", "end", "cluster", "cluster_start", "cluster_end"):
+            assert (np.asarray(part[c]) == np.asarray(full[c])[want]).all(), c
+        assert (np.flatnonzero(sel)[part["row"]] == full["row"][want]).all()
+
+
+def test_cluster_i64_extremes_and_empty(ctx):
+    big = np.iinfo(np.int64).max
+    k = np.zeros(6, np.uint32)
+    s = np.array([0, 100, big - 10, -big, 5, big], np.int64)
+    e = np.array([big - 1, 200, big, -big + 3, 5, big], np.int64)
+    for md in (0, 7, big):
+        for strict in (False, True):
+            _same_cluster(ctx.cluster(k, s, e, n_keys=1, min_dist=md, strict=strict), orc.cluster(k, s, e, min_dist=md, strict=strict, n_keys=1))
+    z = np.zeros(0, np.int64)
+    c = ctx.cluster(np.zeros(0, np.uint32), z, z, n_keys=3)
+    assert c["n_clusters"] == 0 and len(c["cluster"]) == 0 and np.asarray(c["key_clusters"]).tolist() == [0, 0, 0]
+    with pytest.raises(pyivx.IvxError):
+        ctx.cluster(k, s, e, n_keys=1, min_dist=-1)
+
+
+def test_complement_golden(ctx, golden):
+    for case in golden.cases("complement"):
+        rows, view = golden.rows(case["input"]), case["view"] or []
+        names, ((k, s, e), (vk, vs, ve)) = encode_keys(rows, view)
+        ok, os_, oe = ctx.complement(k, s, e, vk, vs, ve, n_keys=max(len(names), 1), strict=case["strict"])
+        got = [[names[a], int(b), int(c)] for a, b, c in zip(ok, os_, oe)]
+        assert got == case["expect"], case["name"]
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_complement_random(ctx, seed):
+    nk = [1, 6, 30, 12][seed % 4]
+    k, s, e = synth(120_000, 270 + seed, nkeys=nk, mean_len=[30, 400][seed % 2], span=4_000_000, dtype=np.int64)
+    rng = np.random.default_rng(seed)
+    mode = seed % 4
+    if mode == 0:                                          # no view at all: implicit [0, i64::MAX) per key
+        vk = vs = ve = None
+    else:                                                  # overlapping, unmerged views; some keys view-only, some input-only
+        nvw = [0, 40, 3000, 50_000][mode]
+        vk = rng.integers(0, nk + 3, nvw).astype(np.uint32)
+        vs = rng.integers(-1000, 4_000_000, nvw).astype(np.int64)
+        ve = vs + rng.integers(-50, [0, 3_000_000, 200_000, 5_000][mode], nvw)
+        keep = ~np.isin(k, [1, 4])                         # keys 1 and 4: view rows only
+        k, s, e = k[keep], s[keep], e[keep]
+    if seed >= 4:
+        e[::23] = s[::23] - 7                              # end < start rows: merged ends no longer ascend (serial walk)
+    for strict in (False, True):
+        got = ctx.complement(k, s, e, vk, vs, ve, n_keys=nk + 3, strict=strict)
+        want = orc.complement(k, s, e, vk, vs, ve, strict=strict)
+        for g, w in zip(got, want):
+            assert len(g) == len(w) and (np.asarray(g).astype(np.int64) == w.astype(np.int64)).all(), (seed, strict)
+
+
+def test_complement_empty_sides_and_count_only(ctx):
+    z64, zk = np.zeros(0, np.int64), np.zeros(0, np.uint32)
+    assert len(ctx.complement(zk, z64, z64, n_keys=2)[0]) == 0                       # nothing in, nothing out
+    ok, os_, oe = ctx.complement(zk, z64, z64, np.array([1, 0], np.uint32), np.array([5, 0], np.int64), np.array([9, 3], np.int64), n_keys=2)
+    assert ok.tolist() == [0, 1] and os_.tolist() == [0, 5] and oe.tolist() == [3, 9]   # views come back whole, key order
+    big = np.iinfo(np.int64).max
+    ok, os_, oe = ctx.complement(np.array([0], np.uint32), np.array([0], np.int64), np.array([big], np.int64), n_keys=1)
+    assert len(ok) == 0                                                                  # the input covers the implicit view
+
+
 def test_wrong_index_kind(ctx):
     bk, bs, be = synth(100, 1)
     ix = ctx.build(pyivx.KIND_COUNT, bk, bs, be, n_keys=1)

@@ -154,6 +154,42 @@ def test_subtract_golden(golden):
             assert ls[row] <= a < b <= le[row]
 
 
+def test_cluster_golden(golden):
+    for case in golden.cases("cluster"):
+        rows = golden.rows(case["input"])
+        names, ((k, s, e),) = encode_keys(rows)
+        c = orc.cluster(k, s, e, min_dist=case["min_dist"], strict=case["strict"], n_keys=len(names))
+        got = [[names[a], int(b), int(cc), int(d), int(f), int(g)] for a, b, cc, d, f, g in
+               zip(c["key"], c["start"], c["end"], c["cluster"], c["cluster_start"], c["cluster_end"])]
+        assert got == case["expect"], case["name"]          # exact order: contig, start, end
+        assert c["n_clusters"] == len({r[3] for r in case["expect"]})
+        assert int(c["key_clusters"].sum()) == c["n_clusters"]
+        for r, row in zip(rows and [rows[i] for i in c["row"]], got):   # out_row points at the input row
+            assert r[1:3] == row[1:3]
+
+
+def test_cluster_key_base_is_coordinator_offset():
+    # a partition that holds only contigs 1 and 3 of four gets their global first ids from the
+    # coordinator's exclusive scan (cluster.rs:396-417): ids are then identical to the one-partition run
+    k = np.array([0, 0, 1, 1, 1, 2, 3, 3], np.uint32)
+    s = np.array([0, 50, 0, 5, 100, 7, 0, 1000], np.int64); e = s + 10
+    full = orc.cluster(k, s, e, n_keys=4)
+    base = np.concatenate([[0], np.cumsum(full["key_clusters"])[:-1]]).astype(np.int64)
+    sel = (k == 1) | (k == 3)
+    part = orc.cluster(k[sel], s[sel], e[sel], n_keys=4, key_base=base)
+    want = full["cluster"][np.isin(full["key"], [1, 3])]
+    assert part["cluster"].tolist() == want.tolist()
+
+
+def test_complement_golden(golden):
+    for case in golden.cases("complement"):
+        rows, view = golden.rows(case["input"]), case["view"] or []
+        names, ((k, s, e), (vk, vs, ve)) = encode_keys(rows, view)
+        ok, os_, oe = orc.complement(k, s, e, vk, vs, ve, strict=case["strict"])
+        got = [[names[a], int(b), int(c)] for a, b, c in zip(ok, os_, oe)]
+        assert got == case["expect"], case["name"]
+
+
 def test_check_i32():
     # array_utils.rs:33-66: first offending row is reported
     assert orc.check_i32([1, 2, 3]) == -1
