@@ -2,7 +2,7 @@
 (Arrow C Data Interface) -- what a DataFusion session would expose as
 
     count_overlaps('l','r'), coverage('l','r'), nearest('l','r',k,overlap,distance),
-    overlap('l','r'[,mode]), merge('t'[,min_dist]), subtract('l','r'),
+    overlap('l','r'[,mode]), merge('t'[,min_dist]), subtract('l','r'), cluster('t'[,min_dist]), complement('t'[,'view']),
     and the SQL range join handled by IntervalJoinExec
 
 Argument meaning and output schemas follow R/src/table_function.rs and the providers
@@ -218,6 +218,43 @@ class Session:
         for n in left.schema.names:
             cols.append(contig if n == key else start if n == cols_left[1] else end if n == cols_left[2] else pc.take(left.column(n), row))
         return pa.table(cols, names=left.schema.names)
+
+
+    # ---- cluster (table_function.rs:574-612; ClusterProvider cluster.rs:29-82)
+    def cluster(self, table, min_dist=0, cols=DEFAULT_COLS, strict=False):
+        if min_dist < 0:
+            raise BioRangesError(f"cluster() min_dist must be >= 0, got {min_dist}")        # table_function.rs:237
+        T = _Exported(table)
+        outs = [_out() for _ in range(7)]
+        try:
+            self._chk(lib().brh_cluster(self.h, T.c, _cols(cols), C.c_int64(int(min_dist)), C.c_int(STRICT if strict else WEAK),
+                                        *[C.byref(x) for pair in outs for x in pair]))
+        finally:
+            T.close()
+        contig, start, end, row, cl, cs, ce = [_import(*o) for o in outs]
+        key = cols[0] if isinstance(cols[0], str) else cols[0][0]
+        if table.num_columns > 3:                            # extra columns: every input field kept as it is (cluster.rs:50-53)
+            out_cols = [pc.take(table.column(n), row) for n in table.schema.names]
+            names = list(table.schema.names)
+        else:
+            out_cols, names = [contig, start, end], [key, cols[1], cols[2]]
+        return pa.table(out_cols + [cl, cs, ce], names=names + ["cluster", "cluster_start", "cluster_end"])
+
+    # ---- complement (table_function.rs:614-786; ComplementProvider complement.rs:28-75)
+    def complement(self, table, view=None, cols=DEFAULT_COLS, view_cols=None, strict=False):
+        T = _Exported(table)
+        V = _Exported(view) if view is not None else None
+        outs = [_out() for _ in range(3)]
+        try:
+            vb = V.c if V is not None else _Batch(None, None)
+            self._chk(lib().brh_complement(self.h, T.c, _cols(cols), vb, _cols(view_cols or cols), C.c_int(STRICT if strict else WEAK),
+                                           *[C.byref(x) for pair in outs for x in pair]))
+        finally:
+            T.close()
+            if V is not None:
+                V.close()
+        key = cols[0] if isinstance(cols[0], str) else cols[0][0]
+        return pa.table([_import(*o) for o in outs], names=[key, cols[1], cols[2]])
 
 
 def check_position_column(table, column, as_i64=False):

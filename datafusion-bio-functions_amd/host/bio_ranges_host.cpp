@@ -448,3 +448,59 @@ extern "C" int brh_subtract(brh_session *s, brh_batch left, brh_columns lcols, b
     make_primitive<uint32_t>(left_row, orow.data(), (int64_t)m2, nullptr); make_schema(left_row_schema, "I", "left_row", false);
     return 0;
 }
+
+extern "C" int brh_cluster(brh_session *s, brh_batch table, brh_columns cols, int64_t min_dist, int filter_op,
+                           ArrowArray *contig, ArrowSchema *contig_schema, ArrowArray *start, ArrowSchema *start_schema,
+                           ArrowArray *end, ArrowSchema *end_schema, ArrowArray *row, ArrowSchema *row_schema,
+                           ArrowArray *cluster, ArrowSchema *cluster_schema, ArrowArray *cluster_start, ArrowSchema *cluster_start_schema,
+                           ArrowArray *cluster_end, ArrowSchema *cluster_end_schema)
+{
+    if (!s) return 1;
+    KeyDict kd; Side64 T;
+    if (build_keys(s, {{table, cols}}, &kd) || load_side64(s, table, cols, &T)) return 1;
+    const uint64_t n = T.s.size(), na = n ? n : 1;
+    std::vector<uint32_t> ok(na), orow(na); std::vector<int64_t> os(na), oe(na), oc(na), ocs(na), oce(na);
+    uint64_t m = 0;
+    ivx_status st = ivx_cluster(s->ctx, IVX_MEM_HOST, kd.ids[0].data(), T.s.data(), T.e.data(), n, (uint32_t)std::max<size_t>(kd.names.size(), 1),
+                                min_dist, filter_op == BRH_STRICT, nullptr, ok.data(), os.data(), oe.data(), orow.data(),
+                                oc.data(), ocs.data(), oce.data(), nullptr, &m);
+    if (st != IVX_OK) return fail_ivx(s, st);
+    make_utf8(contig, kd.names, ok.data(), (int64_t)n); make_schema(contig_schema, "u", cols.keys[0], false);
+    make_primitive<int64_t>(start, os.data(), (int64_t)n, nullptr); make_schema(start_schema, "l", cols.start, false);   // cluster.rs:55-67
+    make_primitive<int64_t>(end, oe.data(), (int64_t)n, nullptr); make_schema(end_schema, "l", cols.end, false);
+    make_primitive<uint32_t>(row, orow.data(), (int64_t)n, nullptr); make_schema(row_schema, "I", "row", false);
+    make_primitive<int64_t>(cluster, oc.data(), (int64_t)n, nullptr); make_schema(cluster_schema, "l", "cluster", false);
+    make_primitive<int64_t>(cluster_start, ocs.data(), (int64_t)n, nullptr); make_schema(cluster_start_schema, "l", "cluster_start", false);
+    make_primitive<int64_t>(cluster_end, oce.data(), (int64_t)n, nullptr); make_schema(cluster_end_schema, "l", "cluster_end", false);
+    return 0;
+}
+
+extern "C" int brh_complement(brh_session *s, brh_batch table, brh_columns cols, brh_batch view, brh_columns view_cols, int filter_op,
+                              ArrowArray *contig, ArrowSchema *contig_schema, ArrowArray *start, ArrowSchema *start_schema,
+                              ArrowArray *end, ArrowSchema *end_schema)
+{
+    if (!s) return 1;
+    const bool has_view = view.array != nullptr;
+    KeyDict kd; Side64 T, V;
+    if (has_view) {
+        if (build_keys(s, {{table, cols}, {view, view_cols}}, &kd) || load_side64(s, table, cols, &T) || load_side64(s, view, view_cols, &V)) return 1;
+    } else {
+        if (build_keys(s, {{table, cols}}, &kd) || load_side64(s, table, cols, &T)) return 1;
+        kd.ids.emplace_back();
+    }
+    const uint32_t nk = (uint32_t)std::max<size_t>(kd.names.size(), 1);
+    const bool strict = filter_op == BRH_STRICT;
+    uint64_t m = 0;
+    ivx_status st = ivx_complement(s->ctx, IVX_MEM_HOST, kd.ids[0].data(), T.s.data(), T.e.data(), T.s.size(),
+                                   kd.ids[1].data(), V.s.data(), V.e.data(), V.s.size(), nk, strict, nullptr, nullptr, nullptr, 0, &m);
+    if (st != IVX_OK) return fail_ivx(s, st);
+    std::vector<uint32_t> ok(m ? m : 1); std::vector<int64_t> os(m ? m : 1), oe(m ? m : 1);
+    uint64_t m2 = 0;
+    st = ivx_complement(s->ctx, IVX_MEM_HOST, kd.ids[0].data(), T.s.data(), T.e.data(), T.s.size(),
+                        kd.ids[1].data(), V.s.data(), V.e.data(), V.s.size(), nk, strict, ok.data(), os.data(), oe.data(), m, &m2);
+    if (st != IVX_OK) return fail_ivx(s, st);
+    make_utf8(contig, kd.names, ok.data(), (int64_t)m2); make_schema(contig_schema, "u", cols.keys[0], false);           // complement.rs:52-58
+    make_primitive<int64_t>(start, os.data(), (int64_t)m2, nullptr); make_schema(start_schema, "l", cols.start, false);
+    make_primitive<int64_t>(end, oe.data(), (int64_t)m2, nullptr); make_schema(end_schema, "l", cols.end, false);
+    return 0;
+}

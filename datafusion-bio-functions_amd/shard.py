@@ -50,3 +50,16 @@ def max_over_ranks(dist, seconds, device):
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t[0])
+
+
+def cluster_key_base(dist, key_clusters, group=None):
+    """cluster(): the one exchange step with real data dependence (cluster.rs:322-420,
+    ClusterIdCoordinator).  Every rank passes the clusters it counted per key (int64
+    tensor [n_keys], zero for keys it does not hold; ivx_cluster's key_clusters from a
+    count-only call).  One all-reduce(SUM) makes the global per-key counts; the exclusive
+    scan over keys in id order (= contig names in byte order) is the id of each key's
+    first cluster, identical on all ranks -- the key_base argument of ivx_cluster."""
+    import torch
+    tot = key_clusters.clone().to(torch.int64)
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
+    return torch.cumsum(tot, 0) - tot

@@ -102,6 +102,27 @@ int brh_subtract(brh_session *s, brh_batch left, brh_columns lcols, brh_batch ri
                  struct ArrowArray *end, struct ArrowSchema *end_schema,
                  struct ArrowArray *left_row, struct ArrowSchema *left_row_schema);
 
+/* cluster('table'[,min_dist]...): ClusterProvider / ClusterStream / ClusterStreamExtra
+ * (R/src/cluster.rs:29-82, :517-760, :762-977).  One output row per input row, sorted by
+ * (contig, start, end, input row): contig Utf8, start Int64, end Int64, row UInt32 (the input row,
+ * for the extra-columns take, cluster.rs:787-806), cluster Int64, cluster_start Int64, cluster_end Int64. */
+int brh_cluster(brh_session *s, brh_batch table, brh_columns cols, int64_t min_dist, int filter_op,
+                struct ArrowArray *contig, struct ArrowSchema *contig_schema,
+                struct ArrowArray *start, struct ArrowSchema *start_schema,
+                struct ArrowArray *end, struct ArrowSchema *end_schema,
+                struct ArrowArray *row, struct ArrowSchema *row_schema,
+                struct ArrowArray *cluster, struct ArrowSchema *cluster_schema,
+                struct ArrowArray *cluster_start, struct ArrowSchema *cluster_start_schema,
+                struct ArrowArray *cluster_end, struct ArrowSchema *cluster_end_schema);
+
+/* complement('table'[,'view_table']...): ComplementProvider / ComplementStream
+ * (R/src/complement.rs:28-75, :236-478).  view.array == NULL means no view table: every contig gets
+ * [0, i64::MAX).  Outputs contig Utf8, start Int64, end Int64 named after the INPUT table's columns. */
+int brh_complement(brh_session *s, brh_batch table, brh_columns cols, brh_batch view, brh_columns view_cols, int filter_op,
+                   struct ArrowArray *contig, struct ArrowSchema *contig_schema,
+                   struct ArrowArray *start, struct ArrowSchema *start_schema,
+                   struct ArrowArray *end, struct ArrowSchema *end_schema);
+
 /* the checks alone (no GPU): resolve a position column like PosArray::resolve / resolve_i64 would;
  * 0 = fine, else the error text is set.  Used by the CPU-only tests. */
 int brh_check_position_column(brh_session *s_or_null, brh_batch table, const char *column, int as_i64,

@@ -55,3 +55,34 @@ def test_sharded_join_allgatherv_world2():
         ret = m.dict()
         mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
         assert ret.get("ok") is True
+
+
+def _cluster_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    from oracle import oracle as orc
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    nk = 9
+    k, s, e = synth(20000, 11, nkeys=nk, mean_len=300, span=2_000_000, dtype=np.int64)
+    rank_of = shard.assign_keys_lpt(np.bincount(k, minlength=nk), world)
+    mine = rank_of[k] == rank
+    counts = orc.cluster(k[mine], s[mine], e[mine], n_keys=nk)["key_clusters"].astype(np.int64)     # count-only call
+    base = shard.cluster_key_base(dist, torch.from_numpy(counts))
+    part = orc.cluster(k[mine], s[mine], e[mine], n_keys=nk, key_base=base.numpy())
+    full = orc.cluster(k, s, e, n_keys=nk)
+    sel = np.isin(full["key"], np.flatnonzero(rank_of == rank))
+    ok = all((part[c] == full[c][sel]).all() for c in ("key", "start", "end", "cluster", "cluster_start", "cluster_end"))
+    flags = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(flags, torch.tensor([int(ok)], dtype=torch.int64))
+    if rank == 0:
+        ret["ok"] = all(int(f) == 1 for f in flags)
+    dist.destroy_process_group()
+
+
+def test_sharded_cluster_ids_world2():
+    # contigs sharded over two ranks; global cluster ids equal the single-process ids
+    port = 31500 + os.getpid() % 2000
+    with mp.Manager() as m:
+        ret = m.dict()
+        mp.spawn(_cluster_worker, args=(2, port, ret), nprocs=2, join=True)
+        assert ret.get("ok") is True

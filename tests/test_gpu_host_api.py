@@ -158,3 +158,42 @@ def test_partition_invariance_tables(ctx, golden):
     case = [c for c in golden.cases("subtract") if c["name"] == "subtract_partitioned_parquet"][0]   # :3758-3890
     out = ctx.subtract(table(case["left"]), table(case["right"]))
     assert [list(r) for r in zip(*[out.column(n).to_pylist() for n in out.schema.names])] == case["expect"]
+
+
+def _rows(t):
+    return [list(r) for r in zip(*[t.column(n).to_pylist() for n in t.schema.names])]
+
+
+def test_cluster_udtf(ctx, golden):
+    for case in golden.cases("cluster"):                                         # :2411-2757, :3792-3802
+        out = ctx.cluster(table(golden.rows(case["input"])), case["min_dist"], strict=case["strict"])
+        assert out.schema.names == ["contig", "pos_start", "pos_end", "cluster", "cluster_start", "cluster_end"]
+        assert all(out.schema.field(n).type == pa.int64() for n in out.schema.names[1:])
+        assert _rows(out) == case["expect"], case["name"]
+    t = pa.table({"chr": ["a", "a"], "s": pa.array([100, 150], pa.int32()), "e": pa.array([200, 250], pa.int32())})
+    out = ctx.cluster(t, 0, cols=("chr", "s", "e"))                              # :2690-2716
+    assert out.schema.names[:4] == ["chr", "s", "e", "cluster"] and out.num_rows == 2
+    with pytest.raises(br.BioRangesError, match="min_dist must be >= 0"):
+        ctx.cluster(table([("a", 1, 2)]), -1)
+
+
+def test_cluster_udtf_preserves_extra_columns(ctx):
+    t = pa.table({"contig": ["a", "a", "a"], "pos_start": pa.array([400, 150, 100], pa.int32()), "pos_end": pa.array([500, 250, 200], pa.int32()),
+                  "gene": ["TP53", "BRCA2", "BRCA1"], "score": [0.75, 0.85, 0.95]})      # :3594-3625
+    out = ctx.cluster(t)
+    assert out.schema.names == ["contig", "pos_start", "pos_end", "gene", "score", "cluster", "cluster_start", "cluster_end"]
+    assert out.schema.field("pos_start").type == pa.int32()                      # input fields kept as they are
+    assert _rows(out) == [["a", 100, 200, "BRCA1", 0.95, 0, 100, 250], ["a", 150, 250, "BRCA2", 0.85, 0, 100, 250],
+                          ["a", 400, 500, "TP53", 0.75, 1, 400, 500]]
+
+
+def test_complement_udtf(ctx, golden):
+    for case in golden.cases("complement"):                                      # :2825-3175, :3803-3822
+        view = table(case["view"]) if case["view"] is not None else None
+        out = ctx.complement(table(golden.rows(case["input"])), view, strict=case["strict"])
+        assert out.schema.names == ["contig", "pos_start", "pos_end"] and out.schema.field("pos_end").type == pa.int64()
+        assert _rows(out) == case["expect"], case["name"]
+    t = pa.table({"chr": ["a"], "s": [100], "e": [200]})
+    v = pa.table({"c": ["a"], "b": [0], "x": [500]})
+    out = ctx.complement(t, v, cols=("chr", "s", "e"), view_cols=("c", "b", "x"))   # :3093-3134, view with its own column names
+    assert out.schema.names == ["chr", "s", "e"] and _rows(out) == [["a", 0, 100], ["a", 200, 500]]

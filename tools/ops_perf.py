@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "datafusion-bio-functions_amd"))
 import pyivx, synth
 dev = torch.device("cuda:0")
-which = os.environ.get("OPS", "count,coverage,nearest,merge,subtract").split(",")
+which = os.environ.get("OPS", "count,coverage,nearest,merge,subtract,cluster,complement").split(",")
 scale = float(os.environ.get("SCALE", "1"))
 ctx = pyivx.Ctx(0); ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 
@@ -42,7 +42,7 @@ if "nearest" in which:
     tp, out = timed(lambda: ctx.nearest(ix, pk[:npr // 5], ps[:npr // 5], pe[:npr // 5], k=3), reps=2)
     report(f"nearest k=3 probe {npr//5}x{nb}", tp, 12 * (npr // 5 + nb) + 48 * (npr // 5), f"rows {out[0].numel()}")
     ix.free(); del bk, bs, be, pk, ps, pe
-if "merge" in which or "subtract" in which:
+if "merge" in which or "subtract" in which or "cluster" in which or "complement" in which:
     n = int(float(os.environ.get("NMERGE", 200_000_000)) * scale)
     k, s, e = synth.gen_torch(n, 1000, 24, 0x5EED0008, dev)
     s64, e64 = s.to(torch.int64), e.to(torch.int64) + 1
@@ -58,3 +58,20 @@ if "merge" in which or "subtract" in which:
         ts, out = timed(lambda: ctx.subtract(k, s64, e64, rk, rs64, re64, n_keys=24), reps=1)
         m = out[0].numel()
         report(f"subtract {n}-{nr} (count+fill)", ts, 20 * (n + nr) + 20 * m, f"out rows {m}")
+    if "subtract" in which:
+        del rk, rs, re, rs64, re64
+    if "cluster" in which or "complement" in which:
+        # dense (everything of a contig chains into one run) and sparse (mean length 20: ~60 % singletons) inputs
+        n2 = n // 4
+        k2, s2, e2 = synth.gen_torch(n2, 20, 24, 0x5EED000A, dev)
+        s2, e2 = s2.to(torch.int64), e2.to(torch.int64) + 1
+        for tag, (kk, ss, ee, nn) in (("dense", (k, s64, e64, n)), ("sparse", (k2, s2, e2, n2))):
+            if "cluster" in which:
+                tc, out = timed(lambda: ctx.cluster(kk, ss, ee, n_keys=24), reps=2)
+                report(f"cluster {tag} {nn}", tc, 68 * nn, f"kernel {ctx.last_kernel_ms():.3f} ms clusters {out['n_clusters']}")
+                del out
+            if "complement" in which:
+                tc, out = timed(lambda: ctx.complement(kk, ss, ee, n_keys=24), reps=2)
+                m = out[0].numel()
+                report(f"complement {tag} {nn} (count+fill)", tc, 20 * nn + 20 * m, f"out rows {m}")
+                del out
