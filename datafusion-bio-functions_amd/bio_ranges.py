@@ -170,10 +170,13 @@ class Session:
         return _import(ba, bs), _import(pa_, ps)
 
     def sql_range_join(self, build, probe, cols_build=DEFAULT_COLS, cols_probe=DEFAULT_COLS, strict_predicate=False,
-                       nearest_algorithm=False):
+                       nearest_algorithm=False, device_take=False):
         """SELECT * FROM build JOIN probe ON key = key AND range predicate  (build columns, then probe columns)."""
         bi, pi = self.interval_join(build, probe, cols_build, cols_probe, JOIN_INNER, strict_predicate, nearest_algorithm)
-        cols = [pc.take(build.column(n), bi) for n in build.schema.names] + [pc.take(probe.column(n), pi) for n in probe.schema.names]
+        if device_take:                                      # payload gather on the GPU as well (SURVEY 8f row 3)
+            cols = list(self.take_table(build, bi).values()) + list(self.take_table(probe, pi).values())
+        else:
+            cols = [pc.take(build.column(n), bi) for n in build.schema.names] + [pc.take(probe.column(n), pi) for n in probe.schema.names]
         names = [f"l.{n}" for n in build.schema.names] + [f"r.{n}" for n in probe.schema.names]
         return pa.table(cols, names=names)
 
@@ -219,6 +222,29 @@ class Session:
             cols.append(contig if n == key else start if n == cols_left[1] else end if n == cols_left[2] else pc.take(left.column(n), row))
         return pa.table(cols, names=left.schema.names)
 
+
+    # ---- f3: compute::take of payload columns on the device (interval_join.rs:1655-1667, nearest.rs:469-482)
+    def take(self, column, idx):
+        """column: pyarrow Array / ChunkedArray; idx: UInt32 array (nulls -> null rows).  Raises for layouts the
+        device gather does not cover (bool, nested, dictionary, views): those stay with the caller's own take."""
+        if isinstance(column, pa.ChunkedArray):
+            column = column.combine_chunks() if column.num_chunks != 1 else column.chunk(0)
+        if isinstance(idx, pa.ChunkedArray):
+            idx = idx.combine_chunks()
+        ca, cs, ia, is_ = _ArrowArray(), _ArrowSchema(), _ArrowArray(), _ArrowSchema()
+        column._export_to_c(C.addressof(ca), C.addressof(cs))
+        idx._export_to_c(C.addressof(ia), C.addressof(is_))
+        a, sc = _out()
+        try:
+            self._chk(lib().brh_take(self.h, C.byref(ca), C.byref(cs), C.byref(ia), C.byref(is_), C.byref(a), C.byref(sc)))
+        finally:
+            for obj in (ca, cs, ia, is_):
+                if obj.release:
+                    C.CFUNCTYPE(None, C.c_void_p)(obj.release)(C.addressof(obj))
+        return _import(a, sc)
+
+    def take_table(self, table, idx, prefix=""):
+        return {prefix + n: self.take(table.column(n), idx) for n in table.schema.names}
 
     # ---- cluster (table_function.rs:574-612; ClusterProvider cluster.rs:29-82)
     def cluster(self, table, min_dist=0, cols=DEFAULT_COLS, strict=False):

@@ -365,6 +365,10 @@ ivx_status ivx_cluster_device(ivx_ctx *ctx, const u32 *key, const i64 *s, const 
 ivx_status ivx_complement_device(ivx_ctx *ctx, const u32 *key, const i64 *s, const i64 *e, u64 n,
                                  const u32 *vkey, const i64 *vs, const i64 *ve, u64 nv, u32 nkeys, int strict,
                                  u32 *ok, i64 *os, i64 *oe, u64 cap, u64 *n_out);
+ivx_status ivx_take_fixed_device(ivx_ctx *ctx, const void *src, u32 width, u64 n_src, const u8 *src_valid,
+                                 const u32 *idx, u64 n, void *out, u8 *out_valid);
+ivx_status ivx_take_utf8_device(ivx_ctx *ctx, int large, const void *offsets, const u8 *data, u64 n_src, const u8 *src_valid,
+                                const u32 *idx, u64 n, void *out_offsets, u8 *out_data, u64 data_cap, u64 *data_bytes, u8 *out_valid);
 
 static ivx_status per_row_i64(ivx_ctx *ctx, const ivx_index *ix, int kind, int mem, const u32 *key, const i32 *start,
                               const i32 *end, u64 n, int strict, i64 *out)
@@ -592,6 +596,65 @@ extern "C" ivx_status ivx_complement(ivx_ctx *ctx, int mem, const uint32_t *key,
         IVX_TRY(copy_out(ctx, mem, out_start, os, m));
         IVX_TRY(copy_out(ctx, mem, out_end, oe, m));
     }
+    if (mem == IVX_MEM_HOST) IVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return IVX_OK;
+}
+
+extern "C" ivx_status ivx_take_fixed(ivx_ctx *ctx, int mem, const void *src, uint32_t width, uint64_t n_src,
+                                     const uint8_t *src_valid_bits, const uint32_t *idx, uint64_t n, void *out, uint8_t *out_valid)
+{
+    if (!ctx) return IVX_ERR_INVALID;
+    if (mem != IVX_MEM_HOST && mem != IVX_MEM_DEVICE) return ctx->fail(IVX_ERR_INVALID, "bad mem");
+    if (n && (!idx || !out)) return ctx->fail(IVX_ERR_INVALID, "take: null idx or out");
+    if (n_src && !src) return ctx->fail(IVX_ERR_INVALID, "take: null source column");
+    if (width == 0 || width > 32 || (width & (width - 1))) return ctx->fail(IVX_ERR_UNSUPPORTED, "take: fixed width must be 1, 2, 4, 8, 16 or 32 bytes");
+    IVX_HIP(ctx, hipSetDevice(ctx->device));
+    const u8 *dsrc, *dvalid; const u32 *didx; u8 *dout, *dov;
+    IVX_TRY(stage_in(ctx, mem, WS_IN_KEY, (const u8 *)src, n_src * width, &dsrc));
+    IVX_TRY(stage_in(ctx, mem, WS_IN_START, src_valid_bits, (n_src + 7) / 8, &dvalid));
+    IVX_TRY(stage_in(ctx, mem, WS_IN_END, idx, n, &didx));
+    IVX_TRY(stage_out(ctx, mem, WS_OUT_A, (u8 *)out, n * width, &dout));
+    IVX_TRY(stage_out(ctx, mem, WS_OUT_B, out_valid, n, &dov));
+    {
+        KernelTimer t(ctx);
+        IVX_TRY(ivx_take_fixed_device(ctx, dsrc, width, n_src, dvalid, didx, n, dout, dov));
+    }
+    IVX_TRY(copy_out(ctx, mem, (u8 *)out, dout, n * width));
+    IVX_TRY(copy_out(ctx, mem, out_valid, dov, n));
+    if (mem == IVX_MEM_HOST) IVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return IVX_OK;
+}
+
+extern "C" ivx_status ivx_take_utf8(ivx_ctx *ctx, int mem, int large, const void *offsets, const uint8_t *data, uint64_t n_src,
+                                    uint64_t src_data_bytes, const uint8_t *src_valid_bits, const uint32_t *idx, uint64_t n,
+                                    void *out_offsets, uint8_t *out_data, uint64_t data_cap, uint64_t *data_bytes, uint8_t *out_valid)
+{
+    if (!ctx) return IVX_ERR_INVALID;
+    if (!data_bytes) return ctx->fail(IVX_ERR_INVALID, "null data_bytes");
+    *data_bytes = 0;
+    if (mem != IVX_MEM_HOST && mem != IVX_MEM_DEVICE) return ctx->fail(IVX_ERR_INVALID, "bad mem");
+    if (n && !idx) return ctx->fail(IVX_ERR_INVALID, "take: null idx");
+    if (!offsets || (src_data_bytes && !data)) return ctx->fail(IVX_ERR_INVALID, "take: null source column");
+    IVX_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t ow = large ? 8 : 4;
+    const u8 *doff, *ddata, *dvalid; const u32 *didx; u8 *dooff, *dodata, *dov;
+    IVX_TRY(stage_in(ctx, mem, WS_IN_KEY, (const u8 *)offsets, (n_src + 1) * ow, &doff));
+    IVX_TRY(stage_in(ctx, mem, WS_IN_START, data, src_data_bytes, &ddata));
+    IVX_TRY(stage_in(ctx, mem, WS_IN_END, src_valid_bits, (n_src + 7) / 8, &dvalid));
+    IVX_TRY(stage_in(ctx, mem, WS_IN2_KEY, idx, n, &didx));
+    IVX_TRY(stage_out(ctx, mem, WS_OUT_A, (u8 *)out_offsets, (n + 1) * ow, &dooff));
+    IVX_TRY(stage_out(ctx, mem, WS_OUT_B, out_data, data_cap, &dodata));
+    IVX_TRY(stage_out(ctx, mem, WS_OUT_C, out_valid, n, &dov));
+    u64 total = 0;
+    {
+        KernelTimer t(ctx);
+        ivx_status st = ivx_take_utf8_device(ctx, large, doff, ddata, n_src, dvalid, didx, n, dooff, dodata, data_cap, &total, dov);
+        *data_bytes = total;
+        if (st != IVX_OK) return st;
+    }
+    IVX_TRY(copy_out(ctx, mem, (u8 *)out_offsets, dooff, (n + 1) * ow));
+    if (out_data) IVX_TRY(copy_out(ctx, mem, out_data, dodata, total));
+    IVX_TRY(copy_out(ctx, mem, out_valid, dov, n));
     if (mem == IVX_MEM_HOST) IVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return IVX_OK;
 }

@@ -1,0 +1,161 @@
+// ivx_take.hip -- f3: `compute::take` of payload columns on the device, the step right after the probe
+// (interval_join.rs:1655-1667 takes every projected build/probe column with left_idx / right_idx;
+// nearest.rs:469-482 does the same with a nullable left index).
+//
+//   fixed-width columns: one thread per output element; the index stream and the output are read and
+//     written coalesced, the source is a gather (payload columns of the BUILD side are small and stay
+//     in L2 / Infinity Cache; probe-side indices ascend, so that gather streams).
+//   Utf8 / LargeUtf8: lengths -> exclusive scan (= the output offsets) -> byte copy.  The copy is
+//     wavefront-cooperative: a wavefront takes 64 rows, prefix-sums their lengths and its lanes then
+//     walk the BYTES of those 64 strings, so output stores are consecutive bytes whatever the mix of
+//     string lengths, and one long string is spread over all lanes.
+//
+// Null handling as arrow's take: a null index (IVX_NULL_IDX) or a null source slot gives a null output
+// slot; the value bytes of a null-index slot are zero / the string is empty.
+#include "ivx_device.hpp"
+#include "ivx_scan.hpp"
+
+namespace {
+
+constexpr int TK = 256;
+
+__device__ __forceinline__ bool bit_at(const u8 *bits, u64 i) { return (bits[i >> 3] >> (i & 7)) & 1u; }
+
+template <typename V>
+__global__ __launch_bounds__(TK) void k_take_fixed(const V *__restrict__ src, u64 n_src, const u8 *__restrict__ src_valid,
+                                                   const u32 *__restrict__ idx, u64 n, V *__restrict__ out, u8 *__restrict__ out_valid, u32 *bad)
+{
+    for (u64 i = (u64)blockIdx.x * TK + threadIdx.x; i < n; i += (u64)gridDim.x * TK) {
+        const u32 j = idx[i];
+        V v{};
+        bool ok = j != IVX_NULL_IDX;
+        if (ok && j >= n_src) { *bad = 1; ok = false; }
+        if (ok) v = src[j];
+        out[i] = v;
+        if (out_valid) out_valid[i] = (ok && (!src_valid || bit_at(src_valid, j))) ? 1 : 0;
+    }
+}
+
+struct alignas(16) B32 { uint4 a, b; };
+
+template <typename O>
+__global__ __launch_bounds__(TK) void k_take_len(const O *__restrict__ off, u64 n_src, const u8 *__restrict__ src_valid,
+                                                 const u32 *__restrict__ idx, u64 n, u64 *__restrict__ len, u8 *__restrict__ out_valid, u32 *bad)
+{
+    for (u64 i = (u64)blockIdx.x * TK + threadIdx.x; i <= n; i += (u64)gridDim.x * TK) {
+        if (i == n) { len[i] = 0; continue; }
+        const u32 j = idx[i];
+        bool ok = j != IVX_NULL_IDX;
+        if (ok && j >= n_src) { *bad = 1; ok = false; }
+        len[i] = ok ? (u64)(off[j + 1] - off[j]) : 0;
+        if (out_valid) out_valid[i] = (ok && (!src_valid || bit_at(src_valid, j))) ? 1 : 0;
+    }
+}
+
+template <typename O>
+__global__ __launch_bounds__(TK) void k_take_offsets(const u64 *__restrict__ pos, u64 n, O *__restrict__ out_off)
+{
+    for (u64 i = (u64)blockIdx.x * TK + threadIdx.x; i <= n; i += (u64)gridDim.x * TK) out_off[i] = (O)pos[i];
+}
+
+template <typename O>
+__global__ __launch_bounds__(TK) void k_take_bytes(const O *__restrict__ off, const u8 *__restrict__ data, const u32 *__restrict__ idx, u64 n,
+                                                   const u64 *__restrict__ pos, u8 *__restrict__ out)
+{
+    __shared__ u64 s_ex[TK / IVX_WAVE][IVX_WAVE];
+    __shared__ u64 s_src[TK / IVX_WAVE][IVX_WAVE];
+    const u32 wv = threadIdx.x / IVX_WAVE, ln = lane_id();
+    const u64 ngroups = (n + IVX_WAVE - 1) / IVX_WAVE;
+    for (u64 g = (u64)blockIdx.x * (TK / IVX_WAVE) + wv; g < ngroups; g += (u64)gridDim.x * (TK / IVX_WAVE)) {
+        const u64 i = g * IVX_WAVE + ln;
+        const u64 p0 = pos[g * IVX_WAVE];                               // output byte position of the group
+        const u64 hi_row = (g + 1) * IVX_WAVE < n ? (g + 1) * IVX_WAVE : n;
+        const u64 total = pos[hi_row] - p0;                             // bytes of the group's strings
+        u64 so = 0, ex = ~0ull;
+        if (i < n) {
+            const u32 j = idx[i];
+            if (j != IVX_NULL_IDX) so = (u64)off[j];
+            ex = pos[i] - p0;
+        }
+        s_ex[wv][ln] = ex; s_src[wv][ln] = so;
+        __builtin_amdgcn_wave_barrier();
+        for (u64 t = ln; t < total; t += IVX_WAVE) {
+            u32 lo = 0, hi = IVX_WAVE - 1;                              // last row whose first byte is <= t
+            while (lo < hi) { const u32 mid = (lo + hi + 1) >> 1; if (s_ex[wv][mid] <= t) lo = mid; else hi = mid - 1; }
+            out[p0 + t] = data[s_src[wv][lo] + (t - s_ex[wv][lo])];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+u32 take_grid(u64 n) { return ivx_stream_grid(n, TK * 4, 256 * 16); }
+
+ivx_status take_flag(ivx_ctx *ctx)
+{
+    IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 8, ctx->d_scalars + 8, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+    IVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (*(u32 *)(ctx->h_scalars + 8)) return ctx->fail(IVX_ERR_INVALID, "take: index out of bounds");
+    return IVX_OK;
+}
+
+}  // namespace
+
+ivx_status ivx_take_fixed_device(ivx_ctx *ctx, const void *src, u32 width, u64 n_src, const u8 *src_valid,
+                                 const u32 *idx, u64 n, void *out, u8 *out_valid)
+{
+    hipStream_t st = ctx->stream;
+    IVX_HIP(ctx, hipMemsetAsync(ctx->d_scalars + 8, 0, sizeof(u64), st));
+    u32 *bad = (u32 *)(ctx->d_scalars + 8);
+    if (n) {
+        const u32 grid = take_grid(n);
+#define IVX_TAKE(V) hipLaunchKernelGGL(k_take_fixed<V>, dim3(grid), dim3(TK), 0, st, (const V *)src, n_src, src_valid, idx, n, (V *)out, out_valid, bad)
+        switch (width) {
+        case 1: IVX_TAKE(u8); break;
+        case 2: IVX_TAKE(unsigned short); break;
+        case 4: IVX_TAKE(u32); break;
+        case 8: IVX_TAKE(u64); break;
+        case 16: IVX_TAKE(uint4); break;
+        case 32: IVX_TAKE(B32); break;
+        default: return ctx->fail(IVX_ERR_UNSUPPORTED, "take: fixed width must be 1, 2, 4, 8, 16 or 32 bytes");
+        }
+#undef IVX_TAKE
+        IVX_HIP(ctx, hipGetLastError());
+    }
+    return take_flag(ctx);
+}
+
+// large != 0: 64-bit offsets (LargeUtf8 / LargeBinary).  out_offsets (n+1) is always written; the bytes only
+// when out_data is given and data_cap suffices (else IVX_ERR_CAPACITY with *data_bytes set).
+ivx_status ivx_take_utf8_device(ivx_ctx *ctx, int large, const void *offsets, const u8 *data, u64 n_src, const u8 *src_valid,
+                                const u32 *idx, u64 n, void *out_offsets, u8 *out_data, u64 data_cap, u64 *data_bytes, u8 *out_valid)
+{
+    hipStream_t st = ctx->stream;
+    *data_bytes = 0;
+    IVX_HIP(ctx, hipMemsetAsync(ctx->d_scalars + 8, 0, sizeof(u64), st));
+    u32 *bad = (u32 *)(ctx->d_scalars + 8);
+    u64 *pos;
+    IVX_TRY(ctx->get_scratch(WS_T0, (n + 1) * sizeof(u64), (void **)&pos));
+    const u32 grid = take_grid(n + 1);
+    if (large) hipLaunchKernelGGL(k_take_len<i64>, dim3(grid), dim3(TK), 0, st, (const i64 *)offsets, n_src, src_valid, idx, n, pos, out_valid, bad);
+    else hipLaunchKernelGGL(k_take_len<i32>, dim3(grid), dim3(TK), 0, st, (const i32 *)offsets, n_src, src_valid, idx, n, pos, out_valid, bad);
+    IVX_TRY(ivx_scan_exclusive_u64(ctx, pos, n + 1));
+    IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 5, pos + n, sizeof(u64), hipMemcpyDeviceToHost, st));
+    IVX_TRY(take_flag(ctx));                                                    // synchronises
+    const u64 total = ctx->h_scalars[5];
+    *data_bytes = total;
+    if (!large && total > 0x7FFFFFFFull) return ctx->fail(IVX_ERR_INVALID, "take: Utf8 offsets overflow i32 (use LargeUtf8)");
+    if (out_offsets) {
+        if (large) hipLaunchKernelGGL(k_take_offsets<i64>, dim3(grid), dim3(TK), 0, st, (const u64 *)pos, n, (i64 *)out_offsets);
+        else hipLaunchKernelGGL(k_take_offsets<i32>, dim3(grid), dim3(TK), 0, st, (const u64 *)pos, n, (i32 *)out_offsets);
+    }
+    if (!out_data) return IVX_OK;                                              // sizing call
+    if (total > data_cap) return ctx->fail(IVX_ERR_CAPACITY, "take: string data buffer too small");
+    if (total && n) {
+        const u64 ngroups = (n + IVX_WAVE - 1) / IVX_WAVE;
+        const u32 g2 = ivx_stream_grid(ngroups, TK / IVX_WAVE, 256 * 16);
+        if (large) hipLaunchKernelGGL(k_take_bytes<i64>, dim3(g2), dim3(TK), 0, st, (const i64 *)offsets, data, idx, n, (const u64 *)pos, out_data);
+        else hipLaunchKernelGGL(k_take_bytes<i32>, dim3(g2), dim3(TK), 0, st, (const i32 *)offsets, data, idx, n, (const u64 *)pos, out_data);
+    }
+    IVX_HIP(ctx, hipGetLastError());
+    return IVX_OK;
+}

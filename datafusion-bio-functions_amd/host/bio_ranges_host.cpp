@@ -504,3 +504,112 @@ extern "C" int brh_complement(brh_session *s, brh_batch table, brh_columns cols,
     make_primitive<int64_t>(end, oe.data(), (int64_t)m2, nullptr); make_schema(end_schema, "l", cols.end, false);
     return 0;
 }
+
+// ---- f3: payload gather
+namespace {
+
+// bytes per element of a fixed-width Arrow format string, 0 if it is not one we gather
+uint32_t fixed_width(const char *f)
+{
+    if (std::strlen(f) == 1) {
+        switch (f[0]) {
+        case 'c': case 'C': return 1;
+        case 's': case 'S': case 'e': return 2;
+        case 'i': case 'I': case 'f': return 4;
+        case 'l': case 'L': case 'g': return 8;
+        default: return 0;
+        }
+    }
+    if (!std::strncmp(f, "tdD", 3) || !std::strncmp(f, "tts", 3) || !std::strncmp(f, "ttm", 3)) return 4;      // date32, time32
+    if (!std::strncmp(f, "tdm", 3) || !std::strncmp(f, "ttu", 3) || !std::strncmp(f, "ttn", 3)) return 8;      // date64, time64
+    if (!std::strncmp(f, "ts", 2) || !std::strncmp(f, "tD", 2)) return 8;                                       // timestamp, duration
+    if (!std::strncmp(f, "d:", 2)) {                                                                            // decimal128 / decimal256
+        int commas = 0; const char *last = nullptr;
+        for (const char *q = f; *q; q++) if (*q == ',') { commas++; last = q; }
+        if (commas < 2) return 16;
+        const int bits = std::atoi(last + 1);
+        return bits == 128 ? 16 : bits == 256 ? 32 : 0;
+    }
+    if (!std::strncmp(f, "w:", 2)) { const int w = std::atoi(f + 2); return (w == 1 || w == 2 || w == 4 || w == 8 || w == 16 || w == 32) ? (uint32_t)w : 0; }
+    return 0;
+}
+
+// validity bitmap of `a` re-based to bit 0 (nullptr when there are no nulls)
+const uint8_t *rebased_validity(const ArrowArray *a, std::vector<uint8_t> *store)
+{
+    if (a->n_buffers < 1 || !a->buffers[0] || null_count(a) == 0) return nullptr;
+    const uint8_t *v = (const uint8_t *)a->buffers[0];
+    if (a->offset % 8 == 0) return v + a->offset / 8;
+    store->assign((size_t)(a->length + 7) / 8, 0);
+    for (int64_t i = 0; i < a->length; i++) { const int64_t j = i + a->offset; if ((v[j >> 3] >> (j & 7)) & 1) (*store)[i >> 3] |= (uint8_t)(1u << (i & 7)); }
+    return store->data();
+}
+
+void finish_array(ArrowArray *a, OutPriv *p, int64_t n, const uint8_t *valid_bytes, int n_buffers)
+{
+    uint8_t *bm = (uint8_t *)std::calloc((size_t)(n + 7) / 8 + 1, 1);
+    int64_t nulls = 0;
+    for (int64_t i = 0; i < n; i++) { if (valid_bytes[i]) bm[i >> 3] |= (uint8_t)(1u << (i & 7)); else nulls++; }
+    p->bufs.push_back(bm);
+    p->ptrs[0] = nulls ? bm : nullptr;
+    a->length = n; a->null_count = nulls; a->n_buffers = n_buffers; a->buffers = p->ptrs; a->private_data = p; a->release = release_array;
+}
+
+}  // namespace
+
+extern "C" int brh_take(brh_session *s, const ArrowArray *column, const ArrowSchema *column_schema,
+                        const ArrowArray *idx, const ArrowSchema *idx_schema, ArrowArray *out, ArrowSchema *out_schema)
+{
+    if (!s) return 1;
+    if (!column || !column_schema || !idx || !idx_schema || !out || !out_schema) return fail(s, "take: null argument");
+    if (std::strcmp(idx_schema->format, "I")) return fail(s, "take: the index array must be UInt32, got " + std::string(idx_schema->format));
+    const char *f = column_schema->format;
+    const int64_t n = idx->length;
+    // indices: nulls become IVX_NULL_IDX (nearest.rs:462: left index with a null buffer)
+    std::vector<uint32_t> ix((size_t)(n ? n : 1));
+    {
+        const uint32_t *iv = (const uint32_t *)idx->buffers[1] + idx->offset;
+        const uint8_t *vb = (idx->n_buffers > 0 && idx->buffers[0] && null_count(idx) > 0) ? (const uint8_t *)idx->buffers[0] : nullptr;
+        for (int64_t i = 0; i < n; i++) {
+            const int64_t j = i + idx->offset;
+            ix[i] = (vb && !((vb[j >> 3] >> (j & 7)) & 1)) ? IVX_NULL_IDX : iv[i];
+        }
+    }
+    std::vector<uint8_t> vstore, valid((size_t)(n ? n : 1));
+    const uint8_t *svb = rebased_validity(column, &vstore);
+    const uint64_t n_src = (uint64_t)column->length;
+    std::memset(out, 0, sizeof *out);
+    const bool str32 = !std::strcmp(f, "u") || !std::strcmp(f, "z"), str64 = !std::strcmp(f, "U") || !std::strcmp(f, "Z");
+    if (str32 || str64) {
+        const size_t ow = str64 ? 8 : 4;
+        const uint8_t *off = (const uint8_t *)column->buffers[1] + (size_t)column->offset * ow;
+        // the data buffer is addressed by absolute offsets, so it goes over whole: up to the last offset of the slice
+        const uint64_t nbytes = str64 ? (uint64_t)((const int64_t *)off)[n_src] : (uint64_t)((const int32_t *)off)[n_src];
+        void *ooff = std::malloc((size_t)(n + 1) * ow);
+        uint64_t need = 0;
+        ivx_status st = ivx_take_utf8(s->ctx, IVX_MEM_HOST, str64, off, (const uint8_t *)column->buffers[2], n_src, nbytes, svb, ix.data(), (uint64_t)n,
+                                      ooff, nullptr, 0, &need, valid.data());
+        uint8_t *odata = (uint8_t *)std::malloc((size_t)(need ? need : 1));
+        if (st == IVX_OK)
+            st = ivx_take_utf8(s->ctx, IVX_MEM_HOST, str64, off, (const uint8_t *)column->buffers[2], n_src, nbytes, svb, ix.data(), (uint64_t)n,
+                               ooff, odata, need ? need : 1, &need, valid.data());
+        if (st != IVX_OK) { std::free(ooff); std::free(odata); return fail_ivx(s, st); }
+        OutPriv *p = new OutPriv();
+        p->bufs.push_back(ooff); p->bufs.push_back(odata);
+        p->ptrs[1] = ooff; p->ptrs[2] = odata;
+        finish_array(out, p, n, valid.data(), 3);
+    } else {
+        const uint32_t w = fixed_width(f);
+        if (!w) return fail(s, "take: unsupported column type " + std::string(f) + " (fixed-width primitives and Utf8/LargeUtf8/Binary/LargeBinary only)");
+        const uint8_t *src = (const uint8_t *)column->buffers[1] + (size_t)column->offset * w;
+        void *o = std::malloc((size_t)(n ? n : 1) * w);
+        const ivx_status st = ivx_take_fixed(s->ctx, IVX_MEM_HOST, src, w, n_src, svb, ix.data(), (uint64_t)n, o, valid.data());
+        if (st != IVX_OK) { std::free(o); return fail_ivx(s, st); }
+        OutPriv *p = new OutPriv();
+        p->bufs.push_back(o);
+        p->ptrs[1] = o;
+        finish_array(out, p, n, valid.data(), 2);
+    }
+    make_schema(out_schema, f, column_schema->name ? column_schema->name : "", true);
+    return 0;
+}

@@ -25,7 +25,7 @@ SYMBOLS = [
     "ivx_ctx_last_kernel_ms", "ivx_version", "ivx_index_build", "ivx_index_free", "ivx_index_rows",
     "ivx_index_device_bytes", "ivx_probe_overlap_count", "ivx_probe_overlap_fill", "ivx_probe_exists",
     "ivx_probe_count", "ivx_probe_coverage", "ivx_probe_nearest", "ivx_merge", "ivx_subtract",
-    "ivx_cluster", "ivx_complement",
+    "ivx_cluster", "ivx_complement", "ivx_take_fixed", "ivx_take_utf8",
 ]
 
 
@@ -368,3 +368,60 @@ class Ctx:
         self._chk(lib().ivx_complement(self.h, *args, _ptr(ok), _ptr(os_), _ptr(oe), C.c_uint64(cap), C.byref(m2)))
         m2 = m2.value
         return ok[:m2], os_[:m2], oe[:m2]
+
+    # ---- f3: compute::take of payload columns ----
+    def take_fixed(self, src, idx, src_valid_bits=None, want_valid=True):
+        """src: 1-D array (numpy or torch) of a fixed-width type (1, 2, 4, 8, 16 or 32 bytes per element; wider
+        records as a 2-D uint8 array [n_src, width]); idx: uint32 rows, NULL_IDX = null.  -> (out, valid u8 or None)"""
+        dev = _is_torch(src)
+        if _is_torch(idx) != dev:
+            raise ValueError("mix of host and device buffers in one call")
+        if dev:
+            import torch
+            assert src.is_contiguous() and idx.is_contiguous()
+            n_src = src.shape[0]
+            width = src.element_size() * (src.shape[1] if src.dim() == 2 else 1)
+            n = int(idx.numel())
+            out = torch.empty((n,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+            valid = torch.empty(max(n, 1), dtype=torch.uint8, device=src.device) if want_valid else None
+            svb = src_valid_bits
+        else:
+            src = np.ascontiguousarray(src); idx = np.ascontiguousarray(idx, np.uint32)
+            n_src = src.shape[0]
+            width = src.dtype.itemsize * (src.shape[1] if src.ndim == 2 else 1)
+            n = len(idx)
+            out = np.empty((n,) + src.shape[1:], src.dtype)
+            valid = np.empty(max(n, 1), np.uint8) if want_valid else None
+            svb = None if src_valid_bits is None else np.ascontiguousarray(src_valid_bits, np.uint8)
+        self._chk(lib().ivx_take_fixed(self.h, C.c_int(MEM_DEVICE if dev else MEM_HOST), _ptr(src), C.c_uint32(width), C.c_uint64(n_src),
+                                        _ptr(svb), _ptr(idx), C.c_uint64(n), _ptr(out), _ptr(valid)))
+        return out, (valid[:n] if valid is not None else None)
+
+    def take_utf8(self, offsets, data, idx, src_valid_bits=None, want_valid=True):
+        """offsets: int32 (Utf8/Binary) or int64 (LargeUtf8/LargeBinary) [n_src+1]; data: uint8 bytes.
+        -> (out_offsets, out_data u8, valid u8 or None)"""
+        dev = _is_torch(offsets)
+        if dev:
+            import torch
+            large = offsets.dtype == torch.int64
+            n_src, nbytes, n = int(offsets.numel()) - 1, int(data.numel()), int(idx.numel())
+            mk = lambda m, dt: torch.empty(max(m, 1), dtype=dt, device=offsets.device)
+            odt, u8 = offsets.dtype, torch.uint8
+            svb = src_valid_bits
+        else:
+            offsets = np.ascontiguousarray(offsets); data = np.ascontiguousarray(data, np.uint8); idx = np.ascontiguousarray(idx, np.uint32)
+            large = offsets.dtype == np.int64
+            assert large or offsets.dtype == np.int32
+            n_src, nbytes, n = len(offsets) - 1, len(data), len(idx)
+            mk = lambda m, dt: np.empty(max(m, 1), dt)
+            odt, u8 = offsets.dtype, np.uint8
+            svb = None if src_valid_bits is None else np.ascontiguousarray(src_valid_bits, np.uint8)
+        mem = C.c_int(MEM_DEVICE if dev else MEM_HOST)
+        out_off = mk(n + 1, odt)
+        valid = mk(n, u8) if want_valid else None
+        need = C.c_uint64(0)
+        head = (self.h, mem, C.c_int(int(large)), _ptr(offsets), _ptr(data), C.c_uint64(n_src), C.c_uint64(nbytes), _ptr(svb), _ptr(idx), C.c_uint64(n))
+        self._chk(lib().ivx_take_utf8(*head, _ptr(out_off), None, C.c_uint64(0), C.byref(need), _ptr(valid)))
+        out_data = mk(need.value, u8)
+        self._chk(lib().ivx_take_utf8(*head, _ptr(out_off), _ptr(out_data), C.c_uint64(max(need.value, 1)), C.byref(need), _ptr(valid)))
+        return out_off[: n + 1], out_data[: need.value], (valid[:n] if valid is not None else None)

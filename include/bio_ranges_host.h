@@ -123,6 +123,16 @@ int brh_complement(brh_session *s, brh_batch table, brh_columns cols, brh_batch 
                    struct ArrowArray *start, struct ArrowSchema *start_schema,
                    struct ArrowArray *end, struct ArrowSchema *end_schema);
 
+/* compute::take of ONE payload column with an index array a join / nearest call returned
+ * (interval_join.rs:1655-1667, nearest.rs:469-482), on the device.  column: any fixed-width primitive
+ * (ints, floats, date/time/timestamp/duration, decimal128/256, fixed-size binary of 1/2/4/8/16/32 bytes)
+ * or Utf8 / LargeUtf8 / Binary / LargeBinary; idx: UInt32, nulls allowed (-> null output slots).
+ * Other layouts (bool bitmaps, views, nested, dictionary) return an error: the caller keeps them on
+ * its own take.  The output has the column's type and is nullable. */
+int brh_take(brh_session *s, const struct ArrowArray *column, const struct ArrowSchema *column_schema,
+             const struct ArrowArray *idx, const struct ArrowSchema *idx_schema,
+             struct ArrowArray *out, struct ArrowSchema *out_schema);
+
 /* the checks alone (no GPU): resolve a position column like PosArray::resolve / resolve_i64 would;
  * 0 = fine, else the error text is set.  Used by the CPU-only tests. */
 int brh_check_position_column(brh_session *s_or_null, brh_batch table, const char *column, int as_i64,

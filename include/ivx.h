@@ -205,6 +205,24 @@ ivx_status ivx_complement(ivx_ctx *ctx, int mem,
                           uint32_t *out_key, int64_t *out_start, int64_t *out_end,
                           uint64_t cap, uint64_t *n_out);
 
+/* ---- f3: `compute::take` of payload columns with the index arrays the probes return
+ *      (interval_join.rs:1655-1667, nearest.rs:469-482).  idx[i] == IVX_NULL_IDX or a null source
+ *      slot (src_valid_bits: Arrow validity bitmap of the source, bit offset 0, nullable) gives
+ *      out_valid[i] = 0 (one byte per output row, nullable) and zero bytes / an empty string;
+ *      any other idx[i] >= n_src is IVX_ERR_INVALID.
+ *      fixed: width = bytes per element, one of 1, 2, 4, 8, 16, 32. */
+ivx_status ivx_take_fixed(ivx_ctx *ctx, int mem, const void *src, uint32_t width, uint64_t n_src,
+                          const uint8_t *src_valid_bits, const uint32_t *idx, uint64_t n,
+                          void *out, uint8_t *out_valid);
+
+/*      Utf8 / Binary (large = 0, int32 offsets) and LargeUtf8 / LargeBinary (large = 1, int64).
+ *      out_offsets[n+1] is written whenever given; *data_bytes always returns the bytes needed.
+ *      out_data = NULL sizes only; data_cap < *data_bytes is IVX_ERR_CAPACITY. */
+ivx_status ivx_take_utf8(ivx_ctx *ctx, int mem, int large, const void *offsets, const uint8_t *data, uint64_t n_src,
+                         uint64_t src_data_bytes, const uint8_t *src_valid_bits, const uint32_t *idx, uint64_t n,
+                         void *out_offsets, uint8_t *out_data, uint64_t data_cap, uint64_t *data_bytes,
+                         uint8_t *out_valid);
+
 #ifdef __cplusplus
 }
 #endif

@@ -202,6 +202,38 @@ def complement(key, s, e, vkey=None, vs=None, ve=None, strict=False):
     return ok, os_, oe
 
 
+def take_fixed(src, idx, src_valid=None):
+    """f3: arrow `compute::take` on a fixed-width column (interval_join.rs:1655-1667, nearest.rs:469-482):
+    out[i] = src[idx[i]]; a NULL_IDX index or a null source slot gives a null output slot (valid 0),
+    a NULL_IDX slot holds zero bytes.  -> (out, valid u8)"""
+    src = np.asarray(src); idx = np.asarray(idx, np.uint32)
+    null = idx == NULL_IDX
+    if (idx[~null] >= len(src)).any():
+        raise IndexError("take: index out of bounds")
+    safe = np.where(null, 0, idx).astype(np.int64)
+    out = src[safe].copy() if len(src) else np.zeros((len(idx),) + src.shape[1:], src.dtype)
+    out[null] = 0
+    valid = ~null
+    if src_valid is not None:
+        valid = np.asarray(src_valid, bool)[safe] & ~null
+    return out, valid.astype(np.uint8)
+
+
+def take_utf8(offsets, data, idx, src_valid=None):
+    """same for Utf8/LargeUtf8: -> (out_offsets, out_data u8, valid u8); a NULL_IDX slot is an empty string."""
+    offsets = np.asarray(offsets); data = np.asarray(data, np.uint8); idx = np.asarray(idx, np.uint32)
+    null = idx == NULL_IDX
+    safe = np.where(null, 0, idx).astype(np.int64)
+    lens = np.where(null, 0, offsets[safe + 1] - offsets[safe]) if len(idx) else np.zeros(0, offsets.dtype)
+    out_off = np.concatenate([[0], np.cumsum(lens)]).astype(offsets.dtype)
+    parts = [data[offsets[j]:offsets[j + 1]] for j, nl in zip(safe, null) if not nl]
+    out_data = np.concatenate(parts) if parts else np.zeros(0, np.uint8)
+    valid = ~null
+    if src_valid is not None:
+        valid = np.asarray(src_valid, bool)[safe] & ~null
+    return out_off, out_data, valid.astype(np.uint8)
+
+
 def check_i32(v):
     v = _c64(v)
     return int(lib().orc_check_i32(_p(v), C.c_uint64(len(v))))

@@ -197,3 +197,39 @@ def test_complement_udtf(ctx, golden):
     v = pa.table({"c": ["a"], "b": [0], "x": [500]})
     out = ctx.complement(t, v, cols=("chr", "s", "e"), view_cols=("c", "b", "x"))   # :3093-3134, view with its own column names
     assert out.schema.names == ["chr", "s", "e"] and _rows(out) == [["a", 0, 100], ["a", 200, 500]]
+
+
+def test_device_take_matches_arrow_take(ctx):
+    import datetime
+    import decimal
+    import pyarrow.compute as pc
+    n = 257
+    cols = {
+        "i8": pa.array([None if i % 9 == 0 else i % 100 for i in range(n)], pa.int8()),
+        "u16": pa.array(range(n), pa.uint16()),
+        "f32": pa.array([i / 7 for i in range(n)], pa.float32()),
+        "f64": pa.array([None if i % 5 == 0 else i / 3 for i in range(n)], pa.float64()),
+        "ts": pa.array([datetime.datetime(2020, 1, 1) + datetime.timedelta(hours=i) for i in range(n)], pa.timestamp("us")),
+        "d32": pa.array([datetime.date(2000, 1, 1) + datetime.timedelta(days=i) for i in range(n)], pa.date32()),
+        "dec": pa.array([decimal.Decimal(i) / 100 for i in range(n)], pa.decimal128(12, 2)),
+        "gene": pa.array([None if i % 11 == 0 else "gene%d" % i * (i % 4) for i in range(n)], pa.string()),
+        "big": pa.array(["x" * (i % 50) for i in range(n)], pa.large_string()),
+        "bin": pa.array([bytes([i % 256]) * (i % 6) for i in range(n)], pa.binary()),
+    }
+    t = pa.table(cols).slice(3)                                       # non-zero offsets into every buffer, bitmaps included
+    idx = pa.array([None if i % 13 == 0 else (i * 7) % t.num_rows for i in range(1000)], pa.uint32())
+    for name in t.schema.names:
+        got, want = ctx.take(t.column(name), idx), pc.take(t.column(name), idx)
+        assert got.type == want.type and got.to_pylist() == want.combine_chunks().to_pylist(), name
+    with pytest.raises(br.BioRangesError, match="unsupported column type"):
+        ctx.take(pa.array([True, False]), pa.array([0], pa.uint32()))
+    with pytest.raises(br.BioRangesError, match="out of bounds"):
+        ctx.take(pa.array([1, 2]), pa.array([2], pa.uint32()))
+
+
+def test_sql_range_join_with_device_take(ctx, golden):
+    reads, targets = table(golden.tables["reads"]), table(golden.tables["targets"])
+    reads = reads.append_column("name", pa.array(["r%d" % i for i in range(reads.num_rows)]))
+    a = ctx.sql_range_join(reads, targets, device_take=True)
+    b = ctx.sql_range_join(reads, targets, device_take=False)
+    assert a.schema.names == b.schema.names and rows_of(a, a.schema.names) == rows_of(b, b.schema.names) and a.num_rows == 16

@@ -190,6 +190,28 @@ def test_complement_golden(golden):
         assert got == case["expect"], case["name"]
 
 
+def test_take_matches_arrow_take():
+    # f3: the restatement of `compute::take` against pyarrow's implementation of the same Arrow kernel
+    import pyarrow as pa
+    import pyarrow.compute as pc
+    rng = np.random.default_rng(0)
+    vals = rng.integers(-50, 50, 300).astype(np.int32); mask = rng.random(300) < 0.2
+    idx = rng.integers(0, 300, 2000).astype(np.uint32); idx[::7] = orc.NULL_IDX
+    pidx = pa.array(idx, mask=idx == orc.NULL_IDX)
+    out, valid = orc.take_fixed(vals, idx, src_valid=~mask)
+    assert pa.array(out, mask=valid == 0).equals(pc.take(pa.array(vals, mask=mask), pidx))
+    py = [None if i % 11 == 0 else "s" * (i % 9) + str(i) for i in range(300)]
+    col = pa.array(py)
+    vb, ob, db = col.buffers()
+    off = np.frombuffer(ob, np.int32)[:301]
+    sv = np.unpackbits(np.frombuffer(vb, np.uint8), bitorder="little")[:300]
+    o, d, v = orc.take_utf8(off, np.frombuffer(db, np.uint8), idx, src_valid=sv)
+    got = pa.Array.from_buffers(pa.string(), len(idx), [pa.py_buffer(np.packbits(v, bitorder="little")), pa.py_buffer(o), pa.py_buffer(d)])
+    assert got.to_pylist() == pc.take(col, pidx).to_pylist()
+    with pytest.raises(IndexError):
+        orc.take_fixed(vals, np.array([300], np.uint32))
+
+
 def test_check_i32():
     # array_utils.rs:33-66: first offending row is reported
     assert orc.check_i32([1, 2, 3]) == -1

@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "datafusion-bio-functions_amd"))
 import pyivx, synth
 dev = torch.device("cuda:0")
-which = os.environ.get("OPS", "count,coverage,nearest,merge,subtract,cluster,complement").split(",")
+which = os.environ.get("OPS", "count,coverage,nearest,merge,subtract,cluster,complement,take").split(",")
 scale = float(os.environ.get("SCALE", "1"))
 ctx = pyivx.Ctx(0); ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 
@@ -75,3 +75,21 @@ if "merge" in which or "subtract" in which or "cluster" in which or "complement"
                 m = out[0].numel()
                 report(f"complement {tag} {nn} (count+fill)", tc, 20 * nn + 20 * m, f"out rows {m}")
                 del out
+if "take" in which:
+    # payload gather for the headline join's 37M pairs: build-side column (1M rows, random indices),
+    # probe-side column (100M rows, ascending-ish indices), a 12-byte string column of the build side
+    npairs, nb, npr = int(37_000_000 * scale), int(1_000_000 * scale), int(100_000_000 * scale)
+    g = torch.Generator(device=dev).manual_seed(7)
+    bi = torch.randint(0, nb, (npairs,), generator=g, device=dev, dtype=torch.int32)
+    pi = torch.sort(torch.randint(0, npr, (npairs,), generator=g, device=dev, dtype=torch.int32)).values
+    for name, src, idx in (("take i64 build col", torch.arange(nb, device=dev, dtype=torch.int64), bi),
+                           ("take i32 probe col", torch.arange(npr, device=dev, dtype=torch.int32), pi),
+                           ("take i64 probe col", torch.arange(npr, device=dev, dtype=torch.int64), pi)):
+        t, out = timed(lambda: ctx.take_fixed(src, idx, want_valid=False))
+        w = src.element_size()
+        report(f"{name} {npairs}", t, (4 + 2 * w) * npairs, f"kernel {ctx.last_kernel_ms():.3f} ms")
+        del out
+    off = torch.arange(0, 12 * (nb + 1), 12, device=dev, dtype=torch.int32)
+    data = torch.randint(65, 90, (12 * nb,), generator=g, device=dev, dtype=torch.uint8)
+    t, out = timed(lambda: ctx.take_utf8(off, data, bi, want_valid=False))
+    report(f"take utf8(12B) build col {npairs} (size+fill)", t, (4 + 4 + 24) * npairs, f"bytes {out[1].numel()}")
