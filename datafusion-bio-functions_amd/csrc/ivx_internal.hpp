@@ -131,8 +131,9 @@ struct ivx_index {
     RankGridView gs{}, ge{};
     CoverageView cv{};
     NearestView nv{};
-    int flags = 0;
+    int flags = 0;              // IVX_IXF_*
 };
+enum { IVX_IXF_REGION_ROWVAL = 1 };   // count/coverage index: jv is usable for the region-partitioned per-row probe
 
 // ---------------------------------------------------------------- internal API
 // scan.hip
@@ -149,5 +150,10 @@ enum { JP_COUNT = 0, JP_PER_ROW = 1, JP_EXISTS = 2, JP_FILL = 3 };
 ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, int mode,
                                   const u32 *key, const i32 *s, const i32 *e, u64 n,
                                   u32 *ob, u32 *op, u64 cap, u64 *d_cursor);
+
+// per-row-output operators through the same partition (count_overlaps: jv over the build rows, no row with
+// end < start; coverage: jv over the merged nodes)
+ivx_status ivx_rowval_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, int coverage,
+                                    const u32 *key, const i32 *s, const i32 *e, u64 n, int strict, i64 *out);
 
 ivx_status ivx_index_alloc(ivx_ctx *ctx, ivx_index *ix, size_t bytes, void **out);

@@ -94,9 +94,11 @@ __device__ __forceinline__ void load4(const u32 *__restrict__ pkey, const i32 *_
     }
 }
 
+// adj = 1 for the UDTFs' strict mode: the query is shrunk to [start+1, end-1] before anything else
+// (interval_tree.rs:185-188, :253-256; i32 wrapping like the reference's release build)
 template <bool VEC>
 __global__ __launch_bounds__(PA_T) void k_part_hist(JoinIndexView ix, const u32 *__restrict__ pkey, const i32 *__restrict__ ps,
-                                                    u64 n, u32 nblk, u32 *__restrict__ hist)
+                                                    u64 n, u32 nblk, u32 *__restrict__ hist, u32 adj)
 {
     __shared__ u32 cnt[256];
     __shared__ i32 s_origin[KT_MAX];
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(PA_T) void k_part_hist(JoinIndexView ix, const u32 
         load4<VEC>(pkey, ps, nullptr, i, hi, k, q, unused);
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const u32 d = region_of(ix, kt, k[u], q[u]);
+            const u32 d = region_of(ix, kt, k[u], (i32)((u32)q[u] + adj));
             if (d != NO_REGION) atomicAdd(&cnt[d], 1u);
         }
     }
@@ -124,13 +126,16 @@ __global__ __launch_bounds__(PA_T) void k_part_hist(JoinIndexView ix, const u32 
 
 // order inside a region is irrelevant (the reference pins only the pair multiset), so the local
 // rank of a row is just the value an LDS counter held when the row arrived
-template <bool VEC>
+// RowT = u32: the row's index in the probe batch (join: it goes into the pair list);
+// RowT = u16: its index inside this workgroup's 32768-row chunk (per-row-output operators: k_unpermute
+// puts the chunk back in input order through LDS, so the chunk-local index is all that is needed)
+template <bool VEC, typename RowT>
 __global__ __launch_bounds__(PA_T) void k_part_scatter(JoinIndexView ix, const u32 *__restrict__ pkey, const i32 *__restrict__ ps,
                                                        const i32 *__restrict__ pe, u64 n, u32 nblk, const u32 *__restrict__ offs,
-                                                       u64 *__restrict__ out_se, u32 *__restrict__ out_row, int dbg)
+                                                       u64 *__restrict__ out_se, RowT *__restrict__ out_row, u32 adj, int dbg)
 {
     __shared__ u64 r_se[PA_TILE];
-    __shared__ u32 r_row[PA_TILE];
+    __shared__ RowT r_row[PA_TILE];
     __shared__ unsigned char r_dig[PA_TILE];
     __shared__ u32 tcnt[256], dstart[256], gbase[256];
     __shared__ u32 scan_lds[PA_T / IVX_WAVE + 1];
@@ -158,6 +163,7 @@ __global__ __launch_bounds__(PA_T) void k_part_scatter(JoinIndexView ix, const u
         }
 #pragma unroll
         for (int k = 0; k < PA_I; k++) {
+            qs[k] = (i32)((u32)qs[k] + adj); qe[k] = (i32)((u32)qe[k] - adj);
             se[k] = (u64)(u32)qs[k] | ((u64)(u32)qe[k] << 32);
             const u32 d = region_of(ix, kt, kk[k], qs[k]);
             dig[k] = d;
@@ -174,7 +180,7 @@ __global__ __launch_bounds__(PA_T) void k_part_scatter(JoinIndexView ix, const u
             if (dig[k] != NO_REGION) {
                 const u32 pos = dstart[dig[k]] + lrank[k];
                 r_se[pos] = se[k];
-                r_row[pos] = (u32)(t0 + ((u64)(k / 4) * PA_T + tid) * 4 + (k % 4));
+                r_row[pos] = (RowT)(t0 - (sizeof(RowT) == 2 ? lo : 0) + ((u64)(k / 4) * PA_T + tid) * 4 + (k % 4));
                 r_dig[pos] = (unsigned char)dig[k];
             }
         }
@@ -226,8 +232,8 @@ struct Slice {
     i32 origin; u32 span;
 };
 
-// every match of one probe row: f(v, is_slot) -- v is a slot of the staged slice (build row = s_row[v])
-// when is_slot, else the build row itself (general path)
+// every match of one probe row: f(v, is_slot, start, end) -- v is a slot of the staged slice (build row =
+// s_row[v]) when is_slot, else the build row itself (general path); start/end are the match's coordinates
 template <class F>
 __device__ __forceinline__ void probe_row(const Slice &S, i32 qs, i32 qe, F &&f)
 {
@@ -247,13 +253,13 @@ __device__ __forceinline__ void probe_row(const Slice &S, i32 qs, i32 qe, F &&f)
                     const u32 a = S.s_off[blo - S.slo], b = S.s_off[bhi + 1 - S.slo];
                     for (u32 j = a; j < b; j++) {
                         const u64 x = S.s_ent[j];
-                        if ((i32)(u32)x <= qe && (i32)(u32)(x >> 32) >= qs) f(j, true);
+                        if ((i32)(u32)x <= qe && (i32)(u32)(x >> 32) >= qs) f(j, true, (i32)(u32)x, (i32)(u32)(x >> 32));
                     }
                 } else {
                     const u32 a = ix.binstart[S.lb + blo], b = ix.binstart[S.lb + bhi + 1];
                     for (u32 j = a; j < b; j++) {
                         const ivx_ent x = ix.ent[j];
-                        if (x.s <= qe && x.e >= qs) f(x.row, false);
+                        if (x.s <= qe && x.e >= qs) f(x.row, false, x.s, x.e);
                     }
                 }
             }
@@ -278,7 +284,7 @@ __device__ __forceinline__ void probe_row(const Slice &S, i32 qs, i32 qe, F &&f)
             const u32 a = ix.binstart[base + blo], b = ix.binstart[base + bhi + 1];
             for (u32 j = a; j < b; j++) {
                 const ivx_ent x = ix.ent[j];
-                if (x.s <= qe && x.e >= qs) f(x.row, false);
+                if (x.s <= qe && x.e >= qs) f(x.row, false, x.s, x.e);
             }
         }
     }
@@ -364,7 +370,7 @@ __device__ __forceinline__ u32 batch_walk(const Slice &S, const ProbeLds &L, con
         for (int q = 0; q < RP_B; q++) {
             if (!((okmask >> q) & 1u)) continue;
             if (dbg & 4) tsum += (u32)(qs[q] ^ qe[q]) & 1u;
-            else probe_row(S, qs[q], qe[q], [&](u32, bool) { tsum++; });
+            else probe_row(S, qs[q], qe[q], [&](u32, bool, i32, i32) { tsum++; });
         }
         return tsum;
     }
@@ -374,7 +380,7 @@ __device__ __forceinline__ u32 batch_walk(const Slice &S, const ProbeLds &L, con
 #pragma unroll
     for (int q = 0; q < RP_B; q++) {
         if (!((okmask >> q) & 1u)) continue;
-        probe_row(S, qs[q], qe[q], [&](u32 v, bool sl) {
+        probe_row(S, qs[q], qe[q], [&](u32 v, bool sl, i32, i32) {
             const u32 pos = __hip_atomic_fetch_add(cp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (pos - ring_tail < RP_RING && !(dbg & 64))
                 L.s_q[wv][pos & (RP_RING - 1)] = (u64)(sl ? S.s_row[v] : v) | ((u64)rowv[q] << 32);
@@ -391,13 +397,45 @@ __device__ __forceinline__ u32 batch_walk(const Slice &S, const ProbeLds &L, con
 #pragma unroll
     for (int q = 0; q < RP_B; q++) {
         if (!((okmask >> q) & 1u)) continue;
-        probe_row(S, qs[q], qe[q], [&](u32 v, bool sl) {
+        probe_row(S, qs[q], qe[q], [&](u32 v, bool sl, i32, i32) {
             const u32 pos = __hip_atomic_fetch_add(cp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - base - wtot;
             if (direct_ok) { ob[own + pos] = sl ? S.s_row[v] : v; op[own + pos] = rowv[q]; }
         });
     }
     ring_start = base + 2 * wtot;
     return 0u;
+}
+
+// Per-row-output operators on the same slices: the row's value instead of its pairs.
+//   RV_COUNT     count_overlaps: 0 if qe < qs (interval_tree.rs:42-44), else the number of build rows the
+//                literal predicate matches -- equal to #{starts <= qe} - #{ends < qs} (:45-48) whenever no
+//                build row has end < start, which is when the host takes this path
+//   RV_COVERAGE  get_coverage over the merged nodes: sum of max(1, min(qe+1, last) - max(qs-1, first)) in
+//                wrapping i32 arithmetic (:145-152)
+enum { RV_COUNT = 2, RV_COVERAGE = 3 };
+
+__device__ __forceinline__ i32 rv_wadd(i32 a, i32 b) { return (i32)((u32)a + (u32)b); }
+__device__ __forceinline__ i32 rv_wsub(i32 a, i32 b) { return (i32)((u32)a - (u32)b); }
+
+template <int KIND>
+__device__ __forceinline__ void batch_rowval(const Slice &S, const i32 (&qs)[RP_B], const i32 (&qe)[RP_B], u32 okmask, u32 (&val)[RP_B])
+{
+#pragma unroll
+    for (int q = 0; q < RP_B; q++) {
+        u32 v = 0;
+        if ((okmask >> q) & 1u) {
+            if (KIND == RV_COUNT) {
+                if (!(qe[q] < qs[q])) probe_row(S, qs[q], qe[q], [&](u32, bool, i32, i32) { v++; });
+            } else {
+                const i32 a = rv_wadd(qe[q], 1), b = rv_wsub(qs[q], 1);
+                probe_row(S, qs[q], qe[q], [&](u32, bool, i32 first, i32 last) {
+                    const i32 d = rv_wsub(a < last ? a : last, b > first ? b : first);
+                    v = (u32)rv_wadd((i32)v, d > 1 ? d : 1);
+                });
+            }
+        }
+        val[q] = v;
+    }
 }
 
 // Fill pass, output reservation without workgroup barriers.  Wavefronts run the rounds of a workgroup
@@ -460,15 +498,18 @@ __device__ __forceinline__ void round_copy_out(const ProbeLds &L, u32 mine, u32 
 // Persistent workgroups: the partitioned probe rows are cut into equal row shares ("virtual
 // workgroups"), a workgroup walks its share region segment by region segment, and inside a segment
 // wavefront w owns batches w, w+16, ... of RP_WB rows.
-//   FILL = false (ivx_probe_overlap_count): wavefronts never synchronise; one atomicAdd of the
-//           wavefront's total at the end.
-//   FILL = true : single walk, see batch_walk / round_publish / round_copy_out.
-template <bool FILL>
+//   MODE 0 (ivx_probe_overlap_count): wavefronts never synchronise; one atomicAdd of the wavefront's
+//           total at the end.
+//   MODE 1 (fill): single walk, see batch_walk / round_publish / round_copy_out.
+//   MODE RV_COUNT / RV_COVERAGE: one 32-bit value per row, written at the row's partitioned position
+//           (`ob`), no synchronisation at all; k_unpermute puts the values back in input order.
+template <int MODE>
 __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const u64 *__restrict__ pse, const u32 *__restrict__ prow,
                                                         const u32 *__restrict__ offs, u32 nblk, u32 vpb,
                                                         u32 *__restrict__ ob, u32 *__restrict__ op, u64 cap,
                                                         unsigned long long *cursor, int dbg)
 {
+    constexpr bool FILL = MODE == 1;
     IVX_PROBE_LDS(FILL)
     const u32 wv = threadIdx.x / IVX_WAVE, ln = lane_id();
     const u32 nreg = ix.hdr[HDR_NREG];
@@ -523,9 +564,17 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
                             nxr[q] = (FILL && i < c_hi) ? prow[i] : 0u;
                         }
                     }
+                    if (MODE >= RV_COUNT) {
+                        u32 val[RP_B];
+                        batch_rowval<MODE>(S, qs, qe, okmask, val);
+#pragma unroll
+                        for (int q = 0; q < RP_B; q++)
+                            if ((okmask >> q) & 1u) ob[b0 + (u64)q * IVX_WAVE + ln] = val[q];
+                        continue;
+                    }
                     u32 start = 0;
                     const u32 got = batch_walk<FILL>(S, L, qs, qe, rowv, okmask, wv, pend_start, start, ob, op, cap, cursor, dbg);
-                    if (!FILL) { wcur += got; continue; }
+                    if (MODE == 0) { wcur += got; continue; }
                     if (!(dbg & 32)) {
                         round_publish(L, got, round, wv, cursor);
                         if (round) round_copy_out(L, pend_mine, pend_start, round - 1, wv, ob, op, cap, dbg);
@@ -535,7 +584,7 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
                 lo = c_hi;
             }
         }
-        if (!FILL) {
+        if (MODE == 0) {
             const u64 tot = wave_sum(wcur);
             if (ln == 0 && tot) atomicAdd(cursor, (unsigned long long)tot);
         }
@@ -543,7 +592,81 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
     if (FILL && round && !(dbg & 32)) round_copy_out(L, pend_mine, pend_start, round - 1, wv, ob, op, cap, dbg);
 }
 
+// ------------------------------------------------------------------ values back into input order
+// The scatter wrote, for every (region, workgroup chunk), one contiguous run, and kept each row's index
+// inside its 32768-row chunk.  So the values of one chunk are ~200 runs of the value stream: read them
+// (each wavefront a contiguous 1/16 of the chunk's values, coalesced inside runs), drop them at their
+// chunk-local index in LDS, write the chunk out in input order.  Rows that were never routed (unknown key,
+// key without build rows) keep the zero LDS was cleared to -- the reference's answer for them.
+constexpr u32 UP_CHUNK = (u32)PA_CHUNK;
+
+template <bool SIGNED>
+__global__ __launch_bounds__(PA_T) void k_unpermute(const u32 *__restrict__ val, const unsigned short *__restrict__ cidx,
+                                                    const u32 *__restrict__ offs, u32 nblk, u32 nreg, u64 n, i64 *__restrict__ out)
+{
+    __shared__ u32 s_val[UP_CHUNK];
+    __shared__ u32 s_pre[PA_ND + 1], s_g[PA_ND];
+    __shared__ u32 scan_lds[PA_T / IVX_WAVE + 1];
+    const u32 tid = threadIdx.x, blk = blockIdx.x;
+    const u64 lo = (u64)blk * PA_CHUNK;
+    const u32 len = (u32)(lo + PA_CHUNK < n ? PA_CHUNK : n - lo);
+    u32 c = 0, g = 0;
+    if (tid < nreg) { g = offs[(u64)tid * nblk + blk]; c = offs[(u64)tid * nblk + blk + 1] - g; }
+    u32 tot;
+    const u32 ex = block_excl_scan<u32, PA_T>(c, scan_lds, &tot);
+    if (tid < PA_ND) { s_pre[tid] = ex; s_g[tid] = g; }
+    if (tid == 0) s_pre[PA_ND] = tot;
+    for (u32 t = tid; t < UP_CHUNK; t += PA_T) s_val[t] = 0;
+    __syncthreads();
+    // wavefront w owns elements [w*per, (w+1)*per) of the chunk's region-major value list
+    const u32 wv = tid / IVX_WAVE, ln = lane_id();
+    const u32 per = (tot + PA_T / IVX_WAVE - 1) / (PA_T / IVX_WAVE);
+    const u32 t_lo = wv * per, t_hi = t_lo + per < tot ? t_lo + per : tot;
+    u32 r = 0;
+    if (t_lo < t_hi) { u32 a = 0, b = PA_ND; while (a < b) { const u32 m = (a + b + 1) >> 1; if (s_pre[m] <= t_lo + ln && m < PA_ND) a = m; else b = m - 1; } r = a; }
+    for (u32 t = t_lo + ln; t < t_hi; t += IVX_WAVE) {
+        while (r + 1 < PA_ND && s_pre[r + 1] <= t) r++;
+        const u64 at = (u64)s_g[r] + (t - s_pre[r]);
+        s_val[cidx[at]] = val[at];
+    }
+    __syncthreads();
+    for (u32 t = tid; t < len; t += PA_T)
+        out[lo + t] = SIGNED ? (i64)(i32)s_val[t] : (i64)s_val[t];
+}
+
 }  // namespace
+
+// count_overlaps / coverage through the region partition: jv indexes the build rows (count) or the merged
+// nodes (coverage); out[i] for every probe row, in input order.
+ivx_status ivx_rowval_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, int coverage,
+                                    const u32 *key, const i32 *s, const i32 *e, u64 n, int strict, i64 *out)
+{
+    if (n == 0) return IVX_OK;
+    hipStream_t st = ctx->stream;
+    const u32 nblk = (u32)((n + PA_CHUNK - 1) / PA_CHUNK);
+    u32 *hist, *val; u64 *pse; unsigned short *cidx;
+    const u64 nh = (u64)256 * nblk + 1;
+    IVX_TRY(ctx->get_scratch(WS_SORTHIST, nh * sizeof(u32), (void **)&hist));
+    IVX_TRY(ctx->get_scratch(WS_T0, n * sizeof(u64), (void **)&pse));
+    IVX_TRY(ctx->get_scratch(WS_T1, n * sizeof(unsigned short), (void **)&cidx));
+    IVX_TRY(ctx->get_scratch(WS_T2, n * sizeof(u32), (void **)&val));
+    IVX_HIP(ctx, hipMemsetAsync(hist + (nh - 1), 0, sizeof(u32), st));
+    const u32 adj = strict ? 1u : 0u;
+    const bool vec = (((uintptr_t)key | (uintptr_t)s | (uintptr_t)e) & 15) == 0;
+    if (vec) hipLaunchKernelGGL(k_part_hist<true>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, n, nblk, hist, adj);
+    else hipLaunchKernelGGL(k_part_hist<false>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, n, nblk, hist, adj);
+    IVX_TRY(ivx_scan_exclusive_u32(ctx, hist, nh));
+    if (vec) hipLaunchKernelGGL((k_part_scatter<true, unsigned short>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, cidx, adj, 0);
+    else hipLaunchKernelGGL((k_part_scatter<false, unsigned short>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, cidx, adj, 0);
+    if (coverage)
+        hipLaunchKernelGGL(k_probe_regions<RV_COVERAGE>, dim3(RP_VGRID), dim3(RP_T), 0, st, jv, (const u64 *)pse, (const u32 *)nullptr, (const u32 *)hist, nblk, 1u, val, (u32 *)nullptr, (u64)0, (unsigned long long *)nullptr, 0);
+    else
+        hipLaunchKernelGGL(k_probe_regions<RV_COUNT>, dim3(RP_VGRID), dim3(RP_T), 0, st, jv, (const u64 *)pse, (const u32 *)nullptr, (const u32 *)hist, nblk, 1u, val, (u32 *)nullptr, (u64)0, (unsigned long long *)nullptr, 0);
+    if (coverage) hipLaunchKernelGGL(k_unpermute<true>, dim3(nblk), dim3(PA_T), 0, st, (const u32 *)val, (const unsigned short *)cidx, (const u32 *)hist, nblk, (u32)PA_ND, n, out);
+    else hipLaunchKernelGGL(k_unpermute<false>, dim3(nblk), dim3(PA_T), 0, st, (const u32 *)val, (const unsigned short *)cidx, (const u32 *)hist, nblk, (u32)PA_ND, n, out);
+    IVX_HIP(ctx, hipGetLastError());
+    return IVX_OK;
+}
 
 ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, int mode,
                                   const u32 *key, const i32 *s, const i32 *e, u64 n,
@@ -560,16 +683,16 @@ ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, int mod
     IVX_HIP(ctx, hipMemsetAsync(hist + (nh - 1), 0, sizeof(u32), st));
     const int dbg = getenv("IVX_DBG") ? atoi(getenv("IVX_DBG")) : 0;   // ablation switches for profiling only
     const bool vec = (((uintptr_t)key | (uintptr_t)s | (uintptr_t)e) & 15) == 0;
-    if (vec) hipLaunchKernelGGL(k_part_hist<true>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, n, nblk, hist);
-    else hipLaunchKernelGGL(k_part_hist<false>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, n, nblk, hist);
+    if (vec) hipLaunchKernelGGL(k_part_hist<true>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, n, nblk, hist, 0u);
+    else hipLaunchKernelGGL(k_part_hist<false>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, n, nblk, hist, 0u);
     IVX_TRY(ivx_scan_exclusive_u32(ctx, hist, nh));
-    if (vec) hipLaunchKernelGGL(k_part_scatter<true>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, prow, dbg);
-    else hipLaunchKernelGGL(k_part_scatter<false>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, prow, dbg);
+    if (vec) hipLaunchKernelGGL((k_part_scatter<true, u32>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, prow, 0u, dbg);
+    else hipLaunchKernelGGL((k_part_scatter<false, u32>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, prow, 0u, dbg);
     unsigned long long *cur = (unsigned long long *)d_cursor;
     if (mode == JP_FILL)     // single walk: pairs staged per wavefront, one output reservation per workgroup and round
-        hipLaunchKernelGGL(k_probe_regions<true>, dim3(RP_GRID), dim3(RP_T), 0, st, jv, (const u64 *)pse, (const u32 *)prow, (const u32 *)hist, nblk, RP_VGRID / RP_GRID, ob, op, cap, cur, dbg);
+        hipLaunchKernelGGL(k_probe_regions<1>, dim3(RP_GRID), dim3(RP_T), 0, st, jv, (const u64 *)pse, (const u32 *)prow, (const u32 *)hist, nblk, RP_VGRID / RP_GRID, ob, op, cap, cur, dbg);
     else
-        hipLaunchKernelGGL(k_probe_regions<false>, dim3(RP_VGRID), dim3(RP_T), 0, st, jv, (const u64 *)pse, (const u32 *)prow, (const u32 *)hist, nblk, 1u, ob, op, cap, cur, dbg);
+        hipLaunchKernelGGL(k_probe_regions<0>, dim3(RP_VGRID), dim3(RP_T), 0, st, jv, (const u64 *)pse, (const u32 *)prow, (const u32 *)hist, nblk, 1u, ob, op, cap, cur, dbg);
     IVX_HIP(ctx, hipGetLastError());
     return IVX_OK;
 }

@@ -8,6 +8,8 @@
 // All kernels are integer/index work bound by random L2/HBM access latency; each
 // probe row costs a handful of dependent gathers instead of the reference's
 // O(log n) binary searches.
+#include <cstdlib>
+#include <cstring>
 #include "ivx_grid.hpp"
 #include "ivx_runs.hpp"
 #include "ivx_scan.hpp"
@@ -49,6 +51,22 @@ __global__ __launch_bounds__(OT) void k_probe_count(RankGridView gs, RankGridVie
         }
         out[i] = c;
     }
+}
+
+__global__ __launch_bounds__(OT) void k_any_inverted(const i32 *__restrict__ s, const i32 *__restrict__ e, u64 n, u32 *flag)
+{
+    const u64 i = (u64)blockIdx.x * OT + threadIdx.x;
+    if (i < n && e[i] < s[i]) *flag = 1;
+}
+
+// large unsorted batches go through the region partition (ivx_join_regions.hip) unless told otherwise
+bool rowval_regions_wanted(const ivx_index *ix, u64 n)
+{
+    if (!(ix->flags & IVX_IXF_REGION_ROWVAL) || ix->jv_nreg == 0) return false;
+    const char *f = getenv("IVX_ROWVAL_PATH");                          // tests: "direct" | "regions"
+    if (f && !strcmp(f, "direct")) return false;
+    if (f && !strcmp(f, "regions")) return true;
+    return n >= (1u << 18);
 }
 
 // ======================================================================= a5
@@ -357,10 +375,18 @@ ivx_status sorted_columns(ivx_ctx *ctx, const u32 *key, const i32 *s, const i32 
 
 ivx_status ivx_count_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32 *s, const i32 *e, u64 n)
 {
-    IVX_HIP(ctx, hipMemsetAsync(ctx->d_scalars + 8, 0, sizeof(u64), ctx->stream));
+    // the overlap index as well: #{starts <= qe} - #{ends < qs} equals the number of rows the overlap
+    // predicate matches as long as no build row has end < start, and then big probe batches can take the
+    // region-partitioned path (validates the key ids too)
+    IVX_TRY(ivx_join_build(ctx, ix, key, s, e, n));
+    IVX_HIP(ctx, hipMemsetAsync(ctx->d_scalars + 8, 0, 2 * sizeof(u64), ctx->stream));
+    if (n) hipLaunchKernelGGL(k_any_inverted, dim3(grid1(n)), dim3(OT), 0, ctx->stream, s, e, n, (u32 *)(ctx->d_scalars + 9));
     IVX_TRY(ivx_grid_build(ctx, ix, key, s, n, ix->nkeys, &ix->gs));     // starts, sorted independently (:35)
     IVX_TRY(ivx_grid_build(ctx, ix, key, e, n, ix->nkeys, &ix->ge));     // ends (:36)
-    return check_keyflag(ctx);
+    IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 9, ctx->d_scalars + 9, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+    IVX_TRY(check_keyflag(ctx));                                          // synchronises
+    if (*(u32 *)(ctx->h_scalars + 9) == 0) ix->flags |= IVX_IXF_REGION_ROWVAL;
+    return IVX_OK;
 }
 
 ivx_status ivx_coverage_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32 *s, const i32 *e, u64 n)
@@ -409,6 +435,9 @@ ivx_status ivx_coverage_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const
     IVX_TRY(ivx_grid_build(ctx, ix, rk, nlast, m, nkeys, &ix->cv.last));
     ix->cv.nfirst = nfirst; ix->cv.nlast = nlast; ix->cv.pw = (const i64 *)pw;
     IVX_HIP(ctx, hipGetLastError());
+    // overlap index over the merged nodes for the region-partitioned probe of big batches
+    IVX_TRY(ivx_join_build(ctx, ix, rk, nfirst, nlast, m));
+    ix->flags |= IVX_IXF_REGION_ROWVAL;
     return IVX_OK;
 }
 
@@ -451,6 +480,7 @@ ivx_status ivx_nearest_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const 
 ivx_status ivx_count_probe(ivx_ctx *ctx, const ivx_index *ix, const u32 *key, const i32 *s, const i32 *e, u64 n, int strict, i64 *out)
 {
     if (n == 0) return IVX_OK;
+    if (rowval_regions_wanted(ix, n)) return ivx_rowval_probe_regions(ctx, ix->jv, 0, key, s, e, n, strict, out);
     hipLaunchKernelGGL(k_probe_count, dim3(ivx_stream_grid(n, OT * 4)), dim3(OT), 0, ctx->stream, ix->gs, ix->ge, key, s, e, n, strict, out);
     IVX_HIP(ctx, hipGetLastError());
     return IVX_OK;
@@ -459,6 +489,7 @@ ivx_status ivx_count_probe(ivx_ctx *ctx, const ivx_index *ix, const u32 *key, co
 ivx_status ivx_coverage_probe(ivx_ctx *ctx, const ivx_index *ix, const u32 *key, const i32 *s, const i32 *e, u64 n, int strict, i64 *out)
 {
     if (n == 0) return IVX_OK;
+    if (rowval_regions_wanted(ix, n)) return ivx_rowval_probe_regions(ctx, ix->jv, 1, key, s, e, n, strict, out);
     hipLaunchKernelGGL(k_probe_coverage, dim3(ivx_stream_grid(n, OT * 4)), dim3(OT), 0, ctx->stream, ix->cv, key, s, e, n, strict, out);
     IVX_HIP(ctx, hipGetLastError());
     return IVX_OK;

@@ -27,6 +27,16 @@ def _i32(*a):
     return [x.astype(np.int32) for x in a]
 
 
+def _paths():
+    """count_overlaps / coverage probes: rank-grid gathers ("direct") and the region partition ("regions")"""
+    for path in ("direct", "regions"):
+        os.environ["IVX_ROWVAL_PATH"] = path
+        try:
+            yield path
+        finally:
+            del os.environ["IVX_ROWVAL_PATH"]
+
+
 # ------------------------------------------------------------------ golden tables
 
 @pytest.mark.parametrize("op", ["count_overlaps", "coverage"])
@@ -38,7 +48,8 @@ def test_count_coverage_golden(ctx, golden, op):
         kind = pyivx.KIND_COUNT if op == "count_overlaps" else pyivx.KIND_COVERAGE
         ix = ctx.build(kind, bk, bs, be, n_keys=len(names))
         fn = ctx.count_overlaps if op == "count_overlaps" else ctx.coverage
-        assert fn(ix, pk, ps, pe, strict=case["strict"]).tolist() == case["expect"], case["name"]
+        for path in _paths():
+            assert fn(ix, pk, ps, pe, strict=case["strict"]).tolist() == case["expect"], (case["name"], path)
 
 
 def test_coverage_parquet_golden(ctx):
@@ -51,7 +62,9 @@ def test_coverage_parquet_golden(ctx):
     ids = {n: i for i, n in enumerate(names)}
     bk = left.contig.map(ids).to_numpy(np.uint32); pk = right.contig.map(ids).to_numpy(np.uint32)
     ix = ctx.build(pyivx.KIND_COVERAGE, bk, left.pos_start.to_numpy(), left.pos_end.to_numpy(), n_keys=len(names))
-    cov = ctx.coverage(ix, pk, right.pos_start.to_numpy(), right.pos_end.to_numpy(), strict=True)
+    for path in _paths():
+        cov = ctx.coverage(ix, pk, right.pos_start.to_numpy(), right.pos_end.to_numpy(), strict=True)
+        assert int(cov.sum()) == 12060428 and int((cov != 0).sum()) == 51432, path
     right["coverage"] = cov
     a = right.sort_values(["contig", "pos_start", "pos_end", "coverage"]).reset_index(drop=True)
     b = exp.sort_values(["contig", "pos_start", "pos_end", "coverage"]).reset_index(drop=True)
@@ -59,9 +72,10 @@ def test_coverage_parquet_golden(ctx):
     assert int(cov.sum()) == 12060428 and int((cov != 0).sum()) == 51432
     # and count_overlaps on the same tables against the oracle
     ixc = ctx.build(pyivx.KIND_COUNT, bk, left.pos_start.to_numpy(), left.pos_end.to_numpy(), n_keys=len(names))
-    got = ctx.count_overlaps(ixc, pk, right.pos_start.to_numpy(), right.pos_end.to_numpy(), strict=True)
     want = orc.count_overlaps(bk, left.pos_start.to_numpy(), left.pos_end.to_numpy(), pk, right.pos_start.to_numpy(), right.pos_end.to_numpy(), strict=True)
-    assert (got == want).all()
+    for path in _paths():
+        got = ctx.count_overlaps(ixc, pk, right.pos_start.to_numpy(), right.pos_end.to_numpy(), strict=True)
+        assert (got == want).all(), path
 
 
 def _triples(names, key, s, e, rows):
@@ -145,7 +159,9 @@ def test_count_random(ctx, seed):
         be, pe = _degenerate(seed, bs, be, ps, pe)
     ix = ctx.build(pyivx.KIND_COUNT, bk, bs, be, n_keys=nk + 1)
     for strict in (False, True):
-        assert (ctx.count_overlaps(ix, pk, ps, pe, strict=strict) == orc.count_overlaps(bk, bs, be, pk, ps, pe, strict=strict)).all()
+        want = orc.count_overlaps(bk, bs, be, pk, ps, pe, strict=strict)
+        for path in _paths():                              # (inverted build rows keep the rank grids whatever is asked)
+            assert (ctx.count_overlaps(ix, pk, ps, pe, strict=strict) == want).all(), (strict, path)
 
 
 @pytest.mark.parametrize("seed", range(6))
@@ -158,7 +174,9 @@ def test_coverage_random(ctx, seed):
         _, pe = _degenerate(seed, bs, be, ps, pe)
     ix = ctx.build(pyivx.KIND_COVERAGE, bk, bs, be, n_keys=nk + 1)
     for strict in (False, True):
-        assert (ctx.coverage(ix, pk, ps, pe, strict=strict) == orc.coverage(bk, bs, be, pk, ps, pe, strict=strict)).all()
+        want = orc.coverage(bk, bs, be, pk, ps, pe, strict=strict)
+        for path in _paths():
+            assert (ctx.coverage(ix, pk, ps, pe, strict=strict) == want).all(), (strict, path)
 
 
 def test_coverage_extreme_queries(ctx):
@@ -167,7 +185,26 @@ def test_coverage_extreme_queries(ctx):
     ps = np.array([lo, lo, 0, -5, hi - 3, 10], np.int32); pe = np.array([hi, 100, hi, 5, hi, hi - 1], np.int32)
     pk = np.zeros(len(ps), np.uint32)
     ix = ctx.build(pyivx.KIND_COVERAGE, bk, bs, be, n_keys=1)
-    assert (ctx.coverage(ix, pk, ps, pe) == orc.coverage(bk, bs, be, pk, ps, pe)).all()
+    ixc = ctx.build(pyivx.KIND_COUNT, bk, bs, be, n_keys=1)
+    for path in _paths():
+        for strict in (False, True):
+            assert (ctx.coverage(ix, pk, ps, pe, strict=strict) == orc.coverage(bk, bs, be, pk, ps, pe, strict=strict)).all(), path
+            assert (ctx.count_overlaps(ixc, pk, ps, pe, strict=strict) == orc.count_overlaps(bk, bs, be, pk, ps, pe, strict=strict)).all(), path
+
+
+def test_count_coverage_large_batch_default_path(ctx):
+    # big enough for the region partition by default: uneven keys, probe keys without build rows, a ragged
+    # last chunk, long probe rows (beyond the LDS slice halo) and chromosome-long build rows (upper levels)
+    bk, bs, be = synth(250_000, 51, nkeys=30, mean_len=700, span=30_000_000)
+    pk, ps, pe = synth(2_500_003, 52, nkeys=33, mean_len=150, span=30_000_000)
+    pe[::97] = ps[::97] + 120_000
+    bs[:40] = 0; be[:40] = 29_000_000
+    pe[5::1001] = ps[5::1001] - 2                          # inverted queries
+    for kind, fn, ofn in ((pyivx.KIND_COUNT, ctx.count_overlaps, orc.count_overlaps), (pyivx.KIND_COVERAGE, ctx.coverage, orc.coverage)):
+        ix = ctx.build(kind, bk, bs, be, n_keys=33)
+        for strict in (False, True):
+            assert (fn(ix, pk, ps, pe, strict=strict) == ofn(bk, bs, be, pk, ps, pe, strict=strict)).all(), (kind, strict)
+        ix.free()
 
 
 def test_coverage_rejects_inverted_build(ctx):
