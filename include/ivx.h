@@ -15,8 +15,8 @@
  * Conventions
  *  - Plain pointers and sizes only.  No Arrow, torch or C++ types.
  *  - `mem` says where EVERY data pointer of that call lives:
- *      IVX_MEM_HOST   host memory (Arrow buffers); the library stages them
- *                     through pinned memory with hipMemcpyAsync;
+ *      IVX_MEM_HOST   host memory (Arrow buffers); the library copies them to
+ *                     device scratch with hipMemcpyAsync on the ctx stream;
  *      IVX_MEM_DEVICE device memory of the ctx's GPU (e.g. buffers the caller
  *                     already keeps in HBM); no copies, kernels run on the
  *                     ctx stream.
