@@ -223,7 +223,10 @@ constexpr u32 RP_ECAP = IVX_RP_ECAP;       // entries staged per slice
 constexpr u32 RP_RING = IVX_RP_RING;       // per-wavefront ring of staged pairs: two consecutive rounds must fit (power of two)
 constexpr u32 RP_NSLOT = 4;                // rounds whose reservation state is kept (see round_publish)
 constexpr u32 RP_GRID = 256;                // fill pass: one workgroup per CU (LDS-bound)
-constexpr u32 RP_VGRID = 512;               // row shares ("virtual workgroups"); the count pass runs two per CU
+#ifndef IVX_RP_VGRID
+#define IVX_RP_VGRID 512
+#endif
+constexpr u32 RP_VGRID = IVX_RP_VGRID;       // row shares ("virtual workgroups"); the count pass runs two per CU
 
 struct Slice {
     const JoinIndexView *ix;
