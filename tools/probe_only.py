@@ -8,7 +8,7 @@ dev = torch.device("cuda:0")
 npb = int(os.environ.get("NP", 100_000_000)); nb = int(os.environ.get("NB", 1_000_000)); nk = int(os.environ.get("NK", 24))
 mode = os.environ.get("MODE", "count")
 reps = int(os.environ.get("REPS", 3))
-bk, bs, be = synth.gen_torch(nb, 1000, nk, 0x5EED0004, dev)
+bk, bs, be = synth.gen_torch(nb, int(os.environ.get("BMEAN", 1000)), nk, 0x5EED0004, dev)
 pk, ps, pe = synth.gen_torch(npb, 150, nk, 0x5EED0005, dev)
 if os.environ.get("SORTED"):
     o = torch.argsort(pk.to(torch.int64) * (1 << 32) + ps.to(torch.int64)); pk, ps, pe = pk[o].contiguous(), ps[o].contiguous(), pe[o].contiguous()
