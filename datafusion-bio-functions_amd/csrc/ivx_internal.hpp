@@ -67,14 +67,16 @@ enum {
 };
 
 // ---------------------------------------------------------------- indexes
-#define IVX_MAXL 8        // length-class levels of the binned overlap index
-#define IVX_LSTEP 4       // bin width grows 16x per level
+#ifndef IVX_LSTEP
+#define IVX_LSTEP 2       // bin width grows 4x per level: a level's cell is at most 4x wider than the rows it holds
+#endif
+#define IVX_MAXL (32 / IVX_LSTEP)   // length-class levels of the binned overlap index
 #define IVX_SH_MIN 4
 
 struct ivx_ent { i32 s, e; u32 row; };          // 12-byte AoS entry of the overlap index
 
 // header words written by the layout kernel (device resident, read by probes)
-enum { HDR_SH0 = 0, HDR_NLEV = 1, HDR_NBINS = 2, HDR_LEVCNT = 4 /* .. +IVX_MAXL */, HDR_CS = 12, HDR_NREG = 13, HDR_WORDS = 16 };
+enum { HDR_SH0 = 0, HDR_NLEV = 1, HDR_NBINS = 2, HDR_CS = 3, HDR_NREG = 4, HDR_LEVCNT = 8 /* .. +IVX_MAXL */, HDR_WORDS = 8 + IVX_MAXL };
 #define IVX_MAXREG 255   // probe regions (one radix digit; 255 = rows that cannot match)
 
 struct JoinIndexView {

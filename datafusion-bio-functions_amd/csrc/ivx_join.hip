@@ -228,7 +228,7 @@ ivx_status ivx_join_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32
 {
     const u32 nkeys = ix->nkeys;
     hipStream_t st = ctx->stream;
-    const u64 maxcells = 2 * n + n / 4 + (u64)IVX_MAXL * nkeys + 64;
+    const u64 maxcells = 2 * n + (IVX_LSTEP >= 4 ? n / 4 : n) + (u64)IVX_MAXL * nkeys + 64;   // geometric sum over the levels
     if (maxcells + 1 >= 0xFFFFFFFFull) return ctx->fail(IVX_ERR_INVALID, "build side too large for 32-bit cell ids");
 
     i32 *origin; u32 *span, *kcnt, *lbase, *binstart, *hdr, *kreg, *rkey; ivx_ent *ent;

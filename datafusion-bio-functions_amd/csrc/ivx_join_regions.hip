@@ -215,8 +215,7 @@ constexpr int RP_W = RP_T / IVX_WAVE;
 #ifndef IVX_RP_ECAP
 #define IVX_RP_ECAP 6144
 #endif
-constexpr int RP_B = IVX_RP_B;             // probe rows per lane per wave batch
-constexpr u32 RP_WB = IVX_WAVE * RP_B;     // rows per wave batch
+constexpr int RP_B = IVX_RP_B;             // probe rows per lane per wavefront batch (fill: 8, 4, 2 or 1 by match density)
 constexpr u32 RP_HALO = 8;                 // slice cells past the region's last cell
 constexpr u32 RP_CCAP = 8192 + RP_HALO + 2;
 constexpr u32 RP_ECAP = IVX_RP_ECAP;       // entries staged per slice
@@ -356,21 +355,20 @@ __device__ __forceinline__ void slice_load(const JoinIndexView &ix, Slice &S, co
     __syncthreads();
 }
 
-// One wave batch: RP_B rows per lane (bit q of okmask says whether the lane holds a row in slot q).
+// One wave batch: B rows per lane (bit q of okmask says whether the lane holds a row in slot q).
 // Count pass: returns the lane's pair count.
 // Fill pass: every match takes the next slot of the wavefront's LDS staging buffer with an LDS atomic on
 // the wavefront's own running counter (lanes of one instruction are serialised by the LDS unit and get
-// distinct slots), so no per-row match stash, prefix sum or second walk is needed.  Returns the
-// wavefront's staged pair count (0 if the batch did not fit the buffer and was written directly).
-template <bool FILL>
-__device__ __forceinline__ u32 batch_walk(const Slice &S, const ProbeLds &L, const i32 (&qs)[RP_B], const i32 (&qe)[RP_B],
-                                          const u32 (&rowv)[RP_B], u32 okmask, u32 wv, u32 ring_tail, u32 &ring_start,
-                                          u32 *ob, u32 *op, u64 cap, unsigned long long *cursor, int dbg)
+// distinct slots), so no per-row match stash, prefix sum or second walk is needed.  Returns the batch's
+// pair count; direct = true if it did not fit the ring (see batch_write_direct).
+template <bool FILL, int B>
+__device__ __forceinline__ u32 batch_walk(const Slice &S, const ProbeLds &L, const i32 (&qs)[B], const i32 (&qe)[B],
+                                          const u32 (&rowv)[B], u32 okmask, u32 wv, u32 ring_tail, u32 &ring_start, bool &direct, int dbg)
 {
     if (!FILL) {
         u32 tsum = 0;
 #pragma unroll
-        for (int q = 0; q < RP_B; q++) {
+        for (int q = 0; q < B; q++) {
             if (!((okmask >> q) & 1u)) continue;
             if (dbg & 4) tsum += (u32)(qs[q] ^ qe[q]) & 1u;
             else probe_row(S, qs[q], qe[q], [&](u32, bool, i32, i32) { tsum++; });
@@ -381,7 +379,7 @@ __device__ __forceinline__ u32 batch_walk(const Slice &S, const ProbeLds &L, con
     const u32 base = __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     ring_start = base;
 #pragma unroll
-    for (int q = 0; q < RP_B; q++) {
+    for (int q = 0; q < B; q++) {
         if (!((okmask >> q) & 1u)) continue;
         probe_row(S, qs[q], qe[q], [&](u32 v, bool sl, i32, i32) {
             const u32 pos = __hip_atomic_fetch_add(cp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -390,23 +388,30 @@ __device__ __forceinline__ u32 batch_walk(const Slice &S, const ProbeLds &L, con
         });
     }
     const u32 wtot = __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - base;
-    if (base + wtot - ring_tail <= RP_RING) return wtot;
-    // rare: this round and the previous one do not fit the ring together -- reserve the batch's output
-    // range directly and walk again (the previous round's pairs were never overwritten)
-    u64 own = 0;
-    if (lane_id() == 0) own = atomicAdd(cursor, (unsigned long long)wtot);
-    own = __shfl(own, 0, IVX_WAVE);
-    const bool direct_ok = own + wtot <= cap;
+    // this round and the previous one must fit the ring together; if not, nothing of this batch counts as
+    // staged (the previous round's pairs were never overwritten) and the caller writes the batch directly
+    // once the round's output range is known (batch_write_direct)
+    direct = base + wtot - ring_tail > RP_RING;
+    if (direct) ring_start = base + wtot;
+    return wtot;
+}
+
+// second walk of a batch that did not fit the staging ring: pairs go straight to their place in the
+// output, [g, g + wtot) of the round's reserved range; slots again by LDS atomic
+template <int B>
+__device__ __forceinline__ void batch_write_direct(const Slice &S, const ProbeLds &L, const i32 (&qs)[B], const i32 (&qe)[B],
+                                                   const u32 (&rowv)[B], u32 okmask, u32 wv, u64 g, bool ok, u32 *ob, u32 *op)
+{
+    u32 *cp = &L.s_wpos[wv];
+    const u32 base = __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
-    for (int q = 0; q < RP_B; q++) {
+    for (int q = 0; q < B; q++) {
         if (!((okmask >> q) & 1u)) continue;
         probe_row(S, qs[q], qe[q], [&](u32 v, bool sl, i32, i32) {
-            const u32 pos = __hip_atomic_fetch_add(cp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - base - wtot;
-            if (direct_ok) { ob[own + pos] = sl ? S.s_row[v] : v; op[own + pos] = rowv[q]; }
+            const u32 pos = __hip_atomic_fetch_add(cp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - base;
+            if (ok) { ob[g + pos] = sl ? S.s_row[v] : v; op[g + pos] = rowv[q]; }
         });
     }
-    ring_start = base + 2 * wtot;
-    return 0u;
 }
 
 // Per-row-output operators on the same slices: the row's value instead of its pairs.
@@ -420,11 +425,11 @@ enum { RV_COUNT = 2, RV_COVERAGE = 3 };
 __device__ __forceinline__ i32 rv_wadd(i32 a, i32 b) { return (i32)((u32)a + (u32)b); }
 __device__ __forceinline__ i32 rv_wsub(i32 a, i32 b) { return (i32)((u32)a - (u32)b); }
 
-template <int KIND>
-__device__ __forceinline__ void batch_rowval(const Slice &S, const i32 (&qs)[RP_B], const i32 (&qe)[RP_B], u32 okmask, u32 (&val)[RP_B])
+template <int KIND, int B>
+__device__ __forceinline__ void batch_rowval(const Slice &S, const i32 (&qs)[B], const i32 (&qe)[B], u32 okmask, u32 (&val)[B])
 {
 #pragma unroll
-    for (int q = 0; q < RP_B; q++) {
+    for (int q = 0; q < B; q++) {
         u32 v = 0;
         if ((okmask >> q) & 1u) {
             if (KIND == RV_COUNT) {
@@ -463,21 +468,30 @@ __device__ __forceinline__ void round_publish(const ProbeLds &L, u32 mine, u32 r
     __hip_atomic_store(&L.s_ready[sl], round + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// wait for round `round`'s reservation, then copy this wavefront's `mine` staged pairs (ring positions
-// start, start+1, ...) to their place in the output with full-width stores
-__device__ __forceinline__ void round_copy_out(const ProbeLds &L, u32 mine, u32 start, u32 round, u32 wv,
-                                               u32 *ob, u32 *op, u64 cap, int dbg)
+// wait for round `round`'s reservation; returns where this wavefront's pairs of that round go and whether
+// the whole round fits the caller's buffers
+__device__ __forceinline__ u64 round_wait(const ProbeLds &L, u32 round, u32 wv, u64 cap, bool &fits)
 {
     const u32 sl = round % RP_NSLOT;
     while (__hip_atomic_load(&L.s_ready[sl], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != round + 1u)
         __builtin_amdgcn_s_sleep(1);
-    if (!mine) return;
     const u64 base = L.s_base[sl];
     u64 g = base;
     u32 tot = 0;
 #pragma unroll
     for (int w = 0; w < RP_W; w++) { const u32 c = L.s_wcnt[sl][w]; if (w < (int)wv) g += c; tot += c; }
-    if (base + tot > cap || (dbg & 16)) return;
+    fits = base + tot <= cap;
+    return g;
+}
+
+// copy this wavefront's `mine` staged pairs of round `round` (ring positions start, start+1, ...) to their
+// place in the output with full-width stores
+__device__ __forceinline__ void round_copy_out(const ProbeLds &L, u32 mine, u32 start, u32 round, u32 wv,
+                                               u32 *ob, u32 *op, u64 cap, int dbg)
+{
+    bool fits;
+    const u64 g = round_wait(L, round, wv, cap, fits);
+    if (!mine || !fits || (dbg & 16)) return;
     for (u32 t = lane_id(); t < mine; t += IVX_WAVE) {
         const u64 x = L.s_q[wv][(start + t) & (RP_RING - 1)];
         ob[g + t] = (u32)x; op[g + t] = (u32)(x >> 32);
@@ -506,13 +520,14 @@ __device__ __forceinline__ void round_copy_out(const ProbeLds &L, u32 mine, u32 
 //   MODE 1 (fill): single walk, see batch_walk / round_publish / round_copy_out.
 //   MODE RV_COUNT / RV_COVERAGE: one 32-bit value per row, written at the row's partitioned position
 //           (`ob`), no synchronisation at all; k_unpermute puts the values back in input order.
-template <int MODE>
+template <int MODE, int B>
 __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const u64 *__restrict__ pse, const u32 *__restrict__ prow,
                                                         const u32 *__restrict__ offs, u32 nblk, u32 vpb,
                                                         u32 *__restrict__ ob, u32 *__restrict__ op, u64 cap,
                                                         unsigned long long *cursor, int dbg)
 {
     constexpr bool FILL = MODE == 1;
+    constexpr u32 WB = IVX_WAVE * B;                                  // rows per wavefront batch
     IVX_PROBE_LDS(FILL)
     const u32 wv = threadIdx.x / IVX_WAVE, ln = lane_id();
     const u32 nreg = ix.hdr[HDR_NREG];
@@ -540,46 +555,53 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
                 if (c_hi <= lo) continue;
                 slice_load(ix, S, L, r, r != loaded_r);
                 loaded_r = r;
-                // every wavefront streams one batch of RP_WB rows per round; the next round's rows are in
+                // every wavefront streams one batch of WB rows per round; the next round's rows are in
                 // flight while the current batch walks the LDS slice
-                u64 nx[RP_B]; u32 nxr[RP_B];
-                u64 b0 = lo + (u64)wv * RP_WB;
+                u64 nx[B]; u32 nxr[B];
+                u64 b0 = lo + (u64)wv * WB;
 #pragma unroll
-                for (int q = 0; q < RP_B; q++) {
+                for (int q = 0; q < B; q++) {
                     const u64 i = b0 + (u64)q * IVX_WAVE + ln;
                     nx[q] = i < c_hi ? pse[i] : 0;
                     nxr[q] = (FILL && i < c_hi) ? prow[i] : 0u;
                 }
-                for (u64 r0 = lo; r0 < c_hi; r0 += (u64)RP_W * RP_WB, b0 += (u64)RP_W * RP_WB) {
-                    i32 qs[RP_B], qe[RP_B]; u32 rowv[RP_B];
+                for (u64 r0 = lo; r0 < c_hi; r0 += (u64)RP_W * WB, b0 += (u64)RP_W * WB) {
+                    i32 qs[B], qe[B]; u32 rowv[B];
                     u32 okmask = 0;
 #pragma unroll
-                    for (int q = 0; q < RP_B; q++) {
+                    for (int q = 0; q < B; q++) {
                         qs[q] = (i32)(u32)nx[q]; qe[q] = (i32)(u32)(nx[q] >> 32); rowv[q] = nxr[q];
                         if (b0 + (u64)q * IVX_WAVE + ln < c_hi) okmask |= 1u << q;
                     }
                     {
-                        const u64 b1 = b0 + (u64)RP_W * RP_WB;
+                        const u64 b1 = b0 + (u64)RP_W * WB;
 #pragma unroll
-                        for (int q = 0; q < RP_B; q++) {
+                        for (int q = 0; q < B; q++) {
                             const u64 i = b1 + (u64)q * IVX_WAVE + ln;
                             nx[q] = i < c_hi ? pse[i] : 0;
                             nxr[q] = (FILL && i < c_hi) ? prow[i] : 0u;
                         }
                     }
                     if (MODE >= RV_COUNT) {
-                        u32 val[RP_B];
-                        batch_rowval<MODE>(S, qs, qe, okmask, val);
+                        u32 val[B];
+                        batch_rowval<MODE, B>(S, qs, qe, okmask, val);
 #pragma unroll
-                        for (int q = 0; q < RP_B; q++)
+                        for (int q = 0; q < B; q++)
                             if ((okmask >> q) & 1u) ob[b0 + (u64)q * IVX_WAVE + ln] = val[q];
                         continue;
                     }
                     u32 start = 0;
-                    const u32 got = batch_walk<FILL>(S, L, qs, qe, rowv, okmask, wv, pend_start, start, ob, op, cap, cursor, dbg);
+                    bool direct = false;
+                    u32 got = batch_walk<FILL, B>(S, L, qs, qe, rowv, okmask, wv, pend_start, start, direct, dbg);
                     if (MODE == 0) { wcur += got; continue; }
                     if (!(dbg & 32)) {
                         round_publish(L, got, round, wv, cursor);
+                        if (direct) {                          // needs this round's range now: wait for the 16th wavefront
+                            bool fits;
+                            const u64 g = round_wait(L, round, wv, cap, fits);
+                            batch_write_direct<B>(S, L, qs, qe, rowv, okmask, wv, g, fits, ob, op);
+                            start += got; got = 0;             // nothing staged; the second walk moved the ring position too
+                        }
                         if (round) round_copy_out(L, pend_mine, pend_start, round - 1, wv, ob, op, cap, dbg);
                     }
                     pend_mine = got; pend_start = start; round++;
@@ -662,9 +684,9 @@ ivx_status ivx_rowval_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, int c
     if (vec) hipLaunchKernelGGL((k_part_scatter<true, unsigned short>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, cidx, adj, 0);
     else hipLaunchKernelGGL((k_part_scatter<false, unsigned short>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, cidx, adj, 0);
     if (coverage)
-        hipLaunchKernelGGL(k_probe_regions<RV_COVERAGE>, dim3(RP_VGRID), dim3(RP_T), 0, st, jv, (const u64 *)pse, (const u32 *)nullptr, (const u32 *)hist, nblk, 1u, val, (u32 *)nullptr, (u64)0, (unsigned long long *)nullptr, 0);
+        hipLaunchKernelGGL((k_probe_regions<RV_COVERAGE, RP_B>), dim3(RP_VGRID), dim3(RP_T), 0, st, jv, (const u64 *)pse, (const u32 *)nullptr, (const u32 *)hist, nblk, 1u, val, (u32 *)nullptr, (u64)0, (unsigned long long *)nullptr, 0);
     else
-        hipLaunchKernelGGL(k_probe_regions<RV_COUNT>, dim3(RP_VGRID), dim3(RP_T), 0, st, jv, (const u64 *)pse, (const u32 *)nullptr, (const u32 *)hist, nblk, 1u, val, (u32 *)nullptr, (u64)0, (unsigned long long *)nullptr, 0);
+        hipLaunchKernelGGL((k_probe_regions<RV_COUNT, RP_B>), dim3(RP_VGRID), dim3(RP_T), 0, st, jv, (const u64 *)pse, (const u32 *)nullptr, (const u32 *)hist, nblk, 1u, val, (u32 *)nullptr, (u64)0, (unsigned long long *)nullptr, 0);
     if (coverage) hipLaunchKernelGGL(k_unpermute<true>, dim3(nblk), dim3(PA_T), 0, st, (const u32 *)val, (const unsigned short *)cidx, (const u32 *)hist, nblk, (u32)PA_ND, n, out);
     else hipLaunchKernelGGL(k_unpermute<false>, dim3(nblk), dim3(PA_T), 0, st, (const u32 *)val, (const unsigned short *)cidx, (const u32 *)hist, nblk, (u32)PA_ND, n, out);
     IVX_HIP(ctx, hipGetLastError());
@@ -692,10 +714,17 @@ ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, int mod
     if (vec) hipLaunchKernelGGL((k_part_scatter<true, u32>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, prow, 0u, dbg);
     else hipLaunchKernelGGL((k_part_scatter<false, u32>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, prow, 0u, dbg);
     unsigned long long *cur = (unsigned long long *)d_cursor;
-    if (mode == JP_FILL)     // single walk: pairs staged per wavefront, one output reservation per workgroup and round
-        hipLaunchKernelGGL(k_probe_regions<1>, dim3(RP_GRID), dim3(RP_T), 0, st, jv, (const u64 *)pse, (const u32 *)prow, (const u32 *)hist, nblk, RP_VGRID / RP_GRID, ob, op, cap, cur, dbg);
-    else
-        hipLaunchKernelGGL(k_probe_regions<0>, dim3(RP_VGRID), dim3(RP_T), 0, st, jv, (const u64 *)pse, (const u32 *)prow, (const u32 *)hist, nblk, 1u, ob, op, cap, cur, dbg);
+    if (mode == JP_FILL) {   // single walk: pairs staged per wavefront, one output reservation per workgroup and round
+        // rows per lane and batch by the expected matches per row (cap / n: callers size the output from the
+        // count pass): two consecutive rounds of a wavefront must fit its 512-pair staging ring, else the
+        // batch takes the slow direct path
+        const double per_row = (double)cap / (double)n;
+        const int b = getenv("IVX_RP_ROWS") ? atoi(getenv("IVX_RP_ROWS")) : per_row <= 0.45 ? 8 : per_row <= 0.9 ? 4 : per_row <= 1.8 ? 2 : 1;
+#define IVX_FILL(B_) hipLaunchKernelGGL((k_probe_regions<1, B_>), dim3(RP_GRID), dim3(RP_T), 0, st, jv, (const u64 *)pse, (const u32 *)prow, (const u32 *)hist, nblk, RP_VGRID / RP_GRID, ob, op, cap, cur, dbg)
+        switch (b) { case 1: IVX_FILL(1); break; case 2: IVX_FILL(2); break; case 4: IVX_FILL(4); break; default: IVX_FILL(8); }
+#undef IVX_FILL
+    } else
+        hipLaunchKernelGGL((k_probe_regions<0, RP_B>), dim3(RP_VGRID), dim3(RP_T), 0, st, jv, (const u64 *)pse, (const u32 *)prow, (const u32 *)hist, nblk, 1u, ob, op, cap, cur, dbg);
     IVX_HIP(ctx, hipGetLastError());
     return IVX_OK;
 }
