@@ -72,6 +72,25 @@ __device__ __forceinline__ u32 region_of(const JoinIndexView &ix, const KeyTab &
     return kreg + (c >> kt.cs);
 }
 
+// LDS counter bump that returns the old value.  Sorted / clustered probe input sends a whole wavefront to
+// the same counter; then one lane adds the wavefront's count and the lanes rank themselves by ballot,
+// instead of 64 serialised same-address atomics.
+__device__ __forceinline__ u32 lds_count_up(u32 *cnt, u32 d, bool active)
+{
+    const u64 act = __ballot(active);
+    if (act == 0) return 0;
+    const u32 first = (u32)__builtin_ctzll(act);
+    const u32 d0 = __shfl(d, first, IVX_WAVE);
+    const u64 same = __ballot(active && d == d0);
+    if (same == act) {                                          // wave-uniform digit
+        u32 base = 0;
+        if (lane_id() == first) base = atomicAdd(&cnt[d0], (u32)__popcll(act));
+        base = __shfl(base, first, IVX_WAVE);
+        return base + mask_rank(act);
+    }
+    return active ? atomicAdd(&cnt[d], 1u) : 0u;
+}
+
 // four consecutive probe rows per lane: 16-byte loads when the columns are 16-byte aligned
 template <bool VEC>
 __device__ __forceinline__ void load4(const u32 *__restrict__ pkey, const i32 *__restrict__ ps, const i32 *__restrict__ pe,
@@ -117,7 +136,7 @@ __global__ __launch_bounds__(PA_T) void k_part_hist(JoinIndexView ix, const u32 
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const u32 d = region_of(ix, kt, k[u], (i32)((u32)q[u] + adj));
-            if (d != NO_REGION) atomicAdd(&cnt[d], 1u);
+            lds_count_up(cnt, d, d != NO_REGION);
         }
     }
     __syncthreads();
@@ -167,7 +186,7 @@ __global__ __launch_bounds__(PA_T) void k_part_scatter(JoinIndexView ix, const u
             se[k] = (u64)(u32)qs[k] | ((u64)(u32)qe[k] << 32);
             const u32 d = region_of(ix, kt, kk[k], qs[k]);
             dig[k] = d;
-            lrank[k] = d != NO_REGION ? atomicAdd(&tcnt[d], 1u) : 0u;
+            lrank[k] = lds_count_up(tcnt, d, d != NO_REGION);
         }
         __syncthreads();
         u32 tot;
