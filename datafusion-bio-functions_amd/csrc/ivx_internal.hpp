@@ -79,6 +79,11 @@ struct ivx_ent { i32 s, e; u32 row; };          // 12-byte AoS entry of the over
 enum { HDR_SH0 = 0, HDR_NLEV = 1, HDR_NBINS = 2, HDR_CS = 3, HDR_NREG = 4, HDR_LEVCNT = 8 /* .. +IVX_MAXL */, HDR_WORDS = 8 + IVX_MAXL };
 #define IVX_MAXREG 255   // probe regions (one radix digit; 255 = rows that cannot match)
 
+// what a probe workgroup needs to stage one region's slice of level 0 (ivx_join_regions.hip), precomputed at
+// build time so that staging starts with ONE load instead of a chain of four dependent ones
+#define IVX_RP_HALO 8u      // slice cells past the region's last cell
+struct ivx_regdesc { u32 k; i32 origin; u32 span, lb, slo, shi, e0, ne; };
+
 struct JoinIndexView {
     const i32 *origin;      // [nkeys] smallest start of the key
     const u32 *span;        // [nkeys] largest start - smallest start
@@ -89,6 +94,7 @@ struct JoinIndexView {
     const u32 *hdr;         // [HDR_WORDS]
     const u32 *kreg;        // [nkeys+1] first probe region of the key (regions never straddle keys)
     const u32 *rkey;        // [IVX_MAXREG+1] key of a region
+    const ivx_regdesc *rdesc;   // [IVX_MAXREG+1] slice window of a region
     u32 nkeys;
 };
 

@@ -111,6 +111,26 @@ __global__ __launch_bounds__(1024) void k_join_layout(const i32 *kmin, const i32
     }
 }
 
+// one thread per probe region: the level-0 cell window a workgroup stages for it and its entry range
+__global__ __launch_bounds__(256) void k_join_regdesc(const i32 *origin, const u32 *span, const u32 *lbase, const u32 *hdr,
+                                                      const u32 *kreg, const u32 *rkey, const u32 *binstart, ivx_regdesc *rdesc)
+{
+    const u32 r = threadIdx.x + blockIdx.x * 256;
+    if (r >= hdr[HDR_NREG]) return;
+    const u32 sh0 = hdr[HDR_SH0], cs = hdr[HDR_CS];
+    ivx_regdesc d;
+    d.k = rkey[r]; d.origin = origin[d.k]; d.span = span[d.k]; d.lb = lbase[d.k];
+    const u32 cells0 = (d.span >> sh0) + 1u;
+    const u32 rc0 = (r - kreg[d.k]) << cs;
+    const u64 rc1w = (u64)rc0 + (1ull << cs);
+    const u32 rc1 = rc1w < cells0 ? (u32)rc1w : cells0;
+    d.slo = rc0 ? rc0 - 1u : 0u;                      // a build row starts at most one cell before the cell it reaches into
+    d.shi = rc1 + IVX_RP_HALO < cells0 ? rc1 + IVX_RP_HALO : cells0;
+    d.e0 = binstart[d.lb + d.slo];
+    d.ne = binstart[d.lb + d.shi] - d.e0;
+    rdesc[r] = d;
+}
+
 __global__ __launch_bounds__(BT) void k_join_count(const u32 *__restrict__ key, const i32 *__restrict__ s,
                                                    const i32 *__restrict__ e, u64 n, u32 nkeys,
                                                    const i32 *origin, const u32 *lbase, u32 *hdr, u32 *bincnt)
@@ -231,7 +251,7 @@ ivx_status ivx_join_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32
     const u64 maxcells = 2 * n + (IVX_LSTEP >= 4 ? n / 4 : n) + (u64)IVX_MAXL * nkeys + 64;   // geometric sum over the levels
     if (maxcells + 1 >= 0xFFFFFFFFull) return ctx->fail(IVX_ERR_INVALID, "build side too large for 32-bit cell ids");
 
-    i32 *origin; u32 *span, *kcnt, *lbase, *binstart, *hdr, *kreg, *rkey; ivx_ent *ent;
+    i32 *origin; u32 *span, *kcnt, *lbase, *binstart, *hdr, *kreg, *rkey; ivx_ent *ent; ivx_regdesc *rdesc;
     IVX_TRY(ivx_index_alloc(ctx, ix, nkeys * sizeof(i32), (void **)&origin));
     IVX_TRY(ivx_index_alloc(ctx, ix, nkeys * sizeof(u32), (void **)&span));
     IVX_TRY(ivx_index_alloc(ctx, ix, nkeys * sizeof(u32), (void **)&kcnt));
@@ -240,6 +260,7 @@ ivx_status ivx_join_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32
     IVX_TRY(ivx_index_alloc(ctx, ix, HDR_WORDS * sizeof(u32), (void **)&hdr));
     IVX_TRY(ivx_index_alloc(ctx, ix, ((size_t)nkeys + 1) * sizeof(u32), (void **)&kreg));
     IVX_TRY(ivx_index_alloc(ctx, ix, (IVX_MAXREG + 1) * sizeof(u32), (void **)&rkey));
+    IVX_TRY(ivx_index_alloc(ctx, ix, (IVX_MAXREG + 1) * sizeof(ivx_regdesc), (void **)&rdesc));
     IVX_TRY(ivx_index_alloc(ctx, ix, (n ? n : 1) * sizeof(ivx_ent), (void **)&ent));
 
     i32 *kmin, *kmax; u32 *cursor, *errflag;
@@ -258,6 +279,7 @@ ivx_status ivx_join_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32
     hipLaunchKernelGGL(k_join_count, dim3(grid), dim3(BT), 0, st, key, s, e, n, nkeys, origin, lbase, hdr, binstart);
     IVX_TRY(ivx_scan_exclusive_u32(ctx, binstart, maxcells + 1));
     hipLaunchKernelGGL(k_join_scatter, dim3(grid), dim3(BT), 0, st, key, s, e, n, nkeys, origin, lbase, hdr, binstart, cursor, ent);
+    hipLaunchKernelGGL(k_join_regdesc, dim3(1), dim3(256), 0, st, origin, span, lbase, hdr, kreg, rkey, binstart, rdesc);
     IVX_HIP(ctx, hipGetLastError());
 
     // key ids are validated on the device; surface the flag (one small D2H)
@@ -269,7 +291,7 @@ ivx_status ivx_join_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32
 
     ix->jv.origin = origin; ix->jv.span = span; ix->jv.kcnt = kcnt; ix->jv.lbase = lbase;
     ix->jv.binstart = binstart; ix->jv.ent = ent; ix->jv.hdr = hdr; ix->jv.nkeys = nkeys;
-    ix->jv.kreg = kreg; ix->jv.rkey = rkey;
+    ix->jv.kreg = kreg; ix->jv.rkey = rkey; ix->jv.rdesc = rdesc;
     return IVX_OK;
 }
 

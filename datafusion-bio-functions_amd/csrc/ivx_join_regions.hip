@@ -235,7 +235,7 @@ constexpr int RP_W = RP_T / IVX_WAVE;
 #define IVX_RP_ECAP 6144
 #endif
 constexpr int RP_B = IVX_RP_B;             // probe rows per lane per wavefront batch (fill: 8, 4, 2 or 1 by match density)
-constexpr u32 RP_HALO = 8;                 // slice cells past the region's last cell
+constexpr u32 RP_HALO = IVX_RP_HALO;       // slice cells past the region's last cell
 constexpr u32 RP_CCAP = 8192 + RP_HALO + 2;
 constexpr u32 RP_ECAP = IVX_RP_ECAP;       // entries staged per slice
 constexpr u32 RP_RING = IVX_RP_RING;       // per-wavefront ring of staged pairs: two consecutive rounds must fit (power of two)
@@ -336,20 +336,12 @@ __device__ __forceinline__ void slice_init(const JoinIndexView &ix, Slice &S, co
 __device__ __forceinline__ void slice_load(const JoinIndexView &ix, Slice &S, const ProbeLds &L, u32 r, bool reload)
 {
     const u32 tid = threadIdx.x;
-    const u32 cs = ix.hdr[HDR_CS];
     __syncthreads();
-    S.k = ix.rkey[r];
-    S.origin = ix.origin[S.k]; S.span = ix.span[S.k];
-    S.lb = ix.lbase[S.k];
-    const u32 cells0 = (S.span >> S.sh0) + 1u;
-    S.ncell0 = cells0;
-    const u32 rc0 = (r - ix.kreg[S.k]) << cs;
-    const u64 rc1w = (u64)rc0 + (1ull << cs);
-    const u32 rc1 = rc1w < cells0 ? (u32)rc1w : cells0;
-    S.slo = rc0 ? rc0 - 1u : 0u;
-    S.shi = rc1 + RP_HALO < cells0 ? rc1 + RP_HALO : cells0;
-    S.e0 = ix.binstart[S.lb + S.slo];
-    const u32 ne = ix.binstart[S.lb + S.shi] - S.e0;
+    const ivx_regdesc d = ix.rdesc[r];                                  // built by k_join_regdesc
+    S.k = d.k; S.origin = d.origin; S.span = d.span; S.lb = d.lb;
+    S.ncell0 = (S.span >> S.sh0) + 1u;
+    S.slo = d.slo; S.shi = d.shi; S.e0 = d.e0;
+    const u32 ne = d.ne;
     const u32 nc = S.shi - S.slo + 1u;
     S.inlds = ne <= RP_ECAP && nc <= RP_CCAP;
     if (S.inlds && reload) {
@@ -550,7 +542,11 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
     IVX_PROBE_LDS(FILL)
     const u32 wv = threadIdx.x / IVX_WAVE, ln = lane_id();
     const u32 nreg = ix.hdr[HDR_NREG];
-    const u64 total_rows = offs[(u64)nreg * nblk];
+    // first partitioned row of every region, once, in LDS (the share boundaries below search it)
+    __shared__ u32 s_rfirst[IVX_MAXREG + 2];
+    for (u32 t = threadIdx.x; t <= nreg; t += RP_T) s_rfirst[t] = offs[(u64)t * nblk];
+    __syncthreads();
+    const u64 total_rows = s_rfirst[nreg];
     const u32 nvb = gridDim.x * vpb;
     u32 loaded_r = 0xFFFFFFFFu;                                       // region whose slice currently sits in LDS
     Slice S;
@@ -565,17 +561,15 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
             u32 r;
             {   // last region whose first row is <= lo
                 u32 a = 0, b = nreg;
-                while (a < b) { const u32 m = (a + b + 1) >> 1; if (offs[(u64)m * nblk] <= lo) a = m; else b = m - 1; }
+                while (a < b) { const u32 m = (a + b + 1) >> 1; if (s_rfirst[m] <= lo) a = m; else b = m - 1; }
                 r = a;
             }
             for (; lo < hi; r++) {
-                const u64 rend = offs[(u64)(r + 1) * nblk];
+                const u64 rend = s_rfirst[r + 1];
                 const u64 c_hi = hi < rend ? hi : rend;
                 if (c_hi <= lo) continue;
-                slice_load(ix, S, L, r, r != loaded_r);
-                loaded_r = r;
                 // every wavefront streams one batch of WB rows per round; the next round's rows are in
-                // flight while the current batch walks the LDS slice
+                // flight while the current batch walks the LDS slice (the first batch while the slice loads)
                 u64 nx[B]; u32 nxr[B];
                 u64 b0 = lo + (u64)wv * WB;
 #pragma unroll
@@ -584,6 +578,8 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
                     nx[q] = i < c_hi ? pse[i] : 0;
                     nxr[q] = (FILL && i < c_hi) ? prow[i] : 0u;
                 }
+                slice_load(ix, S, L, r, r != loaded_r);
+                loaded_r = r;
                 for (u64 r0 = lo; r0 < c_hi; r0 += (u64)RP_W * WB, b0 += (u64)RP_W * WB) {
                     i32 qs[B], qe[B]; u32 rowv[B];
                     u32 okmask = 0;
