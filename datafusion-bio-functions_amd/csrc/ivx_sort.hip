@@ -19,13 +19,18 @@
 
 namespace {
 
-constexpr int RS_T = 256;
-constexpr int RS_I = 8;                         // records per thread per tile
-constexpr int RS_TILE = RS_T * RS_I;            // 2048
-constexpr int RS_WAVES = RS_T / IVX_WAVE;       // 4
-constexpr int RS_WTILE = RS_TILE / RS_WAVES;    // 512 consecutive records per wavefront
-constexpr int RS_TPB = 8;                       // tiles per workgroup
-constexpr u64 RS_CHUNK = (u64)RS_TILE * RS_TPB; // 16384 records per workgroup
+// One workgroup per CU (the tile's records sit in LDS): big tiles make the per-digit runs written to HBM
+// long (8192 records / 256 digits = 32 records = 256 B per word array), which is what the scatter lives on.
+constexpr int RS_T = 1024;
+constexpr int RS_WAVES = RS_T / IVX_WAVE;       // 16
+constexpr int RS_HT = 256;                      // histogram kernel: threads (= digits)
+constexpr int RS_HWAVES = RS_HT / IVX_WAVE;
+constexpr u64 RS_CHUNK = 32768;                 // records per workgroup (histogram and scatter agree on it)
+template <int NW> struct Tile {
+    static constexpr int I = NW == 3 ? 4 : 8;   // records per thread per tile: 8192-record tiles, 4096 for 24-byte records (LDS)
+    static constexpr int N = RS_T * I;
+    static constexpr int WT = N / RS_WAVES;     // consecutive records per wavefront
+};
 
 template <int NW> struct Ptrs { u64 *w[NW]; };
 template <int NW> struct CPtrs { const u64 *w[NW]; };
@@ -54,32 +59,32 @@ __device__ __forceinline__ u64 match_digit(u32 d, bool valid)
     return peers;
 }
 
-__global__ __launch_bounds__(RS_T) void k_varbits(const u64 *__restrict__ w, u64 n, unsigned long long *out)
+__global__ __launch_bounds__(RS_HT) void k_varbits(const u64 *__restrict__ w, u64 n, unsigned long long *out)
 {
-    __shared__ u64 lds[RS_T / IVX_WAVE];
+    __shared__ u64 lds[RS_HT / IVX_WAVE];
     const u64 x0 = n ? w[0] : 0;
     u64 acc = 0;
-    for (u64 i = (u64)blockIdx.x * RS_T + threadIdx.x; i < n; i += (u64)gridDim.x * RS_T) acc |= w[i] ^ x0;
+    for (u64 i = (u64)blockIdx.x * RS_HT + threadIdx.x; i < n; i += (u64)gridDim.x * RS_HT) acc |= w[i] ^ x0;
 #pragma unroll
     for (int d = IVX_WAVE / 2; d > 0; d >>= 1) acc |= __shfl_xor(acc, d, IVX_WAVE);
     if (lane_id() == 0) lds[threadIdx.x / IVX_WAVE] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
         u64 a = 0;
-        for (int i = 0; i < RS_T / IVX_WAVE; i++) a |= lds[i];
+        for (int i = 0; i < RS_HT / IVX_WAVE; i++) a |= lds[i];
         if (a) atomicOr(out, (unsigned long long)a);
     }
 }
 
-__global__ __launch_bounds__(RS_T) void k_hist(const u64 *__restrict__ w, u64 n, int shift, u32 nblk, u32 *__restrict__ hist)
+__global__ __launch_bounds__(RS_HT) void k_hist(const u64 *__restrict__ w, u64 n, int shift, u32 nblk, u32 *__restrict__ hist)
 {
-    __shared__ u32 cnt[RS_WAVES][256];
-    for (int i = threadIdx.x; i < RS_WAVES * 256; i += RS_T) (&cnt[0][0])[i] = 0;
+    __shared__ u32 cnt[RS_HWAVES][256];
+    for (int i = threadIdx.x; i < RS_HWAVES * 256; i += RS_HT) (&cnt[0][0])[i] = 0;
     __syncthreads();
     const u64 lo = (u64)blockIdx.x * RS_CHUNK;
     const u64 hi = lo + RS_CHUNK < n ? lo + RS_CHUNK : n;
     const u32 wv = threadIdx.x / IVX_WAVE;
-    for (u64 i0 = lo; i0 < hi; i0 += RS_T) {
+    for (u64 i0 = lo; i0 < hi; i0 += RS_HT) {
         const u64 i = i0 + threadIdx.x;
         const bool valid = i < hi;
         const u32 d = valid ? (u32)((w[i] >> shift) & 0xFF) : 0u;
@@ -91,7 +96,7 @@ __global__ __launch_bounds__(RS_T) void k_hist(const u64 *__restrict__ w, u64 n,
         const u32 d = threadIdx.x;
         u32 s = 0;
 #pragma unroll
-        for (int k = 0; k < RS_WAVES; k++) s += cnt[k][d];
+        for (int k = 0; k < RS_HWAVES; k++) s += cnt[k][d];
         hist[(u64)d * nblk + blockIdx.x] = s;
     }
 }
@@ -100,6 +105,7 @@ template <int NW>
 __global__ __launch_bounds__(RS_T) void k_scatter(CPtrs<NW> in, Ptrs<NW> out, u64 n, int word, int shift, u32 nblk,
                                                  const u32 *__restrict__ offs)
 {
+    constexpr int RS_I = Tile<NW>::I, RS_TILE = Tile<NW>::N, RS_WTILE = Tile<NW>::WT;
     __shared__ u64 rec[NW][RS_TILE];
     __shared__ u32 wcnt[RS_WAVES][256];          // per-wave digit counts -> exclusive offsets across waves
     __shared__ u32 dstart[256];                  // first local slot of the digit in this tile
@@ -108,7 +114,7 @@ __global__ __launch_bounds__(RS_T) void k_scatter(CPtrs<NW> in, Ptrs<NW> out, u6
     __shared__ u32 scan_lds[RS_T / IVX_WAVE + 1];
 
     const u32 tid = threadIdx.x, wv = tid / IVX_WAVE, ln = lane_id();
-    gbase[tid] = offs[(u64)tid * nblk + blockIdx.x];
+    if (tid < 256) gbase[tid] = offs[(u64)tid * nblk + blockIdx.x];
     const u64 lo = (u64)blockIdx.x * RS_CHUNK;
     const u64 hi = lo + RS_CHUNK < n ? lo + RS_CHUNK : n;
 
@@ -142,11 +148,14 @@ __global__ __launch_bounds__(RS_T) void k_scatter(CPtrs<NW> in, Ptrs<NW> out, u6
         {
             const u32 d = tid;
             u32 run = 0;
+            if (d < 256) {
 #pragma unroll
-            for (int k = 0; k < RS_WAVES; k++) { const u32 c = wcnt[k][d]; wcnt[k][d] = run; run += c; }
-            tcnt[d] = run;
+                for (int k = 0; k < RS_WAVES; k++) { const u32 c = wcnt[k][d]; wcnt[k][d] = run; run += c; }
+                tcnt[d] = run;
+            }
             u32 tot;
-            dstart[d] = block_excl_scan<u32, RS_T>(run, scan_lds, &tot);
+            const u32 ds = block_excl_scan<u32, RS_T>(run, scan_lds, &tot);
+            if (d < 256) dstart[d] = ds;
         }
         __syncthreads();
         // ---- local reorder through LDS
@@ -174,7 +183,7 @@ __global__ __launch_bounds__(RS_T) void k_scatter(CPtrs<NW> in, Ptrs<NW> out, u6
             }
         }
         __syncthreads();
-        gbase[tid] += tcnt[tid];
+        if (tid < 256) gbase[tid] += tcnt[tid];
         __syncthreads();
     }
 }
@@ -190,7 +199,7 @@ ivx_status sort_impl(ivx_ctx *ctx, u64 *const *a, u64 *const *b, u64 n, const iv
     unsigned long long *d_var = (unsigned long long *)(ctx->d_scalars + 16);
     IVX_HIP(ctx, hipMemsetAsync(d_var, 0, 8 * sizeof(u64), st));
     for (int f = 0; f < nfields; f++)
-        hipLaunchKernelGGL(k_varbits, dim3(ivx_stream_grid(n, RS_T * 16, 1024)), dim3(RS_T), 0, st, (const u64 *)a[fields[f].word], n, d_var + f);
+        hipLaunchKernelGGL(k_varbits, dim3(ivx_stream_grid(n, RS_HT * 16, 1024)), dim3(RS_HT), 0, st, (const u64 *)a[fields[f].word], n, d_var + f);
     IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 16, d_var, 8 * sizeof(u64), hipMemcpyDeviceToHost, st));
     IVX_HIP(ctx, hipStreamSynchronize(st));
 
@@ -208,7 +217,7 @@ ivx_status sort_impl(ivx_ctx *ctx, u64 *const *a, u64 *const *b, u64 n, const iv
             u64 *const *dst = cur ? a : b;
             CPtrs<NW> ci; Ptrs<NW> po;
             for (int q = 0; q < NW; q++) { ci.w[q] = src[q]; po.w[q] = dst[q]; }
-            hipLaunchKernelGGL(k_hist, dim3(nblk), dim3(RS_T), 0, st, (const u64 *)src[fields[f].word], n, sh, nblk, hist);
+            hipLaunchKernelGGL(k_hist, dim3(nblk), dim3(RS_HT), 0, st, (const u64 *)src[fields[f].word], n, sh, nblk, hist);
             IVX_TRY(ivx_scan_exclusive_u32(ctx, hist, (u64)256 * nblk));
             hipLaunchKernelGGL((k_scatter<NW>), dim3(nblk), dim3(RS_T), 0, st, ci, po, n, fields[f].word, sh, nblk, (const u32 *)hist);
             cur ^= 1;

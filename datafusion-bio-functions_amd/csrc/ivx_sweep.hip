@@ -56,23 +56,114 @@ __global__ __launch_bounds__(ST) void k_unpack64(const u64 *__restrict__ w0, con
     if (rows) rows[i] = (u32)w2[i];
 }
 
+// ---- packed variant: when (key, start - min start, end - min end) fit 64 bits together -- genomic
+// coordinates always do -- the sort key is ONE word and the record 16 bytes instead of 24, with fewer
+// radix digits in total
+struct Range64 { long long min_s, max_s, min_e, max_e; };
+
+__global__ __launch_bounds__(ST) void k_range64(const u32 *__restrict__ key, const i64 *__restrict__ s, const i64 *__restrict__ e,
+                                                u64 n, u32 nkeys, Range64 *out, u32 *flags)
+{
+    __shared__ i64 red[4][ST / IVX_WAVE];
+    i64 lo_s = INT64_MAX, hi_s = INT64_MIN, lo_e = INT64_MAX, hi_e = INT64_MIN;
+    bool bad = false;
+    for (u64 i = (u64)blockIdx.x * ST + threadIdx.x; i < n; i += (u64)gridDim.x * ST) {
+        const i64 a = s[i], b = e[i];
+        lo_s = a < lo_s ? a : lo_s; hi_s = a > hi_s ? a : hi_s;
+        lo_e = b < lo_e ? b : lo_e; hi_e = b > hi_e ? b : hi_e;
+        bad |= key && key[i] >= nkeys;
+    }
+#pragma unroll
+    for (int d = IVX_WAVE / 2; d > 0; d >>= 1) {
+        i64 t;
+        t = __shfl_xor(lo_s, d, IVX_WAVE); lo_s = t < lo_s ? t : lo_s;
+        t = __shfl_xor(hi_s, d, IVX_WAVE); hi_s = t > hi_s ? t : hi_s;
+        t = __shfl_xor(lo_e, d, IVX_WAVE); lo_e = t < lo_e ? t : lo_e;
+        t = __shfl_xor(hi_e, d, IVX_WAVE); hi_e = t > hi_e ? t : hi_e;
+    }
+    const u32 wv = threadIdx.x / IVX_WAVE;
+    if (lane_id() == 0) { red[0][wv] = lo_s; red[1][wv] = hi_s; red[2][wv] = lo_e; red[3][wv] = hi_e; }
+    if (bad) flags[0] = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < ST / IVX_WAVE; w++) {
+            lo_s = red[0][w] < lo_s ? red[0][w] : lo_s; hi_s = red[1][w] > hi_s ? red[1][w] : hi_s;
+            lo_e = red[2][w] < lo_e ? red[2][w] : lo_e; hi_e = red[3][w] > hi_e ? red[3][w] : hi_e;
+        }
+        atomicMin(&out->min_s, (long long)lo_s); atomicMax(&out->max_s, (long long)hi_s);
+        atomicMin(&out->min_e, (long long)lo_e); atomicMax(&out->max_e, (long long)hi_e);
+    }
+}
+
+struct Pack64 { i64 min_s, min_e; u32 bits_s, bits_e; };
+__device__ __forceinline__ u64 shl64(u64 x, u32 sh) { return sh >= 64 ? 0 : x << sh; }
+__device__ __forceinline__ u64 shr64(u64 x, u32 sh) { return sh >= 64 ? 0 : x >> sh; }
+__device__ __forceinline__ u64 low64(u64 x, u32 bits) { return bits >= 64 ? x : x & ((1ull << bits) - 1); }
+
+__global__ __launch_bounds__(ST) void k_pack1(const u32 *__restrict__ key, const i64 *__restrict__ s, const i64 *__restrict__ e,
+                                              u64 n, Pack64 p, u64 *w0, u64 *w1)
+{
+    const u64 i = (u64)blockIdx.x * ST + threadIdx.x;
+    if (i >= n) return;
+    const u64 k = key ? key[i] : 0u;
+    w0[i] = shl64(k, p.bits_s + p.bits_e) | shl64((u64)s[i] - (u64)p.min_s, p.bits_e) | ((u64)e[i] - (u64)p.min_e);
+    w1[i] = i;
+}
+
+__global__ __launch_bounds__(ST) void k_unpack1(const u64 *__restrict__ w0, const u64 *__restrict__ w1, u64 n, Pack64 p,
+                                                u32 *ks, i64 *ss, i64 *es, u32 *rows)
+{
+    const u64 i = (u64)blockIdx.x * ST + threadIdx.x;
+    if (i >= n) return;
+    const u64 w = w0[i];
+    ks[i] = (u32)shr64(w, p.bits_s + p.bits_e);
+    ss[i] = (i64)(low64(shr64(w, p.bits_e), p.bits_s) + (u64)p.min_s);
+    es[i] = (i64)(low64(w, p.bits_e) + (u64)p.min_e);
+    if (rows) rows[i] = (u32)w1[i];
+}
+
+u32 bits_of(u64 x) { u32 b = 0; while (x) { b++; x >>= 1; } return b; }
+
 // sort (key,start,end,row) ascending; rows of equal (key,start,end) keep input order = ascending row
 ivx_status sort64(ivx_ctx *ctx, int slot_a, int slot_b, const u32 *key, const i64 *s, const i64 *e, u64 n, u32 nkeys,
                   u32 *ks, i64 *ss, i64 *es, u32 *rows)
 {
     if (n == 0) return IVX_OK;
+    hipStream_t st = ctx->stream;
+    u32 *flags = (u32 *)(ctx->d_scalars + 8);
+    Range64 *d_rng = (Range64 *)(ctx->d_scalars + 24);
+    Range64 *h_init = (Range64 *)(ctx->h_scalars + 28);                   // pinned, so the async copy may read it later
+    *h_init = Range64{INT64_MAX, INT64_MIN, INT64_MAX, INT64_MIN};
+    IVX_HIP(ctx, hipMemcpyAsync(d_rng, h_init, sizeof(Range64), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_range64, dim3(ivx_stream_grid(n, ST * 8, 2048)), dim3(ST), 0, st, key, s, e, n, nkeys, d_rng, flags);
+    IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 24, d_rng, sizeof(Range64), hipMemcpyDeviceToHost, st));
+    IVX_HIP(ctx, hipStreamSynchronize(st));
+    const Range64 r = *(const Range64 *)(ctx->h_scalars + 24);
+    Pack64 p;
+    p.min_s = r.min_s; p.min_e = r.min_e;
+    p.bits_s = bits_of((u64)r.max_s - (u64)r.min_s); p.bits_e = bits_of((u64)r.max_e - (u64)r.min_e);
+    const u32 bits_k = bits_of(nkeys ? nkeys - 1 : 0);
+    const u32 total = p.bits_s + p.bits_e + bits_k;
     u64 *a[3], *b[3];
-    for (int q = 0; q < 3; q++) {
+    const int nw = total <= 64 ? 2 : 3;
+    for (int q = 0; q < nw; q++) {
         IVX_TRY(ctx->get_scratch(slot_a + q, n * sizeof(u64), (void **)&a[q]));
         IVX_TRY(ctx->get_scratch(slot_b + q, n * sizeof(u64), (void **)&b[q]));
     }
-    u32 *flags = (u32 *)(ctx->d_scalars + 8);
-    hipLaunchKernelGGL(k_pack64, dim3(grid1(n)), dim3(ST), 0, ctx->stream, key, s, e, n, nkeys, a[0], a[1], a[2], flags);
-    const ivx_sort_field f[3] = {{0, 0, 64}, {1, 0, 64}, {2, 32, 64}};
     int in_b = 0;
-    IVX_TRY(ivx_radix_sort(ctx, 3, a, b, n, f, 3, &in_b));
-    u64 *const *r = in_b ? b : a;
-    hipLaunchKernelGGL(k_unpack64, dim3(grid1(n)), dim3(ST), 0, ctx->stream, (const u64 *)r[0], (const u64 *)r[1], (const u64 *)r[2], n, ks, ss, es, rows);
+    if (nw == 2) {
+        hipLaunchKernelGGL(k_pack1, dim3(grid1(n)), dim3(ST), 0, st, key, s, e, n, p, a[0], a[1]);
+        const ivx_sort_field f[1] = {{0, 0, (int)((total + 7) / 8 * 8)}};
+        IVX_TRY(ivx_radix_sort(ctx, 2, a, b, n, f, 1, &in_b));
+        u64 *const *o = in_b ? b : a;
+        hipLaunchKernelGGL(k_unpack1, dim3(grid1(n)), dim3(ST), 0, st, (const u64 *)o[0], (const u64 *)o[1], n, p, ks, ss, es, rows);
+    } else {
+        hipLaunchKernelGGL(k_pack64, dim3(grid1(n)), dim3(ST), 0, st, key, s, e, n, nkeys, a[0], a[1], a[2], flags);
+        const ivx_sort_field f[3] = {{0, 0, 64}, {1, 0, 64}, {2, 32, 64}};
+        IVX_TRY(ivx_radix_sort(ctx, 3, a, b, n, f, 3, &in_b));
+        u64 *const *o = in_b ? b : a;
+        hipLaunchKernelGGL(k_unpack64, dim3(grid1(n)), dim3(ST), 0, st, (const u64 *)o[0], (const u64 *)o[1], (const u64 *)o[2], n, ks, ss, es, rows);
+    }
     IVX_HIP(ctx, hipGetLastError());
     return IVX_OK;
 }

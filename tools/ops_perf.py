@@ -55,7 +55,7 @@ if "merge" in which or "subtract" in which or "cluster" in which or "complement"
         nr = n // 10
         rk, rs, re = synth.gen_torch(nr, 150, 24, 0x5EED0009, dev)
         rs64, re64 = rs.to(torch.int64), re.to(torch.int64) + 1
-        ts, out = timed(lambda: ctx.subtract(k, s64, e64, rk, rs64, re64, n_keys=24), reps=1)
+        ts, out = timed(lambda: ctx.subtract(k, s64, e64, rk, rs64, re64, n_keys=24), reps=2)
         m = out[0].numel()
         report(f"subtract {n}-{nr} (count+fill)", ts, 20 * (n + nr) + 20 * m, f"out rows {m}")
     if "subtract" in which:
@@ -67,7 +67,7 @@ if "merge" in which or "subtract" in which or "cluster" in which or "complement"
         s2, e2 = s2.to(torch.int64), e2.to(torch.int64) + 1
         for tag, (kk, ss, ee, nn) in (("dense", (k, s64, e64, n)), ("sparse", (k2, s2, e2, n2))):
             if "cluster" in which:
-                tc, out = timed(lambda: ctx.cluster(kk, ss, ee, n_keys=24), reps=2)
+                tc, out = timed(lambda: ctx.cluster(kk, ss, ee, n_keys=24), reps=3)
                 report(f"cluster {tag} {nn}", tc, 68 * nn, f"kernel {ctx.last_kernel_ms():.3f} ms clusters {out['n_clusters']}")
                 del out
             if "complement" in which:
