@@ -89,11 +89,17 @@ def main():
         seed = 0x5EED0000 + 2 * cfg
         bk, bs, be = synth.gen_torch(n_build, 1000, n_contigs, seed + 0, dev)
         pk, ps, pe = synth.gen_torch(n_probe, 150, n_contigs, seed + 1, dev)
-        w = (torch.bincount(bk, minlength=n_contigs) + torch.bincount(pk, minlength=n_contigs)).cpu().numpy()
-        mine = torch.from_numpy(shard.assign_keys_lpt(w, world) == rank).to(dev)
-        mb, mp = mine[bk.long()], mine[pk.long()]
-        bk, bs, be = bk[mb].contiguous(), bs[mb].contiguous(), be[mb].contiguous()
-        pk, ps, pe = pk[mp].contiguous(), ps[mp].contiguous(), pe[mp].contiguous()
+        if n_contigs >= world:
+            w = (torch.bincount(bk, minlength=n_contigs) + torch.bincount(pk, minlength=n_contigs)).cpu().numpy()
+            mine = torch.from_numpy(shard.assign_keys_lpt(w, world) == rank).to(dev)
+            mb, mp = mine[bk.long()], mine[pk.long()]
+            bk, bs, be = bk[mb].contiguous(), bs[mb].contiguous(), be[mb].contiguous()
+            pk, ps, pe = pk[mp].contiguous(), ps[mp].contiguous(), pe[mp].contiguous()
+        else:
+            # fewer contigs than ranks (the single-contig workload): build side replicated, probe rows split
+            # evenly, still no exchange (SURVEY 8e fallback)
+            lo, hi = n_probe * rank // world, n_probe * (rank + 1) // world
+            pk, ps, pe = pk[lo:hi].contiguous(), ps[lo:hi].contiguous(), pe[lo:hi].contiguous()
         n_build, n_probe = int(bk.numel()), int(pk.numel())
     torch.cuda.synchronize()
 
