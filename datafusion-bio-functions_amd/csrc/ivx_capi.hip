@@ -306,7 +306,7 @@ static ivx_status overlap_common(ivx_ctx *ctx, const ivx_index *ix, int mem, int
     {
         // large COUNT/FILL batches: partition the probe rows by index region and probe from LDS;
         // small batches and the per-row modes gather straight from the index
-        bool regions = ix->jv_nreg > 0 && (mode == JP_COUNT || mode == JP_FILL) && n >= (1u << 18);
+        bool regions = ix->jv_nreg > 0 && (mode == JP_COUNT || mode == JP_FILL) && n >= (1u << 21);   // measured crossover (tools/crossover.py)
         if (const char *f = getenv("IVX_JOIN_PATH")) {
             if (!strcmp(f, "direct")) regions = false;
             else if (!strcmp(f, "regions")) regions = ix->jv_nreg > 0 && (mode == JP_COUNT || mode == JP_FILL);

@@ -196,7 +196,7 @@ def test_count_coverage_large_batch_default_path(ctx):
     # big enough for the region partition by default: uneven keys, probe keys without build rows, a ragged
     # last chunk, long probe rows (beyond the LDS slice halo) and chromosome-long build rows (upper levels)
     bk, bs, be = synth(250_000, 51, nkeys=30, mean_len=700, span=30_000_000)
-    pk, ps, pe = synth(2_500_003, 52, nkeys=33, mean_len=150, span=30_000_000)
+    pk, ps, pe = synth(3_300_003, 52, nkeys=33, mean_len=150, span=30_000_000)
     pe[::97] = ps[::97] + 120_000
     bs[:40] = 0; be[:40] = 29_000_000
     pe[5::1001] = ps[5::1001] - 2                          # inverted queries
