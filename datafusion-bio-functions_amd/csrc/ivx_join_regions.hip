@@ -32,7 +32,7 @@ constexpr int PA_T = 1024;
 constexpr int PA_I = 8;
 constexpr int PA_TILE = PA_T * PA_I;              // 8192 rows: ~40 rows per region and tile; one workgroup per CU keeps the open output lines within L2
 constexpr int PA_TPB = 4;
-constexpr u64 PA_CHUNK = (u64)PA_TILE * PA_TPB;   // 16384 rows per workgroup
+constexpr u64 PA_CHUNK = (u64)PA_TILE * PA_TPB;   // most rows one workgroup takes (32768)
 constexpr int PA_ND = 256;                        // radix digits = regions (+ unused)
 constexpr u32 NO_REGION = 0xFFFFFFFFu;
 constexpr u32 KT_MAX = 256;                       // per-key tables cached in LDS up to this many keys
@@ -117,7 +117,7 @@ __device__ __forceinline__ void load4(const u32 *__restrict__ pkey, const i32 *_
 // (interval_tree.rs:185-188, :253-256; i32 wrapping like the reference's release build)
 template <bool VEC>
 __global__ __launch_bounds__(PA_T) void k_part_hist(JoinIndexView ix, const u32 *__restrict__ pkey, const i32 *__restrict__ ps,
-                                                    u64 n, u32 nblk, u32 *__restrict__ hist, u32 adj)
+                                                    u64 n, u32 nblk, u32 chunk, u32 *__restrict__ hist, u32 adj)
 {
     __shared__ u32 cnt[256];
     __shared__ i32 s_origin[KT_MAX];
@@ -126,8 +126,8 @@ __global__ __launch_bounds__(PA_T) void k_part_hist(JoinIndexView ix, const u32 
     keytab_load(ix, s_origin, s_last, s_kreg, kt);
     if (threadIdx.x < PA_ND) cnt[threadIdx.x] = 0;
     __syncthreads();
-    const u64 lo = (u64)blockIdx.x * PA_CHUNK;
-    const u64 hi = lo + PA_CHUNK < n ? lo + PA_CHUNK : n;
+    const u64 lo = (u64)blockIdx.x * chunk;
+    const u64 hi = lo + chunk < n ? lo + chunk : n;
     for (u64 i0 = lo; i0 < hi; i0 += (u64)PA_T * 4) {
         u32 k[4]; i32 q[4], unused[4];
         const u64 i = i0 + (u64)threadIdx.x * 4;
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(PA_T) void k_part_hist(JoinIndexView ix, const u32 
 template <bool VEC, typename RowT>
 __global__ __launch_bounds__(PA_T) void k_part_scatter(JoinIndexView ix, const u32 *__restrict__ pkey, const i32 *__restrict__ ps,
                                                        const i32 *__restrict__ pe, u64 n, u32 nblk, const u32 *__restrict__ offs,
-                                                       u64 *__restrict__ out_se, RowT *__restrict__ out_row, u32 adj, int dbg)
+                                                       u64 *__restrict__ out_se, RowT *__restrict__ out_row, u32 chunk, u32 adj, int dbg)
 {
     __shared__ u64 r_se[PA_TILE];
     __shared__ RowT r_row[PA_TILE];
@@ -165,8 +165,8 @@ __global__ __launch_bounds__(PA_T) void k_part_scatter(JoinIndexView ix, const u
     KeyTab kt;
     keytab_load(ix, s_origin, s_last, s_kreg, kt);
     if (tid < PA_ND) gbase[tid] = offs[(u64)tid * nblk + blockIdx.x];
-    const u64 lo = (u64)blockIdx.x * PA_CHUNK;
-    const u64 hi = lo + PA_CHUNK < n ? lo + PA_CHUNK : n;
+    const u64 lo = (u64)blockIdx.x * chunk;
+    const u64 hi = lo + chunk < n ? lo + chunk : n;
     for (u64 t0 = lo; t0 < hi; t0 += PA_TILE) {
         if (tid < PA_ND) tcnt[tid] = 0;
         __syncthreads();
@@ -632,6 +632,9 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
     if (FILL && round && !(dbg & 32)) round_copy_out(L, pend_mine, pend_start, round - 1, wv, ob, op, cap, dbg);
 }
 
+// rows one partition workgroup takes: 1, 2 or 4 tiles, so that mid-size batches still spread over all CUs
+static inline u32 part_chunk(u64 n) { return (u32)PA_TILE * (n >= (16u << 20) ? 4u : n >= (4u << 20) ? 2u : 1u); }
+
 // ------------------------------------------------------------------ values back into input order
 // The scatter wrote, for every (region, workgroup chunk), one contiguous run, and kept each row's index
 // inside its 32768-row chunk.  So the values of one chunk are ~200 runs of the value stream: read them
@@ -642,21 +645,21 @@ constexpr u32 UP_CHUNK = (u32)PA_CHUNK;
 
 template <bool SIGNED>
 __global__ __launch_bounds__(PA_T) void k_unpermute(const u32 *__restrict__ val, const unsigned short *__restrict__ cidx,
-                                                    const u32 *__restrict__ offs, u32 nblk, u32 nreg, u64 n, i64 *__restrict__ out)
+                                                    const u32 *__restrict__ offs, u32 nblk, u32 chunk, u32 nreg, u64 n, i64 *__restrict__ out)
 {
     __shared__ u32 s_val[UP_CHUNK];
     __shared__ u32 s_pre[PA_ND + 1], s_g[PA_ND];
     __shared__ u32 scan_lds[PA_T / IVX_WAVE + 1];
     const u32 tid = threadIdx.x, blk = blockIdx.x;
-    const u64 lo = (u64)blk * PA_CHUNK;
-    const u32 len = (u32)(lo + PA_CHUNK < n ? PA_CHUNK : n - lo);
+    const u64 lo = (u64)blk * chunk;
+    const u32 len = (u32)(lo + chunk < n ? chunk : n - lo);
     u32 c = 0, g = 0;
     if (tid < nreg) { g = offs[(u64)tid * nblk + blk]; c = offs[(u64)tid * nblk + blk + 1] - g; }
     u32 tot;
     const u32 ex = block_excl_scan<u32, PA_T>(c, scan_lds, &tot);
     if (tid < PA_ND) { s_pre[tid] = ex; s_g[tid] = g; }
     if (tid == 0) s_pre[PA_ND] = tot;
-    for (u32 t = tid; t < UP_CHUNK; t += PA_T) s_val[t] = 0;
+    for (u32 t = tid; t < chunk; t += PA_T) s_val[t] = 0;
     __syncthreads();
     // wavefront w owns elements [w*per, (w+1)*per) of the chunk's region-major value list
     const u32 wv = tid / IVX_WAVE, ln = lane_id();
@@ -683,7 +686,8 @@ ivx_status ivx_rowval_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, int c
 {
     if (n == 0) return IVX_OK;
     hipStream_t st = ctx->stream;
-    const u32 nblk = (u32)((n + PA_CHUNK - 1) / PA_CHUNK);
+    const u32 chunk = part_chunk(n);
+    const u32 nblk = (u32)((n + chunk - 1) / chunk);
     u32 *hist, *val; u64 *pse; unsigned short *cidx;
     const u64 nh = (u64)256 * nblk + 1;
     IVX_TRY(ctx->get_scratch(WS_SORTHIST, nh * sizeof(u32), (void **)&hist));
@@ -693,17 +697,17 @@ ivx_status ivx_rowval_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, int c
     IVX_HIP(ctx, hipMemsetAsync(hist + (nh - 1), 0, sizeof(u32), st));
     const u32 adj = strict ? 1u : 0u;
     const bool vec = (((uintptr_t)key | (uintptr_t)s | (uintptr_t)e) & 15) == 0;
-    if (vec) hipLaunchKernelGGL(k_part_hist<true>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, n, nblk, hist, adj);
-    else hipLaunchKernelGGL(k_part_hist<false>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, n, nblk, hist, adj);
+    if (vec) hipLaunchKernelGGL(k_part_hist<true>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, n, nblk, chunk, hist, adj);
+    else hipLaunchKernelGGL(k_part_hist<false>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, n, nblk, chunk, hist, adj);
     IVX_TRY(ivx_scan_exclusive_u32(ctx, hist, nh));
-    if (vec) hipLaunchKernelGGL((k_part_scatter<true, unsigned short>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, cidx, adj, 0);
-    else hipLaunchKernelGGL((k_part_scatter<false, unsigned short>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, cidx, adj, 0);
+    if (vec) hipLaunchKernelGGL((k_part_scatter<true, unsigned short>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, cidx, chunk, adj, 0);
+    else hipLaunchKernelGGL((k_part_scatter<false, unsigned short>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, cidx, chunk, adj, 0);
     if (coverage)
         hipLaunchKernelGGL((k_probe_regions<RV_COVERAGE, RP_B>), dim3(RP_VGRID), dim3(RP_T), 0, st, jv, (const u64 *)pse, (const u32 *)nullptr, (const u32 *)hist, nblk, 1u, val, (u32 *)nullptr, (u64)0, (unsigned long long *)nullptr, 0);
     else
         hipLaunchKernelGGL((k_probe_regions<RV_COUNT, RP_B>), dim3(RP_VGRID), dim3(RP_T), 0, st, jv, (const u64 *)pse, (const u32 *)nullptr, (const u32 *)hist, nblk, 1u, val, (u32 *)nullptr, (u64)0, (unsigned long long *)nullptr, 0);
-    if (coverage) hipLaunchKernelGGL(k_unpermute<true>, dim3(nblk), dim3(PA_T), 0, st, (const u32 *)val, (const unsigned short *)cidx, (const u32 *)hist, nblk, (u32)PA_ND, n, out);
-    else hipLaunchKernelGGL(k_unpermute<false>, dim3(nblk), dim3(PA_T), 0, st, (const u32 *)val, (const unsigned short *)cidx, (const u32 *)hist, nblk, (u32)PA_ND, n, out);
+    if (coverage) hipLaunchKernelGGL(k_unpermute<true>, dim3(nblk), dim3(PA_T), 0, st, (const u32 *)val, (const unsigned short *)cidx, (const u32 *)hist, nblk, chunk, (u32)PA_ND, n, out);
+    else hipLaunchKernelGGL(k_unpermute<false>, dim3(nblk), dim3(PA_T), 0, st, (const u32 *)val, (const unsigned short *)cidx, (const u32 *)hist, nblk, chunk, (u32)PA_ND, n, out);
     IVX_HIP(ctx, hipGetLastError());
     return IVX_OK;
 }
@@ -714,7 +718,8 @@ ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, int mod
 {
     if (n == 0) return IVX_OK;
     hipStream_t st = ctx->stream;
-    const u32 nblk = (u32)((n + PA_CHUNK - 1) / PA_CHUNK);
+    const u32 chunk = part_chunk(n);
+    const u32 nblk = (u32)((n + chunk - 1) / chunk);
     u32 *hist; u64 *pse; u32 *prow;
     const u64 nh = (u64)256 * nblk + 1;
     IVX_TRY(ctx->get_scratch(WS_SORTHIST, nh * sizeof(u32), (void **)&hist));
@@ -723,11 +728,11 @@ ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, int mod
     IVX_HIP(ctx, hipMemsetAsync(hist + (nh - 1), 0, sizeof(u32), st));
     const int dbg = getenv("IVX_DBG") ? atoi(getenv("IVX_DBG")) : 0;   // ablation switches for profiling only
     const bool vec = (((uintptr_t)key | (uintptr_t)s | (uintptr_t)e) & 15) == 0;
-    if (vec) hipLaunchKernelGGL(k_part_hist<true>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, n, nblk, hist, 0u);
-    else hipLaunchKernelGGL(k_part_hist<false>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, n, nblk, hist, 0u);
+    if (vec) hipLaunchKernelGGL(k_part_hist<true>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, n, nblk, chunk, hist, 0u);
+    else hipLaunchKernelGGL(k_part_hist<false>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, n, nblk, chunk, hist, 0u);
     IVX_TRY(ivx_scan_exclusive_u32(ctx, hist, nh));
-    if (vec) hipLaunchKernelGGL((k_part_scatter<true, u32>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, prow, 0u, dbg);
-    else hipLaunchKernelGGL((k_part_scatter<false, u32>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, prow, 0u, dbg);
+    if (vec) hipLaunchKernelGGL((k_part_scatter<true, u32>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, prow, chunk, 0u, dbg);
+    else hipLaunchKernelGGL((k_part_scatter<false, u32>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, prow, chunk, 0u, dbg);
     unsigned long long *cur = (unsigned long long *)d_cursor;
     if (mode == JP_FILL) {   // single walk: pairs staged per wavefront, one output reservation per workgroup and round
         // rows per lane and batch by the expected matches per row (cap / n: callers size the output from the

@@ -66,7 +66,7 @@ bool rowval_regions_wanted(const ivx_index *ix, u64 n)
     const char *f = getenv("IVX_ROWVAL_PATH");                          // tests: "direct" | "regions"
     if (f && !strcmp(f, "direct")) return false;
     if (f && !strcmp(f, "regions")) return true;
-    return n >= (3u << 20);                                             // measured crossover (tools/crossover.py)
+    return n >= (1u << 21);                                             // measured crossover (tools/crossover.py)
 }
 
 // ======================================================================= a5
