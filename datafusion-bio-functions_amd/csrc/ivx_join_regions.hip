@@ -26,6 +26,14 @@
 
 namespace {
 
+// kernels carry an `int dbg` of ablation switches (skip stores, synthetic loads, ...) that only means
+// something in profiling builds; elsewhere it is forced to 0 and the branches fold away
+#ifdef IVX_ABLATE
+#define IVX_DBG_ARG(dbg) (dbg)
+#else
+#define IVX_DBG_ARG(dbg) 0
+#endif
+
 // ------------------------------------------------------------------ partition pass
 
 constexpr int PA_T = 1024;
@@ -162,6 +170,7 @@ __global__ __launch_bounds__(PA_T) void k_part_scatter(JoinIndexView ix, const u
     __shared__ u32 s_last[KT_MAX], s_kreg[KT_MAX];
 
     const u32 tid = threadIdx.x;
+    dbg = IVX_DBG_ARG(dbg);
     KeyTab kt;
     keytab_load(ix, s_origin, s_last, s_kreg, kt);
     if (tid < PA_ND) gbase[tid] = offs[(u64)tid * nblk + blockIdx.x];
@@ -538,6 +547,7 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
                                                         unsigned long long *cursor, int dbg)
 {
     constexpr bool FILL = MODE == 1;
+    dbg = IVX_DBG_ARG(dbg);
     constexpr u32 WB = IVX_WAVE * B;                                  // rows per wavefront batch
     IVX_PROBE_LDS(FILL)
     const u32 wv = threadIdx.x / IVX_WAVE, ln = lane_id();
@@ -726,7 +736,11 @@ ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, int mod
     IVX_TRY(ctx->get_scratch(WS_T0, n * sizeof(u64), (void **)&pse));
     IVX_TRY(ctx->get_scratch(WS_T1, n * sizeof(u32), (void **)&prow));
     IVX_HIP(ctx, hipMemsetAsync(hist + (nh - 1), 0, sizeof(u32), st));
-    const int dbg = getenv("IVX_DBG") ? atoi(getenv("IVX_DBG")) : 0;   // ablation switches for profiling only
+#ifdef IVX_ABLATE          // profiling builds only (tools/variant.sh <name> -DIVX_ABLATE; tools/ablate.sh): IVX_DBG bit switches
+    const int dbg = getenv("IVX_DBG") ? atoi(getenv("IVX_DBG")) : 0;
+#else
+    const int dbg = 0;
+#endif
     const bool vec = (((uintptr_t)key | (uintptr_t)s | (uintptr_t)e) & 15) == 0;
     if (vec) hipLaunchKernelGGL(k_part_hist<true>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, n, nblk, chunk, hist, 0u);
     else hipLaunchKernelGGL(k_part_hist<false>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, n, nblk, chunk, hist, 0u);
