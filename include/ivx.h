@@ -119,7 +119,9 @@ ivx_status ivx_probe_overlap_count(ivx_ctx *ctx, const ivx_index *ix, int mem,
  *       index_right) before compute::take.  Pair ORDER is unspecified (the
  *       reference pins only the row multiset).  If more than cap pairs exist
  *       nothing useful is written, *written = pairs needed and the call
- *       returns IVX_ERR_CAPACITY. */
+ *       returns IVX_ERR_CAPACITY.  cap also serves as the hint for the expected
+ *       pairs per row (cap / n): size it from ivx_probe_overlap_count, not with
+ *       a blanket maximum, or large batches run with needlessly small rounds. */
 ivx_status ivx_probe_overlap_fill(ivx_ctx *ctx, const ivx_index *ix, int mem,
                                   const uint32_t *key, const int32_t *start, const int32_t *end, uint64_t n,
                                   uint32_t *build_idx, uint32_t *probe_idx, uint64_t cap, uint64_t *written);
