@@ -1,0 +1,22 @@
+"""-m gpu: a plain C99 program against include/ivx.h, linked with libivx_hip.so only (no Python, no torch
+in the process) -- the drop-in boundary used the way a foreign host would use it."""
+import os
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_c_client_builds_and_runs(tmp_path):
+    lib = os.path.join(ROOT, "datafusion-bio-functions_amd", "lib")
+    exe = str(tmp_path / "abi_smoke")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "c", "abi_smoke.c"), "-o", exe, "-L", lib, "-livx_hip",
+                    "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "join pairs=16 written=16 rle_sum=16 valid=1" in r.stdout
+    assert "merge rows=2 first=(100,250,2) second=(300,400,1)" in r.stdout
