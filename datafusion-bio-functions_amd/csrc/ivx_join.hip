@@ -44,52 +44,70 @@ __global__ __launch_bounds__(1024) void k_join_layout(const i32 *kmin, const i32
         span[k] = c ? (u32)((i64)kmax[k] - (i64)kmin[k]) : 0u;
     }
     __syncthreads();
-    // smallest shift whose finest level fits the budget (monotone in sh)
+    // Every candidate of a search is evaluated at once, one wavefront per candidate, instead of a bisection
+    // with a workgroup reduction per step (this kernel is a serial 1-workgroup stage of every index build).
+    __shared__ u64 s_tot[40];
+    __shared__ u64 s_loff[IVX_MAXL + 1];
+    const u32 wv = t / IVX_WAVE, ln = lane_id();
+    constexpr u32 NWV = 1024 / IVX_WAVE;
+    // ---- smallest shift whose finest level fits the budget (cells are monotone in sh)
     const u64 budget0 = 2 * n + nkeys;
-    u32 lo = IVX_SH_MIN, hi = 31;
-    while (lo < hi) {
-        u32 mid = (lo + hi) / 2;
-        u64 s = 0;
-        for (u32 k = t; k < nkeys; k += 1024) s += cells_of(kcnt[k], span[k], mid);
-        u64 tot = block_sum<u64, 1024>(s, red);
-        if (tot <= budget0) hi = mid; else lo = mid + 1;
+    for (u32 sh = IVX_SH_MIN + wv; sh <= 31; sh += NWV) {
+        u64 a = 0;
+        for (u32 k = ln; k < nkeys; k += IVX_WAVE) a += cells_of(kcnt[k], span[k], sh);
+        a = wave_sum(a);
+        if (ln == 0) s_tot[sh] = a;
     }
-    if (t == 0) s_sh0 = lo;
+    __syncthreads();
+    if (t == 0) {
+        u32 sh = IVX_SH_MIN;
+        while (sh < 31 && s_tot[sh] > budget0) sh++;
+        s_sh0 = sh;
+    }
     __syncthreads();
     const u32 sh0 = s_sh0;
     u32 nlev = 0;
     for (u32 l = 0; l < IVX_MAXL; l++) { nlev = l + 1; if (sh0 + IVX_LSTEP * l >= 32) break; }
-    // exclusive prefix over (level, key) cells
-    u64 run = 0;
-    for (u32 l = 0; l < nlev; l++) {
+    // ---- exclusive prefix over (level, key) cells: wavefront l scans level l, then the level offsets are added
+    for (u32 l = wv; l < nlev; l += NWV) {
         const u32 sh = sh0 + IVX_LSTEP * l;
-        for (u32 k0 = 0; k0 < nkeys; k0 += 1024) {
-            u32 k = k0 + t;
-            u64 c = k < nkeys ? cells_of(kcnt[k], span[k], sh) : 0u;
-            u64 tot;
-            u64 ex = block_excl_scan<u64, 1024>(c, red, &tot);
-            if (k < nkeys) lbase[(u64)l * nkeys + k] = (u32)(run + ex);
-            run += tot;
+        u64 carry = 0;
+        for (u32 k0 = 0; k0 < nkeys; k0 += IVX_WAVE) {
+            const u32 k = k0 + ln;
+            const u64 c = k < nkeys ? cells_of(kcnt[k], span[k], sh) : 0u;
+            const u64 inc = wave_incl_scan(c);
+            if (k < nkeys) lbase[(u64)l * nkeys + k] = (u32)(carry + inc - c);
+            carry += __shfl(inc, IVX_WAVE - 1, IVX_WAVE);
         }
+        if (ln == 0) s_tot[l] = carry;
     }
+    __syncthreads();
     if (t == 0) {
+        u64 run = 0;
+        for (u32 l = 0; l < nlev; l++) { s_loff[l] = run; run += s_tot[l]; }
         hdr[HDR_SH0] = sh0;
         hdr[HDR_NLEV] = nlev;
         hdr[HDR_NBINS] = (u32)(run <= maxcells ? run : maxcells);   // never exceeds the budget by construction
     }
-    // ---- probe regions: runs of 2^cs level-0 cells that never straddle a key, at most IVX_MAXREG of them
-    //      (one radix digit of the probe partition pass)
-    u32 clo = 0, chi = 32;
-    while (clo < chi) {
-        const u32 mid = (clo + chi) / 2;
-        u64 s = 0;
-        for (u32 k = t; k < nkeys; k += 1024) {
-            const u64 c = cells_of(kcnt[k], span[k], sh0);
-            s += mid >= 32 ? (c ? 1u : 0u) : ((c + (1ull << mid) - 1) >> mid);
-        }
-        const u64 tot = block_sum<u64, 1024>(s, red);
-        if (tot <= IVX_MAXREG) chi = mid; else clo = mid + 1;
+    __syncthreads();
+    for (u32 l = 1 + wv; l < nlev; l += NWV) {
+        const u32 add = (u32)s_loff[l];
+        for (u32 k = ln; k < nkeys; k += IVX_WAVE) lbase[(u64)l * nkeys + k] += add;
     }
+    // ---- probe regions: runs of 2^cs level-0 cells that never straddle a key, at most IVX_MAXREG of them
+    //      (one radix digit of the probe partition pass); smallest cs that fits (monotone)
+    for (u32 mid = wv; mid <= 32; mid += NWV) {
+        u64 a = 0;
+        for (u32 k = ln; k < nkeys; k += IVX_WAVE) {
+            const u64 c = cells_of(kcnt[k], span[k], sh0);
+            a += mid >= 32 ? (c ? 1u : 0u) : ((c + (1ull << mid) - 1) >> mid);
+        }
+        a = wave_sum(a);
+        if (ln == 0) s_tot[mid] = a;
+    }
+    __syncthreads();
+    u32 clo = 0;
+    while (clo < 32 && s_tot[clo] > IVX_MAXREG) clo++;
     const u32 cs = clo;                                             // 32 = not even one region per key fits
     u64 rrun = 0;
     for (u32 k0 = 0; k0 < nkeys; k0 += 1024) {
@@ -133,39 +151,37 @@ __global__ __launch_bounds__(256) void k_join_regdesc(const i32 *origin, const u
 
 __global__ __launch_bounds__(BT) void k_join_count(const u32 *__restrict__ key, const i32 *__restrict__ s,
                                                    const i32 *__restrict__ e, u64 n, u32 nkeys,
-                                                   const i32 *origin, const u32 *lbase, u32 *hdr, u32 *bincnt)
+                                                   const i32 *origin, const u32 *lbase, u32 *hdr, u32 *bincnt,
+                                                   u32 *__restrict__ cellid, u32 *__restrict__ rank)
 {
-    __shared__ u32 levcnt[IVX_MAXL];
-    if (threadIdx.x < IVX_MAXL) levcnt[threadIdx.x] = 0;
-    __syncthreads();
     const u32 sh0 = hdr[HDR_SH0], nlev = hdr[HDR_NLEV];
+    u32 levels = 0;                                        // levels this thread put a row into
     for (u64 i = (u64)blockIdx.x * BT + threadIdx.x; i < n; i += (u64)gridDim.x * BT) {
         u32 k = key ? key[i] : 0u;
-        if (k >= nkeys) continue;
+        if (k >= nkeys) { cellid[i] = 0xFFFFFFFFu; continue; }
         i32 si = s[i], ei = e[i];
         u32 l = level_of(si, ei, sh0, nlev);
-        atomicAdd(&bincnt[cell_of(origin, lbase, nkeys, k, si, l, sh0)], 1u);
-        atomicAdd(&levcnt[l], 1u);
+        const u32 c = cell_of(origin, lbase, nkeys, k, si, l, sh0);
+        cellid[i] = c;
+        rank[i] = atomicAdd(&bincnt[c], 1u);               // the row's slot inside its cell: the scatter needs no second atomic
+        levels |= 1u << l;
     }
-    __syncthreads();
-    if (threadIdx.x < IVX_MAXL && levcnt[threadIdx.x]) atomicAdd(&hdr[HDR_LEVCNT + threadIdx.x], levcnt[threadIdx.x]);
+#pragma unroll
+    for (int d = IVX_WAVE / 2; d > 0; d >>= 1) levels |= __shfl_xor(levels, d, IVX_WAVE);
+    if (lane_id() == 0)
+        for (u32 l = 0; l < nlev; l++)
+            if ((levels >> l) & 1u) hdr[HDR_LEVCNT + l] = 1u;   // "level holds rows" flag (same value from every writer)
 }
 
-__global__ __launch_bounds__(BT) void k_join_scatter(const u32 *__restrict__ key, const i32 *__restrict__ s,
-                                                     const i32 *__restrict__ e, u64 n, u32 nkeys,
-                                                     const i32 *origin, const u32 *lbase, const u32 *hdr,
-                                                     const u32 *binstart, u32 *cursor, ivx_ent *ent)
+__global__ __launch_bounds__(BT) void k_join_scatter(const i32 *__restrict__ s, const i32 *__restrict__ e, u64 n,
+                                                     const u32 *__restrict__ binstart, const u32 *__restrict__ cellid,
+                                                     const u32 *__restrict__ rank, ivx_ent *ent)
 {
-    const u32 sh0 = hdr[HDR_SH0], nlev = hdr[HDR_NLEV];
     for (u64 i = (u64)blockIdx.x * BT + threadIdx.x; i < n; i += (u64)gridDim.x * BT) {
-        u32 k = key ? key[i] : 0u;
-        if (k >= nkeys) continue;
-        i32 si = s[i], ei = e[i];
-        u32 l = level_of(si, ei, sh0, nlev);
-        u32 c = cell_of(origin, lbase, nkeys, k, si, l, sh0);
-        u32 at = binstart[c] + atomicAdd(&cursor[c], 1u);
-        ivx_ent x; x.s = si; x.e = ei; x.row = (u32)i;
-        ent[at] = x;
+        const u32 c = cellid[i];
+        if (c == 0xFFFFFFFFu) continue;
+        ivx_ent x; x.s = s[i]; x.e = e[i]; x.row = (u32)i;
+        ent[binstart[c] + rank[i]] = x;
     }
 }
 
@@ -263,22 +279,22 @@ ivx_status ivx_join_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32
     IVX_TRY(ivx_index_alloc(ctx, ix, (IVX_MAXREG + 1) * sizeof(ivx_regdesc), (void **)&rdesc));
     IVX_TRY(ivx_index_alloc(ctx, ix, (n ? n : 1) * sizeof(ivx_ent), (void **)&ent));
 
-    i32 *kmin, *kmax; u32 *cursor, *errflag;
+    i32 *kmin, *kmax; u32 *cellid, *rank, *errflag;
     IVX_TRY(ctx->get_scratch(WS_GRID0, nkeys * sizeof(i32), (void **)&kmin));
     IVX_TRY(ctx->get_scratch(WS_GRID1, nkeys * sizeof(i32), (void **)&kmax));
-    IVX_TRY(ctx->get_scratch(WS_GRID2, (maxcells + 1) * sizeof(u32), (void **)&cursor));
+    IVX_TRY(ctx->get_scratch(WS_GRID2, (n ? n : 1) * sizeof(u32), (void **)&cellid));
+    IVX_TRY(ctx->get_scratch(WS_T9, (n ? n : 1) * sizeof(u32), (void **)&rank));
     errflag = (u32 *)(ctx->d_scalars + 8);
 
     IVX_HIP(ctx, hipMemsetAsync(errflag, 0, sizeof(u32), st));
     IVX_HIP(ctx, hipMemsetAsync(binstart, 0, (maxcells + 1) * sizeof(u32), st));
-    IVX_HIP(ctx, hipMemsetAsync(cursor, 0, (maxcells + 1) * sizeof(u32), st));
     IVX_HIP(ctx, hipMemsetAsync(hdr, 0, HDR_WORDS * sizeof(u32), st));
     IVX_TRY(ivx_keystats(ctx, key, s, n, nkeys, kmin, kmax, kcnt, errflag));
     const u32 grid = ivx_stream_grid(n, BT * 8, 1024);
     hipLaunchKernelGGL(k_join_layout, dim3(1), dim3(1024), 0, st, kmin, kmax, kcnt, nkeys, n, origin, span, lbase, hdr, maxcells, kreg, rkey);
-    hipLaunchKernelGGL(k_join_count, dim3(grid), dim3(BT), 0, st, key, s, e, n, nkeys, origin, lbase, hdr, binstart);
+    hipLaunchKernelGGL(k_join_count, dim3(grid), dim3(BT), 0, st, key, s, e, n, nkeys, origin, lbase, hdr, binstart, cellid, rank);
     IVX_TRY(ivx_scan_exclusive_u32(ctx, binstart, maxcells + 1));
-    hipLaunchKernelGGL(k_join_scatter, dim3(grid), dim3(BT), 0, st, key, s, e, n, nkeys, origin, lbase, hdr, binstart, cursor, ent);
+    hipLaunchKernelGGL(k_join_scatter, dim3(grid), dim3(BT), 0, st, s, e, n, (const u32 *)binstart, (const u32 *)cellid, (const u32 *)rank, ent);
     hipLaunchKernelGGL(k_join_regdesc, dim3(1), dim3(256), 0, st, origin, span, lbase, hdr, kreg, rkey, binstart, rdesc);
     IVX_HIP(ctx, hipGetLastError());
 
