@@ -233,3 +233,36 @@ def test_sql_range_join_with_device_take(ctx, golden):
     a = ctx.sql_range_join(reads, targets, device_take=True)
     b = ctx.sql_range_join(reads, targets, device_take=False)
     assert a.schema.names == b.schema.names and rows_of(a, a.schema.names) == rows_of(b, b.schema.names) and a.num_rows == 16
+
+
+def test_overlap_udtf_boundary_cases(ctx):
+    # R/tests/integration_test.rs:1653-1798: the five two-table cases, row counts as asserted there
+    a = table([("a", 100, 200)])
+    assert ctx.overlap(a, table([("a", 200, 300)]), strict=True).num_rows == 0      # adjacent, 0-based half-open (:1653-1680)
+    assert ctx.overlap(a, table([("a", 200, 300)])).num_rows == 1                   # adjacent, 1-based closed (:1683-1710)
+    assert ctx.overlap(a, table([("a", 100, 200)])).num_rows == 1                   # same interval (:1713-1739)
+    assert ctx.overlap(a, table([("a", 150, 180)])).num_rows == 1                   # contained (:1742-1768)
+    assert ctx.overlap(a, table([("a", 300, 400), ("b", 100, 200)])).num_rows == 0  # no matches, other contig (:1771-1798)
+
+
+def test_overlap_udtf_left_modes_keep_payload_and_multiplicity(ctx):
+    reads = pa.table({"contig": ["chr1", "chr1", "chr1", "chr2"], "pos_start": pa.array([100, 100, 1000, 50], pa.int32()),
+                      "pos_end": pa.array([200, 200, 1100, 60], pa.int32()), "name": ["dup", "dup", "miss", "other"]})
+    targets = table([("chr1", 90, 150), ("chr1", 120, 180), ("chr2", 55, 56)], pos_type=pa.int32())
+    left = ctx.overlap(reads, targets, mode="left")                              # :1888-1958, RightSemi: each matching left row once
+    assert left.schema.names == ["contig", "pos_start", "pos_end", "name"]
+    assert rows_of(left, left.schema.names) == sorted([("chr1", 100, 200, "dup"), ("chr1", 100, 200, "dup"), ("chr2", 50, 60, "other")], key=repr)
+    left_all = ctx.overlap(reads, targets, mode="left_all")                      # :1961-2017, Inner projected on the left: multiplicity kept
+    assert rows_of(left_all, left_all.schema.names) == sorted([("chr1", 100, 200, "dup")] * 4 + [("chr2", 50, 60, "other")], key=repr)
+    a = pa.table({"chr": ["a", "a"], "s": [100, 100], "e": [200, 201], "label": ["touching", "overlap"]})
+    b = pa.table({"chr": ["a"], "s": [200], "e": [300]})
+    out = ctx.overlap(a, b, mode="left", cols_left=("chr", "s", "e"), cols_right=("chr", "s", "e"), strict=True)   # :2020-2061
+    assert out.schema.names == ["chr", "s", "e", "label"] and _rows(out) == [["a", 100, 201, "overlap"]]
+
+
+def test_overlap_udtf_custom_columns(ctx):
+    # :1801-1832: left_/right_ prefixed output names follow the column arguments
+    a = pa.table({"chr": ["a"], "s": [100], "e": [200]})
+    b = pa.table({"chr": ["a"], "s": [150], "e": [250]})
+    out = ctx.overlap(a, b, cols_left=("chr", "s", "e"), cols_right=("chr", "s", "e"))
+    assert out.num_rows == 1 and out.schema.names[0] == "left_chr" and out.schema.names[3] == "right_chr"

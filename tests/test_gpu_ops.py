@@ -484,3 +484,26 @@ def test_take_device_buffers(ctx):
     idx = torch.randint(0, 100_000, (1_000_000,), generator=g, dtype=torch.int32)
     out, valid = ctx.take_fixed(src.to(dev), idx.to(dev))
     assert torch.equal(out.cpu(), src[idx.long()]) and bool(valid.all())
+
+
+def test_cluster_exons_issue_373(ctx, golden):
+    # R/tests/integration_test.rs:4026-4084: 438 694 exons, the pinned cluster extents, with 1 and with 4
+    # "target partitions" (contigs dealt round-robin, ids from the coordinator's exclusive scan)
+    from test_oracle_golden import _exons_cluster_case, _selected_cluster_rows
+    case, names, k, s, e = _exons_cluster_case(golden)
+    nk = len(names)
+    full = ctx.cluster(k, s, e, n_keys=nk)
+    assert _selected_cluster_rows(case, names, full) == sorted(case["expect"])
+    want = orc.cluster(k, s, e, n_keys=nk)
+    for c in CLUSTER_COLS:
+        assert (np.asarray(full[c]).astype(np.int64) == want[c].astype(np.int64)).all(), c
+    parts = [np.isin(k, np.arange(p, nk, 4)) for p in range(4)]
+    counts = sum(np.asarray(ctx.cluster(k[m], s[m], e[m], n_keys=nk, rows=False)["key_clusters"]).astype(np.int64) for m in parts)
+    base = np.concatenate([[0], np.cumsum(counts)[:-1]])
+    ids = {}
+    for m in parts:
+        part = ctx.cluster(k[m], s[m], e[m], n_keys=nk, key_base=base)
+        assert _selected_cluster_rows(case, names, part) == sorted(r for r in case["expect"] if names.index(r[0]) in set(np.unique(k[m]).tolist()))
+        for cid, cs, ce in zip(part["cluster"], part["cluster_start"], part["cluster_end"]):
+            assert ids.setdefault(int(cid), (int(cs), int(ce))) == (int(cs), int(ce))   # :2761-2818: an id never names two extents
+    assert len(ids) == full["n_clusters"]

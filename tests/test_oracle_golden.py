@@ -247,3 +247,26 @@ def test_oracle_matches_reference_superintervals(seed):
     b = pair_set(*orc.join(bk, bs, be, pk, ps, pe))
     assert len(a) == len(b) and (a == b).all()
     assert (orc.ref_count(bk, bs, be, pk, ps, pe) == orc.count_overlaps(bk, bs, be, pk, ps, pe)).all()
+
+
+def _exons_cluster_case(golden):
+    import pyarrow.parquet as pq
+    case = golden.cases("cluster_exons")[0]
+    t = pq.read_table(os.path.join(GOLDEN, "data", "ranges", "exons")).to_pandas()
+    names = sorted(set(t.contig), key=lambda x: x.encode())
+    ids = {n: i for i, n in enumerate(names)}
+    return case, names, t.contig.map(ids).to_numpy(np.uint32), t.pos_start.to_numpy(np.int64), t.pos_end.to_numpy(np.int64)
+
+
+def _selected_cluster_rows(case, names, c):
+    want = {(r[0], r[1], r[2]) for r in case["select"]}
+    rows = [[names[k], int(s), int(e), int(cs), int(ce)] for k, s, e, cs, ce in
+            zip(c["key"], c["start"], c["end"], c["cluster_start"], c["cluster_end"]) if (names[k], int(s), int(e)) in want]
+    return sorted(rows)
+
+
+def test_cluster_exons_issue_373(golden):
+    # 438 694 exons: the cluster extents the reference pins for five exons (one of them present 11 times)
+    case, names, k, s, e = _exons_cluster_case(golden)
+    c = orc.cluster(k, s, e, n_keys=len(names))
+    assert _selected_cluster_rows(case, names, c) == sorted(case["expect"])
