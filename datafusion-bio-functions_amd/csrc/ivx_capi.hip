@@ -312,7 +312,7 @@ static ivx_status overlap_common(ivx_ctx *ctx, const ivx_index *ix, int mem, int
             else if (!strcmp(f, "regions")) regions = ix->jv_nreg > 0 && (mode == JP_COUNT || mode == JP_FILL);
         }
         KernelTimer t(ctx);
-        if (regions) IVX_TRY(ivx_join_probe_regions(ctx, ix->jv, mode, dk, ds, de, n, d_b, d_p, cap, ctx->d_scalars));
+        if (regions) IVX_TRY(ivx_join_probe_regions(ctx, ix->jv, ix->jv_nreg, mode, dk, ds, de, n, d_b, d_p, cap, ctx->d_scalars));
         else IVX_TRY(ivx_join_probe(ctx, ix->jv, mode, dk, ds, de, n, d_row, d_ex, d_b, d_p, cap, ctx->d_scalars));
     }
     u64 tot = 0;

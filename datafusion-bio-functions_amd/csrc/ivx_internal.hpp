@@ -77,7 +77,9 @@ struct ivx_ent { i32 s, e; u32 row; };          // 12-byte AoS entry of the over
 
 // header words written by the layout kernel (device resident, read by probes)
 enum { HDR_SH0 = 0, HDR_NLEV = 1, HDR_NBINS = 2, HDR_CS = 3, HDR_NREG = 4, HDR_LEVCNT = 8 /* .. +IVX_MAXL */, HDR_WORDS = 8 + IVX_MAXL };
-#define IVX_MAXREG 255   // probe regions (one radix digit; 255 = rows that cannot match)
+#define IVX_MAXREG 255   // probe regions routed with ONE partition pass (one radix digit; 255 = rows that cannot match)
+#define IVX_MAXREG2 65025u   // most regions at all: beyond 255 the probe rows are routed by a two-digit stable sort
+#define IVX_REG_CS_MAX 13   // a region spans at most 2^13 level-0 cells, what a workgroup can stage in LDS
 
 // what a probe workgroup needs to stage one region's slice of level 0 (ivx_join_regions.hip), precomputed at
 // build time so that staging starts with ONE load instead of a chain of four dependent ones
@@ -93,8 +95,8 @@ struct JoinIndexView {
     const ivx_ent *ent;     // [n] entries grouped by bin
     const u32 *hdr;         // [HDR_WORDS]
     const u32 *kreg;        // [nkeys+1] first probe region of the key (regions never straddle keys)
-    const u32 *rkey;        // [IVX_MAXREG+1] key of a region
-    const ivx_regdesc *rdesc;   // [IVX_MAXREG+1] slice window of a region
+    const u32 *rkey;        // [IVX_MAXREG2+1] key of a region
+    const ivx_regdesc *rdesc;   // [IVX_MAXREG2+1] slice window of a region
     u32 nkeys;
 };
 
@@ -155,7 +157,7 @@ ivx_status ivx_join_probe(ivx_ctx *ctx, const JoinIndexView &jv, int mode,
                           u32 *per_row, u8 *exists, u32 *ob, u32 *op, u64 cap, u64 *d_cursor);
 enum { JP_COUNT = 0, JP_PER_ROW = 1, JP_EXISTS = 2, JP_FILL = 3 };
 // join_regions.hip: partition the probe rows by index region, probe each region from LDS
-ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, int mode,
+ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nreg, int mode,
                                   const u32 *key, const i32 *s, const i32 *e, u64 n,
                                   u32 *ob, u32 *op, u64 cap, u64 *d_cursor);
 

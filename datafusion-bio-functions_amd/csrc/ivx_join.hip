@@ -108,6 +108,9 @@ __global__ __launch_bounds__(1024) void k_join_layout(const i32 *kmin, const i32
     __syncthreads();
     u32 clo = 0;
     while (clo < 32 && s_tot[clo] > IVX_MAXREG) clo++;
+    // regions wider than 2^IVX_REG_CS_MAX cells cannot be staged in LDS: take more, narrower regions instead
+    // (the probe rows are then routed by a two-digit sort), as long as their number stays within IVX_MAXREG2
+    if (clo > IVX_REG_CS_MAX && clo <= 32 && s_tot[IVX_REG_CS_MAX] <= IVX_MAXREG2) clo = IVX_REG_CS_MAX;
     const u32 cs = clo;                                             // 32 = not even one region per key fits
     u64 rrun = 0;
     for (u32 k0 = 0; k0 < nkeys; k0 += 1024) {
@@ -275,8 +278,10 @@ ivx_status ivx_join_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32
     IVX_TRY(ivx_index_alloc(ctx, ix, (maxcells + 1) * sizeof(u32), (void **)&binstart));
     IVX_TRY(ivx_index_alloc(ctx, ix, HDR_WORDS * sizeof(u32), (void **)&hdr));
     IVX_TRY(ivx_index_alloc(ctx, ix, ((size_t)nkeys + 1) * sizeof(u32), (void **)&kreg));
-    IVX_TRY(ivx_index_alloc(ctx, ix, (IVX_MAXREG + 1) * sizeof(u32), (void **)&rkey));
-    IVX_TRY(ivx_index_alloc(ctx, ix, (IVX_MAXREG + 1) * sizeof(ivx_regdesc), (void **)&rdesc));
+    // region tables: 256 entries cover the one-digit scheme; big build sides may need up to IVX_MAXREG2
+    const size_t regcap = (maxcells >> IVX_REG_CS_MAX) + nkeys + 2 > IVX_MAXREG + 1 ? (size_t)IVX_MAXREG2 + 1 : (size_t)IVX_MAXREG + 1;
+    IVX_TRY(ivx_index_alloc(ctx, ix, regcap * sizeof(u32), (void **)&rkey));
+    IVX_TRY(ivx_index_alloc(ctx, ix, regcap * sizeof(ivx_regdesc), (void **)&rdesc));
     IVX_TRY(ivx_index_alloc(ctx, ix, (n ? n : 1) * sizeof(ivx_ent), (void **)&ent));
 
     i32 *kmin, *kmax; u32 *cellid, *rank, *errflag;
@@ -295,7 +300,7 @@ ivx_status ivx_join_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32
     hipLaunchKernelGGL(k_join_count, dim3(grid), dim3(BT), 0, st, key, s, e, n, nkeys, origin, lbase, hdr, binstart, cellid, rank);
     IVX_TRY(ivx_scan_exclusive_u32(ctx, binstart, maxcells + 1));
     hipLaunchKernelGGL(k_join_scatter, dim3(grid), dim3(BT), 0, st, s, e, n, (const u32 *)binstart, (const u32 *)cellid, (const u32 *)rank, ent);
-    hipLaunchKernelGGL(k_join_regdesc, dim3(1), dim3(256), 0, st, origin, span, lbase, hdr, kreg, rkey, binstart, rdesc);
+    hipLaunchKernelGGL(k_join_regdesc, dim3((u32)((regcap + 255) / 256)), dim3(256), 0, st, origin, span, lbase, hdr, kreg, rkey, binstart, rdesc);
     IVX_HIP(ctx, hipGetLastError());
 
     // key ids are validated on the device; surface the flag (one small D2H)

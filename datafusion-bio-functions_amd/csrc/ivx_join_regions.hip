@@ -21,6 +21,7 @@
 // HBM traffic per probe row: 8 B (hist) + 12 B + 12 B (scatter) + 12 B (probe) +
 // 8 B per pair, all streaming (measured: profiles/r1_d_regions_pipeline_pmc.txt).
 #include "ivx_join.hpp"
+#include "ivx_sort.hpp"
 #include <cstdlib>
 #include <cstdlib>
 
@@ -544,7 +545,7 @@ template <int MODE, int B>
 __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const u64 *__restrict__ pse, const u32 *__restrict__ prow,
                                                         const u32 *__restrict__ offs, u32 nblk, u32 vpb,
                                                         u32 *__restrict__ ob, u32 *__restrict__ op, u64 cap,
-                                                        unsigned long long *cursor, int dbg)
+                                                        unsigned long long *cursor, u32 prow_stride, int dbg)
 {
     constexpr bool FILL = MODE == 1;
     dbg = IVX_DBG_ARG(dbg);
@@ -554,9 +555,11 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
     const u32 nreg = ix.hdr[HDR_NREG];
     // first partitioned row of every region, once, in LDS (the share boundaries below search it)
     __shared__ u32 s_rfirst[IVX_MAXREG + 2];
-    for (u32 t = threadIdx.x; t <= nreg; t += RP_T) s_rfirst[t] = offs[(u64)t * nblk];
+    const bool rf_lds = nreg <= IVX_MAXREG;                           // (the two-digit scheme has up to 65025 regions: global table)
+    if (rf_lds) for (u32 t = threadIdx.x; t <= nreg; t += RP_T) s_rfirst[t] = offs[(u64)t * nblk];
     __syncthreads();
-    const u64 total_rows = s_rfirst[nreg];
+    auto rfirst = [&](u32 r) -> u32 { return rf_lds ? s_rfirst[r] : offs[(u64)r * nblk]; };
+    const u64 total_rows = rfirst(nreg);
     const u32 nvb = gridDim.x * vpb;
     u32 loaded_r = 0xFFFFFFFFu;                                       // region whose slice currently sits in LDS
     Slice S;
@@ -571,11 +574,11 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
             u32 r;
             {   // last region whose first row is <= lo
                 u32 a = 0, b = nreg;
-                while (a < b) { const u32 m = (a + b + 1) >> 1; if (s_rfirst[m] <= lo) a = m; else b = m - 1; }
+                while (a < b) { const u32 m = (a + b + 1) >> 1; if (rfirst(m) <= lo) a = m; else b = m - 1; }
                 r = a;
             }
             for (; lo < hi; r++) {
-                const u64 rend = s_rfirst[r + 1];
+                const u64 rend = rfirst(r + 1);
                 const u64 c_hi = hi < rend ? hi : rend;
                 if (c_hi <= lo) continue;
                 // every wavefront streams one batch of WB rows per round; the next round's rows are in
@@ -586,7 +589,7 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
                 for (int q = 0; q < B; q++) {
                     const u64 i = b0 + (u64)q * IVX_WAVE + ln;
                     nx[q] = i < c_hi ? pse[i] : 0;
-                    nxr[q] = (FILL && i < c_hi) ? prow[i] : 0u;
+                    nxr[q] = (FILL && i < c_hi) ? prow[i * prow_stride] : 0u;
                 }
                 slice_load(ix, S, L, r, r != loaded_r);
                 loaded_r = r;
@@ -604,7 +607,7 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
                         for (int q = 0; q < B; q++) {
                             const u64 i = b1 + (u64)q * IVX_WAVE + ln;
                             nx[q] = i < c_hi ? pse[i] : 0;
-                            nxr[q] = (FILL && i < c_hi) ? prow[i] : 0u;
+                            nxr[q] = (FILL && i < c_hi) ? prow[i * prow_stride] : 0u;
                         }
                     }
                     if (MODE >= RV_COUNT) {
@@ -713,20 +716,89 @@ ivx_status ivx_rowval_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, int c
     if (vec) hipLaunchKernelGGL((k_part_scatter<true, unsigned short>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, cidx, chunk, adj, 0);
     else hipLaunchKernelGGL((k_part_scatter<false, unsigned short>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, cidx, chunk, adj, 0);
     if (coverage)
-        hipLaunchKernelGGL((k_probe_regions<RV_COVERAGE, RP_B>), dim3(RP_VGRID), dim3(RP_T), 0, st, jv, (const u64 *)pse, (const u32 *)nullptr, (const u32 *)hist, nblk, 1u, val, (u32 *)nullptr, (u64)0, (unsigned long long *)nullptr, 0);
+        hipLaunchKernelGGL((k_probe_regions<RV_COVERAGE, RP_B>), dim3(RP_VGRID), dim3(RP_T), 0, st, jv, (const u64 *)pse, (const u32 *)nullptr, (const u32 *)hist, nblk, 1u, val, (u32 *)nullptr, (u64)0, (unsigned long long *)nullptr, 1u, 0);
     else
-        hipLaunchKernelGGL((k_probe_regions<RV_COUNT, RP_B>), dim3(RP_VGRID), dim3(RP_T), 0, st, jv, (const u64 *)pse, (const u32 *)nullptr, (const u32 *)hist, nblk, 1u, val, (u32 *)nullptr, (u64)0, (unsigned long long *)nullptr, 0);
+        hipLaunchKernelGGL((k_probe_regions<RV_COUNT, RP_B>), dim3(RP_VGRID), dim3(RP_T), 0, st, jv, (const u64 *)pse, (const u32 *)nullptr, (const u32 *)hist, nblk, 1u, val, (u32 *)nullptr, (u64)0, (unsigned long long *)nullptr, 1u, 0);
     if (coverage) hipLaunchKernelGGL(k_unpermute<true>, dim3(nblk), dim3(PA_T), 0, st, (const u32 *)val, (const unsigned short *)cidx, (const u32 *)hist, nblk, chunk, (u32)PA_ND, n, out);
     else hipLaunchKernelGGL(k_unpermute<false>, dim3(nblk), dim3(PA_T), 0, st, (const u32 *)val, (const unsigned short *)cidx, (const u32 *)hist, nblk, chunk, (u32)PA_ND, n, out);
     IVX_HIP(ctx, hipGetLastError());
     return IVX_OK;
 }
 
-ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, int mode,
+// ------------------------------------------------------------------ more than 255 regions
+// Build sides beyond ~1.5 M rows need more than 255 LDS-sized regions.  The probe rows are then routed by
+// region id with the stable radix sort (two 8-bit digits; records = (qs,qe) + (region << 32 | row)), the
+// region starts come from binary searches in the sorted ids, and the same probe kernel runs on top.
+namespace {
+
+constexpr int WR_T = 256;
+
+__global__ __launch_bounds__(WR_T) void k_region_ids(JoinIndexView ix, const u32 *__restrict__ pkey, const i32 *__restrict__ ps,
+                                                     const i32 *__restrict__ pe, u64 n, u32 nreg, u64 *__restrict__ w_se, u64 *__restrict__ w_rr)
+{
+    __shared__ i32 s_origin[KT_MAX];
+    __shared__ u32 s_last[KT_MAX], s_kreg[KT_MAX];
+    KeyTab kt;
+    keytab_load(ix, s_origin, s_last, s_kreg, kt);
+    __syncthreads();
+    for (u64 i = (u64)blockIdx.x * WR_T + threadIdx.x; i < n; i += (u64)gridDim.x * WR_T) {
+        const i32 qs = ps[i], qe = pe[i];
+        u32 r = region_of(ix, kt, pkey ? pkey[i] : 0u, qs);
+        if (r == NO_REGION) r = nreg;                                   // sorts behind every real region, never probed
+        w_se[i] = (u64)(u32)qs | ((u64)(u32)qe << 32);
+        w_rr[i] = ((u64)r << 32) | (u32)i;
+    }
+}
+
+// rfirst[r] = first sorted position whose region id is >= r, for r = 0 .. nreg
+__global__ __launch_bounds__(WR_T) void k_region_bounds(const u64 *__restrict__ w_rr, u64 n, u32 nreg, u32 *__restrict__ rfirst)
+{
+    const u32 r = blockIdx.x * WR_T + threadIdx.x;
+    if (r > nreg) return;
+    u64 lo = 0, hi = n;
+    while (lo < hi) { const u64 mid = lo + ((hi - lo) >> 1); if ((u32)(w_rr[mid] >> 32) < r) lo = mid + 1; else hi = mid; }
+    rfirst[r] = (u32)lo;
+}
+
+ivx_status probe_wide(ivx_ctx *ctx, const JoinIndexView &jv, int mode, u32 nreg, const u32 *key, const i32 *s, const i32 *e, u64 n,
+                      u32 *ob, u32 *op, u64 cap, u64 *d_cursor)
+{
+    hipStream_t st = ctx->stream;
+    u64 *a[2], *b[2]; u32 *rfirst;
+    IVX_TRY(ctx->get_scratch(WS_T0, n * sizeof(u64), (void **)&a[0]));
+    IVX_TRY(ctx->get_scratch(WS_T1, n * sizeof(u64), (void **)&a[1]));
+    IVX_TRY(ctx->get_scratch(WS_SA0, n * sizeof(u64), (void **)&b[0]));
+    IVX_TRY(ctx->get_scratch(WS_SA1, n * sizeof(u64), (void **)&b[1]));
+    IVX_TRY(ctx->get_scratch(WS_T2, ((size_t)nreg + 1) * sizeof(u32), (void **)&rfirst));
+    hipLaunchKernelGGL(k_region_ids, dim3(ivx_stream_grid(n, WR_T * 8, 4096)), dim3(WR_T), 0, st, jv, key, s, e, n, nreg, a[0], a[1]);
+    const ivx_sort_field f[1] = {{1, 32, 48}};
+    int in_b = 0;
+    IVX_TRY(ivx_radix_sort(ctx, 2, a, b, n, f, 1, &in_b));
+    u64 *const *o = in_b ? b : a;
+    hipLaunchKernelGGL(k_region_bounds, dim3((nreg + 1 + WR_T - 1) / WR_T), dim3(WR_T), 0, st, (const u64 *)o[1], n, nreg, rfirst);
+    unsigned long long *cur = (unsigned long long *)d_cursor;
+    const u32 *prow = (const u32 *)o[1];                                // low word of (region << 32 | row): stride 2
+    if (mode == JP_FILL) {
+        const double per_row = (double)cap / (double)n;
+        const int bsel = per_row <= 0.45 ? 8 : per_row <= 0.9 ? 4 : per_row <= 1.8 ? 2 : 1;
+#define IVX_FILLW(B_) hipLaunchKernelGGL((k_probe_regions<1, B_>), dim3(RP_GRID), dim3(RP_T), 0, st, jv, (const u64 *)o[0], prow, (const u32 *)rfirst, 1u, RP_VGRID / RP_GRID, ob, op, cap, cur, 2u, 0)
+        switch (bsel) { case 1: IVX_FILLW(1); break; case 2: IVX_FILLW(2); break; case 4: IVX_FILLW(4); break; default: IVX_FILLW(8); }
+#undef IVX_FILLW
+    } else {
+        hipLaunchKernelGGL((k_probe_regions<0, RP_B>), dim3(RP_VGRID), dim3(RP_T), 0, st, jv, (const u64 *)o[0], prow, (const u32 *)rfirst, 1u, 1u, ob, op, cap, cur, 2u, 0);
+    }
+    IVX_HIP(ctx, hipGetLastError());
+    return IVX_OK;
+}
+
+}  // namespace
+
+ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nreg, int mode,
                                   const u32 *key, const i32 *s, const i32 *e, u64 n,
                                   u32 *ob, u32 *op, u64 cap, u64 *d_cursor)
 {
     if (n == 0) return IVX_OK;
+    if (nreg > IVX_MAXREG) return probe_wide(ctx, jv, mode, nreg, key, s, e, n, ob, op, cap, d_cursor);
     hipStream_t st = ctx->stream;
     const u32 chunk = part_chunk(n);
     const u32 nblk = (u32)((n + chunk - 1) / chunk);
@@ -754,11 +826,11 @@ ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, int mod
         // batch takes the slow direct path
         const double per_row = (double)cap / (double)n;
         const int b = getenv("IVX_RP_ROWS") ? atoi(getenv("IVX_RP_ROWS")) : per_row <= 0.45 ? 8 : per_row <= 0.9 ? 4 : per_row <= 1.8 ? 2 : 1;
-#define IVX_FILL(B_) hipLaunchKernelGGL((k_probe_regions<1, B_>), dim3(RP_GRID), dim3(RP_T), 0, st, jv, (const u64 *)pse, (const u32 *)prow, (const u32 *)hist, nblk, RP_VGRID / RP_GRID, ob, op, cap, cur, dbg)
+#define IVX_FILL(B_) hipLaunchKernelGGL((k_probe_regions<1, B_>), dim3(RP_GRID), dim3(RP_T), 0, st, jv, (const u64 *)pse, (const u32 *)prow, (const u32 *)hist, nblk, RP_VGRID / RP_GRID, ob, op, cap, cur, 1u, dbg)
         switch (b) { case 1: IVX_FILL(1); break; case 2: IVX_FILL(2); break; case 4: IVX_FILL(4); break; default: IVX_FILL(8); }
 #undef IVX_FILL
     } else
-        hipLaunchKernelGGL((k_probe_regions<0, RP_B>), dim3(RP_VGRID), dim3(RP_T), 0, st, jv, (const u64 *)pse, (const u32 *)prow, (const u32 *)hist, nblk, 1u, ob, op, cap, cur, dbg);
+        hipLaunchKernelGGL((k_probe_regions<0, RP_B>), dim3(RP_VGRID), dim3(RP_T), 0, st, jv, (const u64 *)pse, (const u32 *)prow, (const u32 *)hist, nblk, 1u, ob, op, cap, cur, 1u, dbg);
     IVX_HIP(ctx, hipGetLastError());
     return IVX_OK;
 }

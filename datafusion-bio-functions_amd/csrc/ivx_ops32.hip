@@ -62,7 +62,7 @@ __global__ __launch_bounds__(OT) void k_any_inverted(const i32 *__restrict__ s, 
 // large unsorted batches go through the region partition (ivx_join_regions.hip) unless told otherwise
 bool rowval_regions_wanted(const ivx_index *ix, u64 n)
 {
-    if (!(ix->flags & IVX_IXF_REGION_ROWVAL) || ix->jv_nreg == 0) return false;
+    if (!(ix->flags & IVX_IXF_REGION_ROWVAL) || ix->jv_nreg == 0 || ix->jv_nreg > IVX_MAXREG) return false;   // one-digit regions only
     const char *f = getenv("IVX_ROWVAL_PATH");                          // tests: "direct" | "regions"
     if (f && !strcmp(f, "direct")) return false;
     if (f && !strcmp(f, "regions")) return true;

@@ -137,6 +137,16 @@ def test_join_regions_staging_ring_overflow(ctx):
     _check_join(ctx, z(nb, np.uint32), bs, be, z(len(ps), np.uint32), ps, pe, 1)
 
 
+def test_join_more_than_255_regions(ctx):
+    # a build side too big for 255 LDS-sized regions: ~600 narrower regions, probe rows routed by the
+    # two-digit stable sort; three keys, rows of unknown keys, long rows, a few chromosome-long build rows
+    bk, bs, be = synth(2_400_000, 61, nkeys=3, mean_len=300, span=240_000_000)
+    pk, ps, pe = synth(700_000, 62, nkeys=4, mean_len=150, span=240_000_000)
+    pe[::89] = ps[::89] + 50_000
+    bs[:20] = 0; be[:20] = 200_000_000
+    _check_join(ctx, bk, bs, be, pk, ps, pe, 4)
+
+
 def test_capacity_error(ctx):
     bk, bs, be = synth(5000, 3, span=100_000)
     ix = ctx.build(pyivx.KIND_OVERLAP, bk, bs, be, n_keys=1)
