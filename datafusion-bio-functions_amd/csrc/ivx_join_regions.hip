@@ -645,6 +645,14 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
     if (FILL && round && !(dbg & 32)) round_copy_out(L, pend_mine, pend_start, round - 1, wv, ob, op, cap, dbg);
 }
 
+// fill pass: rows per lane and batch from the expected matches per row (cap / n)
+static inline int fill_rows_per_lane(u64 cap, u64 n)
+{
+    if (const char *f = getenv("IVX_RP_ROWS")) return atoi(f);             // experiments
+    const double per_row = (double)cap / (double)n;
+    return per_row <= 0.45 ? 8 : per_row <= 0.9 ? 4 : per_row <= 1.8 ? 2 : 1;
+}
+
 // rows one partition workgroup takes: 1, 2 or 4 tiles, so that mid-size batches still spread over all CUs
 static inline u32 part_chunk(u64 n) { return (u32)PA_TILE * (n >= (16u << 20) ? 4u : n >= (4u << 20) ? 2u : 1u); }
 
@@ -779,8 +787,7 @@ ivx_status probe_wide(ivx_ctx *ctx, const JoinIndexView &jv, int mode, u32 nreg,
     unsigned long long *cur = (unsigned long long *)d_cursor;
     const u32 *prow = (const u32 *)o[1];                                // low word of (region << 32 | row): stride 2
     if (mode == JP_FILL) {
-        const double per_row = (double)cap / (double)n;
-        const int bsel = per_row <= 0.45 ? 8 : per_row <= 0.9 ? 4 : per_row <= 1.8 ? 2 : 1;
+        const int bsel = fill_rows_per_lane(cap, n);
 #define IVX_FILLW(B_) hipLaunchKernelGGL((k_probe_regions<1, B_>), dim3(RP_GRID), dim3(RP_T), 0, st, jv, (const u64 *)o[0], prow, (const u32 *)rfirst, 1u, RP_VGRID / RP_GRID, ob, op, cap, cur, 2u, 0)
         switch (bsel) { case 1: IVX_FILLW(1); break; case 2: IVX_FILLW(2); break; case 4: IVX_FILLW(4); break; default: IVX_FILLW(8); }
 #undef IVX_FILLW
@@ -824,8 +831,7 @@ ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nre
         // rows per lane and batch by the expected matches per row (cap / n: callers size the output from the
         // count pass): two consecutive rounds of a wavefront must fit its 512-pair staging ring, else the
         // batch takes the slow direct path
-        const double per_row = (double)cap / (double)n;
-        const int b = getenv("IVX_RP_ROWS") ? atoi(getenv("IVX_RP_ROWS")) : per_row <= 0.45 ? 8 : per_row <= 0.9 ? 4 : per_row <= 1.8 ? 2 : 1;
+        const int b = fill_rows_per_lane(cap, n);
 #define IVX_FILL(B_) hipLaunchKernelGGL((k_probe_regions<1, B_>), dim3(RP_GRID), dim3(RP_T), 0, st, jv, (const u64 *)pse, (const u32 *)prow, (const u32 *)hist, nblk, RP_VGRID / RP_GRID, ob, op, cap, cur, 1u, dbg)
         switch (b) { case 1: IVX_FILL(1); break; case 2: IVX_FILL(2); break; case 4: IVX_FILL(4); break; default: IVX_FILL(8); }
 #undef IVX_FILL
