@@ -124,16 +124,22 @@ __device__ __forceinline__ void load4(const u32 *__restrict__ pkey, const i32 *_
 
 // adj = 1 for the UDTFs' strict mode: the query is shrunk to [start+1, end-1] before anything else
 // (interval_tree.rs:185-188, :253-256; i32 wrapping like the reference's release build)
+// `unsorted` (device flag, preset 0) is raised when the rows are NOT already grouped by ascending region --
+// a row of a smaller region after a larger one, or a row that cannot be routed.  If it stays 0 (probe input
+// sorted by contig id and start: the usual state of genomic files) the partitioned order IS the input order
+// and the scatter pass is skipped altogether.
 template <bool VEC>
 __global__ __launch_bounds__(PA_T) void k_part_hist(JoinIndexView ix, const u32 *__restrict__ pkey, const i32 *__restrict__ ps,
-                                                    u64 n, u32 nblk, u32 chunk, u32 *__restrict__ hist, u32 adj)
+                                                    u64 n, u32 nblk, u32 chunk, u32 *__restrict__ hist, u32 adj, u32 *unsorted)
 {
     __shared__ u32 cnt[256];
     __shared__ i32 s_origin[KT_MAX];
     __shared__ u32 s_last[KT_MAX], s_kreg[KT_MAX];
+    __shared__ u32 s_unsorted;
     KeyTab kt;
     keytab_load(ix, s_origin, s_last, s_kreg, kt);
     if (threadIdx.x < PA_ND) cnt[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_unsorted = 0;
     __syncthreads();
     const u64 lo = (u64)blockIdx.x * chunk;
     const u64 hi = lo + chunk < n ? lo + chunk : n;
@@ -142,14 +148,29 @@ __global__ __launch_bounds__(PA_T) void k_part_hist(JoinIndexView ix, const u32 
         const u64 i = i0 + (u64)threadIdx.x * 4;
         if (i >= hi) continue;
         load4<VEC>(pkey, ps, nullptr, i, hi, k, q, unused);
+        u32 d[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            const u32 d = region_of(ix, kt, k[u], (i32)((u32)q[u] + adj));
-            lds_count_up(cnt, d, d != NO_REGION);
+            d[u] = region_of(ix, kt, k[u], (i32)((u32)q[u] + adj));
+            lds_count_up(cnt, d[u], d[u] != NO_REGION);
+        }
+        if (!s_unsorted) {                                  // (once raised nobody needs to look any further)
+            bool bad = false;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (i + u >= hi) break;
+                bad |= d[u] == NO_REGION || (u && d[u] < d[u - 1]);
+            }
+            if (i + 3 < hi && i + 4 < n) {                  // the row after this thread's four: next thread, wavefront, loop step or workgroup
+                const u32 dn = region_of(ix, kt, pkey ? pkey[i + 4] : 0u, (i32)((u32)ps[i + 4] + adj));
+                bad |= dn < d[3];
+            }
+            if (bad) s_unsorted = 1;
         }
     }
     __syncthreads();
     if (threadIdx.x < PA_ND) hist[(u64)threadIdx.x * nblk + blockIdx.x] = cnt[threadIdx.x];
+    if (threadIdx.x == 0 && s_unsorted) *unsorted = 1;
 }
 
 // order inside a region is irrelevant (the reference pins only the pair multiset), so the local
@@ -160,7 +181,7 @@ __global__ __launch_bounds__(PA_T) void k_part_hist(JoinIndexView ix, const u32 
 template <bool VEC, typename RowT>
 __global__ __launch_bounds__(PA_T) void k_part_scatter(JoinIndexView ix, const u32 *__restrict__ pkey, const i32 *__restrict__ ps,
                                                        const i32 *__restrict__ pe, u64 n, u32 nblk, const u32 *__restrict__ offs,
-                                                       u64 *__restrict__ out_se, RowT *__restrict__ out_row, u32 chunk, u32 adj, int dbg)
+                                                       u64 *__restrict__ out_se, RowT *__restrict__ out_row, u32 chunk, u32 adj, const u32 *unsorted, int dbg)
 {
     __shared__ u64 r_se[PA_TILE];
     __shared__ RowT r_row[PA_TILE];
@@ -172,6 +193,7 @@ __global__ __launch_bounds__(PA_T) void k_part_scatter(JoinIndexView ix, const u
 
     const u32 tid = threadIdx.x;
     dbg = IVX_DBG_ARG(dbg);
+    if (*unsorted == 0) return;                             // input already in region order: nothing to move
     KeyTab kt;
     keytab_load(ix, s_origin, s_last, s_kreg, kt);
     if (tid < PA_ND) gbase[tid] = offs[(u64)tid * nblk + blockIdx.x];
@@ -541,13 +563,24 @@ __device__ __forceinline__ void round_copy_out(const ProbeLds &L, u32 mine, u32 
 //   MODE 1 (fill): single walk, see batch_walk / round_publish / round_copy_out.
 //   MODE RV_COUNT / RV_COVERAGE: one 32-bit value per row, written at the row's partitioned position
 //           (`ob`), no synchronisation at all; k_unpermute puts the values back in input order.
-template <int MODE, int B>
-__global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const u64 *__restrict__ pse, const u32 *__restrict__ prow,
+template <int MODE, int B, bool IDENT>
+__global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const void *__restrict__ rows_a, const void *__restrict__ rows_b,
                                                         const u32 *__restrict__ offs, u32 nblk, u32 vpb,
                                                         u32 *__restrict__ ob, u32 *__restrict__ op, u64 cap,
-                                                        unsigned long long *cursor, u32 prow_stride, int dbg)
+                                                        unsigned long long *cursor, u32 prow_stride, u32 adj,
+                                                        const u32 *unsorted, int dbg)
 {
     constexpr bool FILL = MODE == 1;
+    // IDENT: the input already is in region order (k_part_hist left `unsorted` at 0): the partitioned arrays
+    // were never written and row i IS input row i.  Both instantiations are launched; the one whose case
+    // does not apply returns at once (the host never waits for the flag).
+    if ((unsorted != nullptr && *unsorted == 0) != IDENT) return;
+    // rows_a / rows_b: the partitioned (qs,qe) and row-id arrays, or -- IDENT -- the input start and end columns
+    auto row_se = [&](u64 i) -> u64 {
+        if (IDENT) return (u64)(u32)((u32)((const i32 *)rows_a)[i] + adj) | ((u64)(u32)((u32)((const i32 *)rows_b)[i] - adj) << 32);
+        return ((const u64 *)rows_a)[i];
+    };
+    auto row_id = [&](u64 i) -> u32 { return IDENT ? (u32)i : ((const u32 *)rows_b)[i * prow_stride]; };
     dbg = IVX_DBG_ARG(dbg);
     constexpr u32 WB = IVX_WAVE * B;                                  // rows per wavefront batch
     IVX_PROBE_LDS(FILL)
@@ -584,12 +617,14 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
                 // every wavefront streams one batch of WB rows per round; the next round's rows are in
                 // flight while the current batch walks the LDS slice (the first batch while the slice loads)
                 u64 nx[B]; u32 nxr[B];
-                u64 b0 = lo + (u64)wv * WB;
+                // a round is RP_W * WB consecutive rows; wavefront w takes the 64-row granules w, w+16, ... of it, so
+                // that dense and empty stretches of sorted input are shared evenly by the 16 wavefronts
+                u64 b0 = lo + (u64)wv * IVX_WAVE;
 #pragma unroll
                 for (int q = 0; q < B; q++) {
-                    const u64 i = b0 + (u64)q * IVX_WAVE + ln;
-                    nx[q] = i < c_hi ? pse[i] : 0;
-                    nxr[q] = (FILL && i < c_hi) ? prow[i * prow_stride] : 0u;
+                    const u64 i = b0 + (u64)q * (RP_W * IVX_WAVE) + ln;
+                    nx[q] = i < c_hi ? row_se(i) : 0;
+                    nxr[q] = (FILL && i < c_hi) ? row_id(i) : 0u;
                 }
                 slice_load(ix, S, L, r, r != loaded_r);
                 loaded_r = r;
@@ -599,15 +634,15 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
 #pragma unroll
                     for (int q = 0; q < B; q++) {
                         qs[q] = (i32)(u32)nx[q]; qe[q] = (i32)(u32)(nx[q] >> 32); rowv[q] = nxr[q];
-                        if (b0 + (u64)q * IVX_WAVE + ln < c_hi) okmask |= 1u << q;
+                        if (b0 + (u64)q * (RP_W * IVX_WAVE) + ln < c_hi) okmask |= 1u << q;
                     }
                     {
                         const u64 b1 = b0 + (u64)RP_W * WB;
 #pragma unroll
                         for (int q = 0; q < B; q++) {
-                            const u64 i = b1 + (u64)q * IVX_WAVE + ln;
-                            nx[q] = i < c_hi ? pse[i] : 0;
-                            nxr[q] = (FILL && i < c_hi) ? prow[i * prow_stride] : 0u;
+                            const u64 i = b1 + (u64)q * (RP_W * IVX_WAVE) + ln;
+                            nx[q] = i < c_hi ? row_se(i) : 0;
+                            nxr[q] = (FILL && i < c_hi) ? row_id(i) : 0u;
                         }
                     }
                     if (MODE >= RV_COUNT) {
@@ -615,7 +650,7 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
                         batch_rowval<MODE, B>(S, qs, qe, okmask, val);
 #pragma unroll
                         for (int q = 0; q < B; q++)
-                            if ((okmask >> q) & 1u) ob[b0 + (u64)q * IVX_WAVE + ln] = val[q];
+                            if ((okmask >> q) & 1u) ob[b0 + (u64)q * (RP_W * IVX_WAVE) + ln] = val[q];
                         continue;
                     }
                     u32 start = 0;
@@ -666,8 +701,15 @@ constexpr u32 UP_CHUNK = (u32)PA_CHUNK;
 
 template <bool SIGNED>
 __global__ __launch_bounds__(PA_T) void k_unpermute(const u32 *__restrict__ val, const unsigned short *__restrict__ cidx,
-                                                    const u32 *__restrict__ offs, u32 nblk, u32 chunk, u32 nreg, u64 n, i64 *__restrict__ out)
+                                                    const u32 *__restrict__ offs, u32 nblk, u32 chunk, u32 nreg, u64 n, i64 *__restrict__ out,
+                                                    const u32 *unsorted)
 {
+    if (*unsorted == 0) {                                   // values already sit in input order
+        const u64 lo0 = (u64)blockIdx.x * chunk;
+        const u64 hi0 = lo0 + chunk < n ? lo0 + chunk : n;
+        for (u64 t = lo0 + threadIdx.x; t < hi0; t += PA_T) out[t] = SIGNED ? (i64)(i32)val[t] : (i64)val[t];
+        return;
+    }
     __shared__ u32 s_val[UP_CHUNK];
     __shared__ u32 s_pre[PA_ND + 1], s_g[PA_ND];
     __shared__ u32 scan_lds[PA_T / IVX_WAVE + 1];
@@ -718,17 +760,19 @@ ivx_status ivx_rowval_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, int c
     IVX_HIP(ctx, hipMemsetAsync(hist + (nh - 1), 0, sizeof(u32), st));
     const u32 adj = strict ? 1u : 0u;
     const bool vec = (((uintptr_t)key | (uintptr_t)s | (uintptr_t)e) & 15) == 0;
-    if (vec) hipLaunchKernelGGL(k_part_hist<true>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, n, nblk, chunk, hist, adj);
-    else hipLaunchKernelGGL(k_part_hist<false>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, n, nblk, chunk, hist, adj);
+    u32 *unsorted = (u32 *)(ctx->d_scalars + 10);                       // stays 0 if the rows already come in region order
+    IVX_HIP(ctx, hipMemsetAsync(unsorted, 0, sizeof(u32), st));
+    if (vec) hipLaunchKernelGGL(k_part_hist<true>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, n, nblk, chunk, hist, adj, unsorted);
+    else hipLaunchKernelGGL(k_part_hist<false>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, n, nblk, chunk, hist, adj, unsorted);
     IVX_TRY(ivx_scan_exclusive_u32(ctx, hist, nh));
-    if (vec) hipLaunchKernelGGL((k_part_scatter<true, unsigned short>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, cidx, chunk, adj, 0);
-    else hipLaunchKernelGGL((k_part_scatter<false, unsigned short>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, cidx, chunk, adj, 0);
-    if (coverage)
-        hipLaunchKernelGGL((k_probe_regions<RV_COVERAGE, RP_B>), dim3(RP_VGRID), dim3(RP_T), 0, st, jv, (const u64 *)pse, (const u32 *)nullptr, (const u32 *)hist, nblk, 1u, val, (u32 *)nullptr, (u64)0, (unsigned long long *)nullptr, 1u, 0);
-    else
-        hipLaunchKernelGGL((k_probe_regions<RV_COUNT, RP_B>), dim3(RP_VGRID), dim3(RP_T), 0, st, jv, (const u64 *)pse, (const u32 *)nullptr, (const u32 *)hist, nblk, 1u, val, (u32 *)nullptr, (u64)0, (unsigned long long *)nullptr, 1u, 0);
-    if (coverage) hipLaunchKernelGGL(k_unpermute<true>, dim3(nblk), dim3(PA_T), 0, st, (const u32 *)val, (const unsigned short *)cidx, (const u32 *)hist, nblk, chunk, (u32)PA_ND, n, out);
-    else hipLaunchKernelGGL(k_unpermute<false>, dim3(nblk), dim3(PA_T), 0, st, (const u32 *)val, (const unsigned short *)cidx, (const u32 *)hist, nblk, chunk, (u32)PA_ND, n, out);
+    if (vec) hipLaunchKernelGGL((k_part_scatter<true, unsigned short>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, cidx, chunk, adj, (const u32 *)unsorted, 0);
+    else hipLaunchKernelGGL((k_part_scatter<false, unsigned short>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, cidx, chunk, adj, (const u32 *)unsorted, 0);
+#define IVX_RV(M_, ID_) hipLaunchKernelGGL((k_probe_regions<M_, RP_B, ID_>), dim3(RP_VGRID), dim3(RP_T), 0, st, jv, ID_ ? (const void *)s : (const void *)pse, ID_ ? (const void *)e : (const void *)nullptr, (const u32 *)hist, nblk, 1u, val, (u32 *)nullptr, (u64)0, (unsigned long long *)nullptr, 1u, adj, (const u32 *)unsorted, 0)
+    if (coverage) { IVX_RV(RV_COVERAGE, false); IVX_RV(RV_COVERAGE, true); }
+    else { IVX_RV(RV_COUNT, false); IVX_RV(RV_COUNT, true); }
+#undef IVX_RV
+    if (coverage) hipLaunchKernelGGL(k_unpermute<true>, dim3(nblk), dim3(PA_T), 0, st, (const u32 *)val, (const unsigned short *)cidx, (const u32 *)hist, nblk, chunk, (u32)PA_ND, n, out, (const u32 *)unsorted);
+    else hipLaunchKernelGGL(k_unpermute<false>, dim3(nblk), dim3(PA_T), 0, st, (const u32 *)val, (const unsigned short *)cidx, (const u32 *)hist, nblk, chunk, (u32)PA_ND, n, out, (const u32 *)unsorted);
     IVX_HIP(ctx, hipGetLastError());
     return IVX_OK;
 }
@@ -788,11 +832,11 @@ ivx_status probe_wide(ivx_ctx *ctx, const JoinIndexView &jv, int mode, u32 nreg,
     const u32 *prow = (const u32 *)o[1];                                // low word of (region << 32 | row): stride 2
     if (mode == JP_FILL) {
         const int bsel = fill_rows_per_lane(cap, n);
-#define IVX_FILLW(B_) hipLaunchKernelGGL((k_probe_regions<1, B_>), dim3(RP_GRID), dim3(RP_T), 0, st, jv, (const u64 *)o[0], prow, (const u32 *)rfirst, 1u, RP_VGRID / RP_GRID, ob, op, cap, cur, 2u, 0)
+#define IVX_FILLW(B_) hipLaunchKernelGGL((k_probe_regions<1, B_, false>), dim3(RP_GRID), dim3(RP_T), 0, st, jv, (const void *)o[0], (const void *)prow, (const u32 *)rfirst, 1u, RP_VGRID / RP_GRID, ob, op, cap, cur, 2u, 0u, (const u32 *)nullptr, 0)
         switch (bsel) { case 1: IVX_FILLW(1); break; case 2: IVX_FILLW(2); break; case 4: IVX_FILLW(4); break; default: IVX_FILLW(8); }
 #undef IVX_FILLW
     } else {
-        hipLaunchKernelGGL((k_probe_regions<0, RP_B>), dim3(RP_VGRID), dim3(RP_T), 0, st, jv, (const u64 *)o[0], prow, (const u32 *)rfirst, 1u, 1u, ob, op, cap, cur, 2u, 0);
+        hipLaunchKernelGGL((k_probe_regions<0, RP_B, false>), dim3(RP_VGRID), dim3(RP_T), 0, st, jv, (const void *)o[0], (const void *)prow, (const u32 *)rfirst, 1u, 1u, ob, op, cap, cur, 2u, 0u, (const u32 *)nullptr, 0);
     }
     IVX_HIP(ctx, hipGetLastError());
     return IVX_OK;
@@ -821,22 +865,28 @@ ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nre
     const int dbg = 0;
 #endif
     const bool vec = (((uintptr_t)key | (uintptr_t)s | (uintptr_t)e) & 15) == 0;
-    if (vec) hipLaunchKernelGGL(k_part_hist<true>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, n, nblk, chunk, hist, 0u);
-    else hipLaunchKernelGGL(k_part_hist<false>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, n, nblk, chunk, hist, 0u);
+    u32 *unsorted = (u32 *)(ctx->d_scalars + 10);                       // stays 0 if the rows already come in region order
+    IVX_HIP(ctx, hipMemsetAsync(unsorted, 0, sizeof(u32), st));
+    if (vec) hipLaunchKernelGGL(k_part_hist<true>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, n, nblk, chunk, hist, 0u, unsorted);
+    else hipLaunchKernelGGL(k_part_hist<false>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, n, nblk, chunk, hist, 0u, unsorted);
     IVX_TRY(ivx_scan_exclusive_u32(ctx, hist, nh));
-    if (vec) hipLaunchKernelGGL((k_part_scatter<true, u32>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, prow, chunk, 0u, dbg);
-    else hipLaunchKernelGGL((k_part_scatter<false, u32>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, prow, chunk, 0u, dbg);
+    if (vec) hipLaunchKernelGGL((k_part_scatter<true, u32>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, prow, chunk, 0u, (const u32 *)unsorted, dbg);
+    else hipLaunchKernelGGL((k_part_scatter<false, u32>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, prow, chunk, 0u, (const u32 *)unsorted, dbg);
     unsigned long long *cur = (unsigned long long *)d_cursor;
     if (mode == JP_FILL) {   // single walk: pairs staged per wavefront, one output reservation per workgroup and round
         // rows per lane and batch by the expected matches per row (cap / n: callers size the output from the
         // count pass): two consecutive rounds of a wavefront must fit its 512-pair staging ring, else the
         // batch takes the slow direct path
         const int b = fill_rows_per_lane(cap, n);
-#define IVX_FILL(B_) hipLaunchKernelGGL((k_probe_regions<1, B_>), dim3(RP_GRID), dim3(RP_T), 0, st, jv, (const u64 *)pse, (const u32 *)prow, (const u32 *)hist, nblk, RP_VGRID / RP_GRID, ob, op, cap, cur, 1u, dbg)
+#define IVX_FILL1(B_, ID_) hipLaunchKernelGGL((k_probe_regions<1, B_, ID_>), dim3(RP_GRID), dim3(RP_T), 0, st, jv, ID_ ? (const void *)s : (const void *)pse, ID_ ? (const void *)e : (const void *)prow, (const u32 *)hist, nblk, RP_VGRID / RP_GRID, ob, op, cap, cur, 1u, 0u, (const u32 *)unsorted, dbg)
+#define IVX_FILL(B_) do { IVX_FILL1(B_, false); IVX_FILL1(B_, true); } while (0)
         switch (b) { case 1: IVX_FILL(1); break; case 2: IVX_FILL(2); break; case 4: IVX_FILL(4); break; default: IVX_FILL(8); }
 #undef IVX_FILL
-    } else
-        hipLaunchKernelGGL((k_probe_regions<0, RP_B>), dim3(RP_VGRID), dim3(RP_T), 0, st, jv, (const u64 *)pse, (const u32 *)prow, (const u32 *)hist, nblk, 1u, ob, op, cap, cur, 1u, dbg);
+#undef IVX_FILL1
+    } else {
+        hipLaunchKernelGGL((k_probe_regions<0, RP_B, false>), dim3(RP_VGRID), dim3(RP_T), 0, st, jv, (const void *)pse, (const void *)prow, (const u32 *)hist, nblk, 1u, ob, op, cap, cur, 1u, 0u, (const u32 *)unsorted, dbg);
+        hipLaunchKernelGGL((k_probe_regions<0, RP_B, true>), dim3(RP_VGRID), dim3(RP_T), 0, st, jv, (const void *)s, (const void *)e, (const u32 *)hist, nblk, 1u, ob, op, cap, cur, 1u, 0u, (const u32 *)unsorted, dbg);
+    }
     IVX_HIP(ctx, hipGetLastError());
     return IVX_OK;
 }

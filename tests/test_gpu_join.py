@@ -218,3 +218,21 @@ def test_unaligned_device_views(ctx):
     got = (ob.cpu().numpy().view(np.uint32), op.cpu().numpy().view(np.uint32))
     assert (pair_set(*got) == pair_set(*want)).all()
     ctx.use_own_stream()
+
+
+def _sorted_by_key_start(k, s, e):
+    o = np.lexsort((s, k))
+    return k[o].copy(), s[o].copy(), e[o].copy()
+
+
+def test_join_sorted_probe_input_skips_the_scatter(ctx):
+    # probe rows already in (contig id, start) order: the partition detects it and the probe reads the
+    # input columns in place; same answers, and a single inversion or an unroutable row switches back
+    bk, bs, be = synth(200_000, 71, nkeys=5, mean_len=600, span=30_000_000)
+    pk, ps, pe = _sorted_by_key_start(*synth(1_000_003, 72, nkeys=5, mean_len=150, span=30_000_000))
+    _check_join(ctx, bk, bs, be, pk, ps, pe, 5)
+    pk2, ps2, pe2 = pk.copy(), ps.copy(), pe.copy()
+    ps2[500_000], pe2[500_000] = 0, 100                     # one row out of order
+    _check_join(ctx, bk, bs, be, pk2, ps2, pe2, 5)
+    pk3 = pk.copy(); pk3[-7:] = 9                            # trailing rows of a key the build side does not have
+    _check_join(ctx, bk, bs, be, pk3, ps, pe, 5)

@@ -507,3 +507,18 @@ def test_cluster_exons_issue_373(ctx, golden):
         for cid, cs, ce in zip(part["cluster"], part["cluster_start"], part["cluster_end"]):
             assert ids.setdefault(int(cid), (int(cs), int(ce))) == (int(cs), int(ce))   # :2761-2818: an id never names two extents
     assert len(ids) == full["n_clusters"]
+
+
+def test_count_coverage_sorted_probe_input(ctx):
+    # sorted probe rows take the in-place path of the region pipeline (no scatter, no un-permute); strict mode
+    # shrinks the query before routing, so the order check runs on start+1
+    bk, bs, be = synth(150_000, 81, nkeys=6, mean_len=500, span=20_000_000)
+    pk, ps, pe = synth(900_001, 82, nkeys=6, mean_len=150, span=20_000_000)
+    o = np.lexsort((ps, pk)); pk, ps, pe = pk[o].copy(), ps[o].copy(), pe[o].copy()
+    for kind, fn, ofn in ((pyivx.KIND_COUNT, ctx.count_overlaps, orc.count_overlaps), (pyivx.KIND_COVERAGE, ctx.coverage, orc.coverage)):
+        ix = ctx.build(kind, bk, bs, be, n_keys=6)
+        for strict in (False, True):
+            want = ofn(bk, bs, be, pk, ps, pe, strict=strict)
+            for path in _paths():
+                assert (fn(ix, pk, ps, pe, strict=strict) == want).all(), (kind, strict, path)
+        ix.free()
