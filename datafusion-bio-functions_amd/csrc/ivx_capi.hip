@@ -311,8 +311,16 @@ static ivx_status overlap_common(ivx_ctx *ctx, const ivx_index *ix, int mem, int
             if (!strcmp(f, "direct")) regions = false;
             else if (!strcmp(f, "regions")) regions = ix->jv_nreg > 0 && (mode == JP_COUNT || mode == JP_FILL);
         }
+        // the per-row modes (rle_right, semi / anti) of big batches: same partition, one value per row, un-permuted
+        bool rowval = ix->jv_nreg > 0 && ix->jv_nreg <= IVX_MAXREG && (mode == JP_PER_ROW || mode == JP_EXISTS) && n >= (1u << 21);
+        if (const char *f = getenv("IVX_JOIN_PATH")) {
+            if (!strcmp(f, "direct")) rowval = false;
+            else if (!strcmp(f, "regions")) rowval = ix->jv_nreg > 0 && ix->jv_nreg <= IVX_MAXREG && (mode == JP_PER_ROW || mode == JP_EXISTS);
+        }
         KernelTimer t(ctx);
         if (regions) IVX_TRY(ivx_join_probe_regions(ctx, ix->jv, ix->jv_nreg, mode, dk, ds, de, n, d_b, d_p, cap, ctx->d_scalars));
+        else if (rowval) IVX_TRY(ivx_rowval_probe_regions(ctx, ix->jv, mode == JP_PER_ROW ? IVX_RV_PER_ROW : IVX_RV_EXISTS, dk, ds, de, n, 0,
+                                                          mode == JP_PER_ROW ? (void *)d_row : (void *)d_ex, ctx->d_scalars));
         else IVX_TRY(ivx_join_probe(ctx, ix->jv, mode, dk, ds, de, n, d_row, d_ex, d_b, d_p, cap, ctx->d_scalars));
     }
     u64 tot = 0;

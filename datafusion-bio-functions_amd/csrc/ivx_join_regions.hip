@@ -463,7 +463,7 @@ __device__ __forceinline__ void batch_write_direct(const Slice &S, const ProbeLd
 //                build row has end < start, which is when the host takes this path
 //   RV_COVERAGE  get_coverage over the merged nodes: sum of max(1, min(qe+1, last) - max(qs-1, first)) in
 //                wrapping i32 arithmetic (:145-152)
-enum { RV_COUNT = 2, RV_COVERAGE = 3 };
+enum { RV_COUNT = 2, RV_COVERAGE = 3, RV_MATCHES = 4 };   // RV_MATCHES: the join's rle_right / exists (plain match count)
 
 __device__ __forceinline__ i32 rv_wadd(i32 a, i32 b) { return (i32)((u32)a + (u32)b); }
 __device__ __forceinline__ i32 rv_wsub(i32 a, i32 b) { return (i32)((u32)a - (u32)b); }
@@ -477,6 +477,8 @@ __device__ __forceinline__ void batch_rowval(const Slice &S, const i32 (&qs)[B],
         if ((okmask >> q) & 1u) {
             if (KIND == RV_COUNT) {
                 if (!(qe[q] < qs[q])) probe_row(S, qs[q], qe[q], [&](u32, bool, i32, i32) { v++; });
+            } else if (KIND == RV_MATCHES) {
+                probe_row(S, qs[q], qe[q], [&](u32, bool, i32, i32) { v++; });
             } else {
                 const i32 a = rv_wadd(qe[q], 1), b = rv_wsub(qs[q], 1);
                 probe_row(S, qs[q], qe[q], [&](u32, bool, i32 first, i32 last) {
@@ -699,15 +701,30 @@ static inline u32 part_chunk(u64 n) { return (u32)PA_TILE * (n >= (16u << 20) ? 
 // key without build rows) keep the zero LDS was cleared to -- the reference's answer for them.
 constexpr u32 UP_CHUNK = (u32)PA_CHUNK;
 
-template <bool SIGNED>
-__global__ __launch_bounds__(PA_T) void k_unpermute(const u32 *__restrict__ val, const unsigned short *__restrict__ cidx,
-                                                    const u32 *__restrict__ offs, u32 nblk, u32 chunk, u32 nreg, u64 n, i64 *__restrict__ out,
-                                                    const u32 *unsorted)
+// OUT: UP_I64 zero-extended (count), UP_I64S sign-extended (coverage), UP_U32 (rle_right; the workgroup's sum
+// goes to *total), UP_U8 (exists = value != 0)
+enum { UP_I64 = 0, UP_I64S = 1, UP_U32 = 2, UP_U8 = 3 };
+template <int OUT>
+__device__ __forceinline__ void up_store(void *out, u64 i, u32 v)
 {
+    if (OUT == UP_I64) ((i64 *)out)[i] = (i64)v;
+    else if (OUT == UP_I64S) ((i64 *)out)[i] = (i64)(i32)v;
+    else if (OUT == UP_U32) ((u32 *)out)[i] = v;
+    else ((u8 *)out)[i] = v != 0;
+}
+
+template <int OUT>
+__global__ __launch_bounds__(PA_T) void k_unpermute(const u32 *__restrict__ val, const unsigned short *__restrict__ cidx,
+                                                    const u32 *__restrict__ offs, u32 nblk, u32 chunk, u32 nreg, u64 n, void *__restrict__ out,
+                                                    const u32 *unsorted, unsigned long long *total)
+{
+    __shared__ u64 s_sum[PA_T / IVX_WAVE];
+    u64 mysum = 0;
     if (*unsorted == 0) {                                   // values already sit in input order
         const u64 lo0 = (u64)blockIdx.x * chunk;
         const u64 hi0 = lo0 + chunk < n ? lo0 + chunk : n;
-        for (u64 t = lo0 + threadIdx.x; t < hi0; t += PA_T) out[t] = SIGNED ? (i64)(i32)val[t] : (i64)val[t];
+        for (u64 t = lo0 + threadIdx.x; t < hi0; t += PA_T) { const u32 v = val[t]; up_store<OUT>(out, t, v); mysum += v; }
+        if (OUT == UP_U32 && total) { const u64 b = block_sum<u64, PA_T>(mysum, s_sum); if (threadIdx.x == 0 && b) atomicAdd(total, (unsigned long long)b); }
         return;
     }
     __shared__ u32 s_val[UP_CHUNK];
@@ -736,16 +753,17 @@ __global__ __launch_bounds__(PA_T) void k_unpermute(const u32 *__restrict__ val,
         s_val[cidx[at]] = val[at];
     }
     __syncthreads();
-    for (u32 t = tid; t < len; t += PA_T)
-        out[lo + t] = SIGNED ? (i64)(i32)s_val[t] : (i64)s_val[t];
+    for (u32 t = tid; t < len; t += PA_T) { const u32 v = s_val[t]; up_store<OUT>(out, lo + t, v); mysum += v; }
+    if (OUT == UP_U32 && total) { const u64 b = block_sum<u64, PA_T>(mysum, s_sum); if (tid == 0 && b) atomicAdd(total, (unsigned long long)b); }
 }
 
 }  // namespace
 
-// count_overlaps / coverage through the region partition: jv indexes the build rows (count) or the merged
-// nodes (coverage); out[i] for every probe row, in input order.
-ivx_status ivx_rowval_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, int coverage,
-                                    const u32 *key, const i32 *s, const i32 *e, u64 n, int strict, i64 *out)
+// One value per probe row, in input order, through the region partition.  kind: IVX_RV_COUNT (count_overlaps,
+// jv over the build rows, i64 out), IVX_RV_COVERAGE (jv over the merged nodes, i64 out), IVX_RV_PER_ROW (the
+// join's rle_right: u32 out, *d_total += all matches), IVX_RV_EXISTS (semi / anti join: u8 out).
+ivx_status ivx_rowval_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, int kind,
+                                    const u32 *key, const i32 *s, const i32 *e, u64 n, int strict, void *out, u64 *d_total)
 {
     if (n == 0) return IVX_OK;
     hipStream_t st = ctx->stream;
@@ -768,11 +786,18 @@ ivx_status ivx_rowval_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, int c
     if (vec) hipLaunchKernelGGL((k_part_scatter<true, unsigned short>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, cidx, chunk, adj, (const u32 *)unsorted, 0);
     else hipLaunchKernelGGL((k_part_scatter<false, unsigned short>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, cidx, chunk, adj, (const u32 *)unsorted, 0);
 #define IVX_RV(M_, ID_) hipLaunchKernelGGL((k_probe_regions<M_, RP_B, ID_>), dim3(RP_VGRID), dim3(RP_T), 0, st, jv, ID_ ? (const void *)s : (const void *)pse, ID_ ? (const void *)e : (const void *)nullptr, (const u32 *)hist, nblk, 1u, val, (u32 *)nullptr, (u64)0, (unsigned long long *)nullptr, 1u, adj, (const u32 *)unsorted, 0)
-    if (coverage) { IVX_RV(RV_COVERAGE, false); IVX_RV(RV_COVERAGE, true); }
-    else { IVX_RV(RV_COUNT, false); IVX_RV(RV_COUNT, true); }
+    if (kind == IVX_RV_COVERAGE) { IVX_RV(RV_COVERAGE, false); IVX_RV(RV_COVERAGE, true); }
+    else if (kind == IVX_RV_COUNT) { IVX_RV(RV_COUNT, false); IVX_RV(RV_COUNT, true); }
+    else { IVX_RV(RV_MATCHES, false); IVX_RV(RV_MATCHES, true); }
 #undef IVX_RV
-    if (coverage) hipLaunchKernelGGL(k_unpermute<true>, dim3(nblk), dim3(PA_T), 0, st, (const u32 *)val, (const unsigned short *)cidx, (const u32 *)hist, nblk, chunk, (u32)PA_ND, n, out, (const u32 *)unsorted);
-    else hipLaunchKernelGGL(k_unpermute<false>, dim3(nblk), dim3(PA_T), 0, st, (const u32 *)val, (const unsigned short *)cidx, (const u32 *)hist, nblk, chunk, (u32)PA_ND, n, out, (const u32 *)unsorted);
+#define IVX_UP(O_) hipLaunchKernelGGL(k_unpermute<O_>, dim3(nblk), dim3(PA_T), 0, st, (const u32 *)val, (const unsigned short *)cidx, (const u32 *)hist, nblk, chunk, (u32)PA_ND, n, out, (const u32 *)unsorted, (unsigned long long *)d_total)
+    switch (kind) {
+    case IVX_RV_COVERAGE: IVX_UP(UP_I64S); break;
+    case IVX_RV_COUNT: IVX_UP(UP_I64); break;
+    case IVX_RV_PER_ROW: IVX_UP(UP_U32); break;
+    default: IVX_UP(UP_U8); break;
+    }
+#undef IVX_UP
     IVX_HIP(ctx, hipGetLastError());
     return IVX_OK;
 }

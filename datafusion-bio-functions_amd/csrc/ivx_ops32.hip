@@ -480,7 +480,7 @@ ivx_status ivx_nearest_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const 
 ivx_status ivx_count_probe(ivx_ctx *ctx, const ivx_index *ix, const u32 *key, const i32 *s, const i32 *e, u64 n, int strict, i64 *out)
 {
     if (n == 0) return IVX_OK;
-    if (rowval_regions_wanted(ix, n)) return ivx_rowval_probe_regions(ctx, ix->jv, 0, key, s, e, n, strict, out);
+    if (rowval_regions_wanted(ix, n)) return ivx_rowval_probe_regions(ctx, ix->jv, IVX_RV_COUNT, key, s, e, n, strict, out, nullptr);
     hipLaunchKernelGGL(k_probe_count, dim3(ivx_stream_grid(n, OT * 4)), dim3(OT), 0, ctx->stream, ix->gs, ix->ge, key, s, e, n, strict, out);
     IVX_HIP(ctx, hipGetLastError());
     return IVX_OK;
@@ -489,7 +489,7 @@ ivx_status ivx_count_probe(ivx_ctx *ctx, const ivx_index *ix, const u32 *key, co
 ivx_status ivx_coverage_probe(ivx_ctx *ctx, const ivx_index *ix, const u32 *key, const i32 *s, const i32 *e, u64 n, int strict, i64 *out)
 {
     if (n == 0) return IVX_OK;
-    if (rowval_regions_wanted(ix, n)) return ivx_rowval_probe_regions(ctx, ix->jv, 1, key, s, e, n, strict, out);
+    if (rowval_regions_wanted(ix, n)) return ivx_rowval_probe_regions(ctx, ix->jv, IVX_RV_COVERAGE, key, s, e, n, strict, out, nullptr);
     hipLaunchKernelGGL(k_probe_coverage, dim3(ivx_stream_grid(n, OT * 4)), dim3(OT), 0, ctx->stream, ix->cv, key, s, e, n, strict, out);
     IVX_HIP(ctx, hipGetLastError());
     return IVX_OK;

@@ -33,10 +33,14 @@ def _check_join(ctx, bk, bs, be, pk, ps, pe, nkeys):
         try:
             assert ctx.overlap_count(ix, pk, ps, pe) == total, path
             ob, op = ctx.overlap_fill(ix, pk, ps, pe, cap=total)
+            t2, pr2 = ctx.overlap_count(ix, pk, ps, pe, per_row=True)     # rle_right and semi/anti through the same partition
+            ex2 = ctx.exists(ix, pk, ps, pe)
         finally:
             del os.environ["IVX_JOIN_PATH"]
         assert len(ob) == total, path
         assert (pair_set(ob, op) == pair_set(want_b, want_p)).all(), path
+        assert t2 == total and (pr2.astype(np.uint64) == want_cnt).all(), path
+        assert (ex2 == (want_cnt > 0)).all(), path
     ex = ctx.exists(ix, pk, ps, pe)
     assert (ex == (want_cnt > 0)).all()
     ix.free()
