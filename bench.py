@@ -172,6 +172,9 @@ def main():
                          "kernel_ms": kern_ms, "algorithmic_bytes": alg_bytes,
                          "build_ms": float(np.mean(build_ms))},
         }
+        tr = out["roofline"]["traffic"]
+        # real HBM traffic of the pipeline (PMC) over its measured time: the bandwidth utilisation rocprof sees
+        out["roofline"]["traffic_frac"] = (tr / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if tr else None
         if world == 1 and args.cpu_sample > 0:
             from oracle import oracle as orc                     # checker used as the timed CPU baseline only
             ns = min(args.cpu_sample, n_probe)
