@@ -433,12 +433,11 @@ extern "C" int brh_subtract(brh_session *s, brh_batch left, brh_columns lcols, b
     KeyDict kd; Side64 L, R;
     if (build_keys(s, {{left, lcols}, {right, rcols}}, &kd) || load_side64(s, left, lcols, &L) || load_side64(s, right, rcols, &R)) return 1;
     const uint32_t nk = (uint32_t)std::max<size_t>(kd.names.size(), 1);
-    uint64_t m = 0;
+    uint64_t m = 0, m2 = 0;                              // sizing call, then the fill call
     ivx_status st = ivx_subtract(s->ctx, IVX_MEM_HOST, kd.ids[0].data(), L.s.data(), L.e.data(), L.s.size(), kd.ids[1].data(), R.s.data(), R.e.data(),
                                  R.s.size(), nk, filter_op == BRH_STRICT, nullptr, nullptr, nullptr, nullptr, 0, &m);
     if (st != IVX_OK) return fail_ivx(s, st);
     std::vector<uint32_t> ok(m ? m : 1), orow(m ? m : 1); std::vector<int64_t> os(m ? m : 1), oe(m ? m : 1);
-    uint64_t m2 = 0;
     st = ivx_subtract(s->ctx, IVX_MEM_HOST, kd.ids[0].data(), L.s.data(), L.e.data(), L.s.size(), kd.ids[1].data(), R.s.data(), R.e.data(),
                       R.s.size(), nk, filter_op == BRH_STRICT, ok.data(), os.data(), oe.data(), orow.data(), m, &m2);
     if (st != IVX_OK) return fail_ivx(s, st);
@@ -490,14 +489,16 @@ extern "C" int brh_complement(brh_session *s, brh_batch table, brh_columns cols,
     }
     const uint32_t nk = (uint32_t)std::max<size_t>(kd.names.size(), 1);
     const bool strict = filter_op == BRH_STRICT;
-    uint64_t m = 0;
+    uint64_t m = T.s.size() + 2 * V.s.size() + 2 * (uint64_t)nk + 16, m2 = 0;
+    std::vector<uint32_t> ok(m); std::vector<int64_t> os(m), oe(m);
     ivx_status st = ivx_complement(s->ctx, IVX_MEM_HOST, kd.ids[0].data(), T.s.data(), T.e.data(), T.s.size(),
-                                   kd.ids[1].data(), V.s.data(), V.e.data(), V.s.size(), nk, strict, nullptr, nullptr, nullptr, 0, &m);
-    if (st != IVX_OK) return fail_ivx(s, st);
-    std::vector<uint32_t> ok(m ? m : 1); std::vector<int64_t> os(m ? m : 1), oe(m ? m : 1);
-    uint64_t m2 = 0;
-    st = ivx_complement(s->ctx, IVX_MEM_HOST, kd.ids[0].data(), T.s.data(), T.e.data(), T.s.size(),
-                        kd.ids[1].data(), V.s.data(), V.e.data(), V.s.size(), nk, strict, ok.data(), os.data(), oe.data(), m, &m2);
+                                   kd.ids[1].data(), V.s.data(), V.e.data(), V.s.size(), nk, strict, ok.data(), os.data(), oe.data(), m, &m2);
+    if (st == IVX_ERR_CAPACITY) {                        // heavily overlapping views: repeat with the exact size
+        m = m2 ? m2 : 1;
+        ok.resize(m); os.resize(m); oe.resize(m);
+        st = ivx_complement(s->ctx, IVX_MEM_HOST, kd.ids[0].data(), T.s.data(), T.e.data(), T.s.size(),
+                            kd.ids[1].data(), V.s.data(), V.e.data(), V.s.size(), nk, strict, ok.data(), os.data(), oe.data(), m, &m2);
+    }
     if (st != IVX_OK) return fail_ivx(s, st);
     make_utf8(contig, kd.names, ok.data(), (int64_t)m2); make_schema(contig_schema, "u", cols.keys[0], false);           // complement.rs:52-58
     make_primitive<int64_t>(start, os.data(), (int64_t)m2, nullptr); make_schema(start_schema, "l", cols.start, false);

@@ -288,16 +288,18 @@ class Ctx:
             n_keys = mk + 1
         args = (C.c_int(mem), _ptr(lkey), _ptr(ls), _ptr(le), C.c_uint64(nl), _ptr(rkey), _ptr(rs), _ptr(re),
                 C.c_uint64(nr), C.c_uint32(n_keys), C.c_int(int(strict)))
+        def bufs(cap):
+            if mem == MEM_DEVICE:
+                import torch
+                dev = ls.device
+                return (torch.empty(cap, dtype=torch.int32, device=dev), torch.empty(cap, dtype=torch.int64, device=dev),
+                        torch.empty(cap, dtype=torch.int64, device=dev), torch.empty(cap, dtype=torch.int32, device=dev))
+            return np.empty(cap, np.uint32), np.empty(cap, np.int64), np.empty(cap, np.int64), np.empty(cap, np.uint32)
+        # sizing call (counting half only), then the fill call: the fragment count has no useful a-priori bound
         m = C.c_uint64(0)
         self._chk(lib().ivx_subtract(self.h, *args, None, None, None, None, C.c_uint64(0), C.byref(m)))
         cap = max(m.value, 1)
-        if mem == MEM_DEVICE:
-            import torch
-            dev = ls.device
-            ok = torch.empty(cap, dtype=torch.int32, device=dev); os_ = torch.empty(cap, dtype=torch.int64, device=dev)
-            oe = torch.empty(cap, dtype=torch.int64, device=dev); orow = torch.empty(cap, dtype=torch.int32, device=dev)
-        else:
-            ok = np.empty(cap, np.uint32); os_ = np.empty(cap, np.int64); oe = np.empty(cap, np.int64); orow = np.empty(cap, np.uint32)
+        ok, os_, oe, orow = bufs(cap)
         m2 = C.c_uint64(0)
         self._chk(lib().ivx_subtract(self.h, *args, _ptr(ok), _ptr(os_), _ptr(oe), _ptr(orow), C.c_uint64(cap), C.byref(m2)))
         m2 = m2.value
@@ -354,18 +356,21 @@ class Ctx:
             n_keys = mx + 1
         args = (C.c_int(mem), _ptr(key), _ptr(s), _ptr(e), C.c_uint64(n), _ptr(vk), _ptr(vs), _ptr(ve), C.c_uint64(nv),
                 C.c_uint32(n_keys), C.c_int(int(strict)))
-        m = C.c_uint64(0)
-        self._chk(lib().ivx_complement(self.h, *args, None, None, None, C.c_uint64(0), C.byref(m)))
-        cap = max(m.value, 1)
-        if mem == MEM_DEVICE:
-            import torch
-            dev = s.device
-            ok = torch.empty(cap, dtype=torch.int32, device=dev); os_ = torch.empty(cap, dtype=torch.int64, device=dev)
-            oe = torch.empty(cap, dtype=torch.int64, device=dev)
-        else:
-            ok = np.empty(cap, np.uint32); os_ = np.empty(cap, np.int64); oe = np.empty(cap, np.int64)
+        def bufs(cap):
+            if mem == MEM_DEVICE:
+                import torch
+                dev = s.device
+                return torch.empty(cap, dtype=torch.int32, device=dev), torch.empty(cap, dtype=torch.int64, device=dev), torch.empty(cap, dtype=torch.int64, device=dev)
+            return np.empty(cap, np.uint32), np.empty(cap, np.int64), np.empty(cap, np.int64)
+        cap = max(n + 2 * nv + 2 * n_keys + 16, 1)          # enough unless views overlap each other heavily; else one retry
         m2 = C.c_uint64(0)
-        self._chk(lib().ivx_complement(self.h, *args, _ptr(ok), _ptr(os_), _ptr(oe), C.c_uint64(cap), C.byref(m2)))
+        ok, os_, oe = bufs(cap)
+        st = lib().ivx_complement(self.h, *args, _ptr(ok), _ptr(os_), _ptr(oe), C.c_uint64(cap), C.byref(m2))
+        if st == ERR_CAPACITY:
+            cap = m2.value
+            ok, os_, oe = bufs(cap)
+            st = lib().ivx_complement(self.h, *args, _ptr(ok), _ptr(os_), _ptr(oe), C.c_uint64(cap), C.byref(m2))
+        self._chk(st)
         m2 = m2.value
         return ok[:m2], os_[:m2], oe[:m2]
 
@@ -421,7 +426,13 @@ class Ctx:
         valid = mk(n, u8) if want_valid else None
         need = C.c_uint64(0)
         head = (self.h, mem, C.c_int(int(large)), _ptr(offsets), _ptr(data), C.c_uint64(n_src), C.c_uint64(nbytes), _ptr(svb), _ptr(idx), C.c_uint64(n))
-        self._chk(lib().ivx_take_utf8(*head, _ptr(out_off), None, C.c_uint64(0), C.byref(need), _ptr(valid)))
-        out_data = mk(need.value, u8)
-        self._chk(lib().ivx_take_utf8(*head, _ptr(out_off), _ptr(out_data), C.c_uint64(max(need.value, 1)), C.byref(need), _ptr(valid)))
+        # optimistic size from the mean source string length; the call reports the exact need if it is short
+        cap = int(n * (nbytes / max(n_src, 1)) * 1.5) + 64
+        out_data = mk(cap, u8)
+        st = lib().ivx_take_utf8(*head, _ptr(out_off), _ptr(out_data), C.c_uint64(cap), C.byref(need), _ptr(valid))
+        if st == ERR_CAPACITY:
+            cap = max(need.value, 1)
+            out_data = mk(cap, u8)
+            st = lib().ivx_take_utf8(*head, _ptr(out_off), _ptr(out_data), C.c_uint64(cap), C.byref(need), _ptr(valid))
+        self._chk(st)
         return out_off[: n + 1], out_data[: need.value], (valid[:n] if valid is not None else None)
