@@ -1,6 +1,7 @@
 // ivx_grid.hip -- per-key statistics and the rank-grid build (see ivx_grid.hpp).
 // Counting sort with atomics: histogram of cells, exclusive scan, scatter.
 #include "ivx_grid.hpp"
+#include "ivx_scan.hpp"
 
 namespace {
 
@@ -106,6 +107,33 @@ __global__ __launch_bounds__(GT) void k_grid_scatter(const u32 *__restrict__ key
     }
 }
 
+// input already sorted by (key, value): the cell table needs no atomics and the values no copy.  The last
+// element of every non-empty cell c leaves its end index at E[c+1]; an inclusive max-scan turns E into
+// binstart (an empty cell inherits the end of the last non-empty cell before it).
+__global__ __launch_bounds__(GT) void k_grid_bounds(const u32 *__restrict__ key, const i32 *__restrict__ v, u64 n, u32 nkeys,
+                                                    const i32 *origin, const u32 *kbase, const u32 *hdr, u32 *E)
+{
+    const u32 sh = hdr[0];
+    for (u64 i = (u64)blockIdx.x * GT + threadIdx.x; i < n; i += (u64)gridDim.x * GT) {
+        const u32 k = key ? key[i] : 0u;
+        if (k >= nkeys) continue;
+        const u32 c = kbase[k] + ((u32)((i64)v[i] - (i64)origin[k]) >> sh);
+        bool last = i + 1 == n;
+        if (!last) {
+            const u32 k2 = key ? key[i + 1] : 0u;
+            last = k2 != k || k2 >= nkeys || kbase[k2] + ((u32)((i64)v[i + 1] - (i64)origin[k2]) >> sh) != c;
+        }
+        if (last) E[c + 1] = (u32)(i + 1);
+    }
+}
+
+struct MaxU32Op {
+    using T = u32;
+    __host__ __device__ static T identity() { return 0u; }
+    __device__ static T combine(const T &a, const T &b) { return a > b ? a : b; }
+    __device__ static T shfl_up(const T &x, int d) { return __shfl_up(x, d, IVX_WAVE); }
+};
+
 }  // namespace
 
 ivx_status ivx_keystats(ivx_ctx *ctx, const u32 *key, const i32 *v, u64 n, u32 nkeys,
@@ -122,7 +150,7 @@ ivx_status ivx_keystats(ivx_ctx *ctx, const u32 *key, const i32 *v, u64 n, u32 n
     return IVX_OK;
 }
 
-ivx_status ivx_grid_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32 *v, u64 n, u32 nkeys, RankGridView *out)
+ivx_status ivx_grid_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32 *v, u64 n, u32 nkeys, RankGridView *out, bool sorted)
 {
     hipStream_t st = ctx->stream;
     const u64 maxcells = 2 * n + nkeys + 64;
@@ -135,17 +163,22 @@ ivx_status ivx_grid_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32
     IVX_TRY(ivx_index_alloc(ctx, ix, nkeys * sizeof(u32), (void **)&kbase));
     IVX_TRY(ivx_index_alloc(ctx, ix, (maxcells + 1) * sizeof(u32), (void **)&binstart));
     IVX_TRY(ivx_index_alloc(ctx, ix, 4 * sizeof(u32), (void **)&hdr));
-    IVX_TRY(ivx_index_alloc(ctx, ix, (n ? n : 1) * sizeof(i32), (void **)&val));
+    if (sorted) val = const_cast<i32 *>(v);                 // the caller's column (index memory) is the value array as it is
+    else IVX_TRY(ivx_index_alloc(ctx, ix, (n ? n : 1) * sizeof(i32), (void **)&val));
     i32 *kmin, *kmax; u32 *cursor;
     IVX_TRY(ctx->get_scratch(WS_GRID0, nkeys * sizeof(i32), (void **)&kmin));
     IVX_TRY(ctx->get_scratch(WS_GRID1, nkeys * sizeof(i32), (void **)&kmax));
     IVX_TRY(ctx->get_scratch(WS_GRID2, (maxcells + 1) * sizeof(u32), (void **)&cursor));
     u32 *errflag = (u32 *)(ctx->d_scalars + 8);
     IVX_HIP(ctx, hipMemsetAsync(binstart, 0, (maxcells + 1) * sizeof(u32), st));
-    IVX_HIP(ctx, hipMemsetAsync(cursor, 0, (maxcells + 1) * sizeof(u32), st));
+    if (!sorted) IVX_HIP(ctx, hipMemsetAsync(cursor, 0, (maxcells + 1) * sizeof(u32), st));
     IVX_TRY(ivx_keystats(ctx, key, v, n, nkeys, kmin, kmax, kcnt, errflag));
     hipLaunchKernelGGL(k_grid_layout, dim3(1), dim3(1024), 0, st, kmin, kmax, kcnt, nkeys, n, origin, span, koff, kbase, hdr);
-    if (n) {
+    if (n && sorted) {
+        const u32 grid = ivx_stream_grid(n, GT * 8, 2048);
+        hipLaunchKernelGGL(k_grid_bounds, dim3(grid), dim3(GT), 0, st, key, v, n, nkeys, origin, kbase, hdr, binstart);
+        IVX_TRY(ivxscan::inclusive<MaxU32Op>(ctx, binstart, maxcells + 1));
+    } else if (n) {
         const u32 grid = ivx_stream_grid(n, GT * 8, 1024);
         hipLaunchKernelGGL(k_grid_count, dim3(grid), dim3(GT), 0, st, key, v, n, nkeys, origin, kbase, hdr, binstart);
         IVX_TRY(ivx_scan_exclusive_u32(ctx, binstart, maxcells + 1));

@@ -39,4 +39,6 @@ ivx_status ivx_keystats(ivx_ctx *ctx, const u32 *key, const i32 *v, u64 n, u32 n
                         i32 *kmin, i32 *kmax, u32 *kcnt, u32 *errflag);
 // Build a rank grid over (key[i], v[i]), i < n.  Index memory is owned by ix.
 // kcnt_hint: per-key row counts are recomputed; key may be NULL (single key).
-ivx_status ivx_grid_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32 *v, u64 n, u32 nkeys, RankGridView *out);
+// sorted = the rows come grouped by ascending key with non-decreasing v inside a key AND v is index memory
+// that outlives the grid: no atomics, no copy of the values.
+ivx_status ivx_grid_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32 *v, u64 n, u32 nkeys, RankGridView *out, bool sorted = false);

@@ -431,8 +431,8 @@ ivx_status ivx_coverage_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const
     IVX_TRY(ivx_index_alloc(ctx, ix, (m + 1) * sizeof(u64), (void **)&pw));
     hipLaunchKernelGGL(k_nodes, dim3(grid1(m + 1)), dim3(OT), 0, st, (const i64 *)rs, (const i64 *)re, m, nfirst, nlast, pw);
     IVX_TRY(ivx_scan_exclusive_u64(ctx, pw, m + 1));
-    IVX_TRY(ivx_grid_build(ctx, ix, rk, nfirst, m, nkeys, &ix->cv.first));
-    IVX_TRY(ivx_grid_build(ctx, ix, rk, nlast, m, nkeys, &ix->cv.last));
+    IVX_TRY(ivx_grid_build(ctx, ix, rk, nfirst, m, nkeys, &ix->cv.first, true));   // merged nodes: disjoint, ascending
+    IVX_TRY(ivx_grid_build(ctx, ix, rk, nlast, m, nkeys, &ix->cv.last, true));
     ix->cv.nfirst = nfirst; ix->cv.nlast = nlast; ix->cv.pw = (const i64 *)pw;
     IVX_HIP(ctx, hipGetLastError());
     // overlap index over the merged nodes for the region-partitioned probe of big batches
@@ -466,9 +466,9 @@ ivx_status ivx_nearest_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const 
         IVX_TRY(ivxscan::inclusive<SegMaxOp>(ctx, sm, n));                               // prefix_max_end :58-63
         hipLaunchKernelGGL(k_segmax_out, dim3(grid1(n)), dim3(OT), 0, st, (const SegMax *)sm, n, pmaxv);
     }
-    IVX_TRY(ivx_grid_build(ctx, ix, ks, s_start, n, nkeys, &ix->nv.by_start));
-    IVX_TRY(ivx_grid_build(ctx, ix, ke, e_end, n, nkeys, &ix->nv.by_end));
-    IVX_TRY(ivx_grid_build(ctx, ix, ks, pmaxv, n, nkeys, &ix->nv.pmax));
+    IVX_TRY(ivx_grid_build(ctx, ix, ks, s_start, n, nkeys, &ix->nv.by_start, true));   // sorted columns, prefix max: all ascending per key
+    IVX_TRY(ivx_grid_build(ctx, ix, ke, e_end, n, nkeys, &ix->nv.by_end, true));
+    IVX_TRY(ivx_grid_build(ctx, ix, ks, pmaxv, n, nkeys, &ix->nv.pmax, true));
     ix->nv.s_start = s_start; ix->nv.s_end = s_end; ix->nv.s_row = s_row;
     ix->nv.e_start = e_start; ix->nv.e_end = e_end; ix->nv.e_row = e_row; ix->nv.pmaxv = pmaxv;
     IVX_HIP(ctx, hipGetLastError());
