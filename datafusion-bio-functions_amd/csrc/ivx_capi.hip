@@ -375,6 +375,7 @@ ivx_status ivx_complement_device(ivx_ctx *ctx, const u32 *key, const i64 *s, con
                                  u32 *ok, i64 *os, i64 *oe, u64 cap, u64 *n_out);
 ivx_status ivx_take_fixed_device(ivx_ctx *ctx, const void *src, u32 width, u64 n_src, const u8 *src_valid,
                                  const u32 *idx, u64 n, void *out, u8 *out_valid);
+ivx_status ivx_take_bits_device(ivx_ctx *ctx, const u8 *src_bits, u64 n_src, const u8 *src_valid, const u32 *idx, u64 n, u8 *out_bits, u8 *out_valid);
 ivx_status ivx_take_utf8_device(ivx_ctx *ctx, int large, const void *offsets, const u8 *data, u64 n_src, const u8 *src_valid,
                                 const u32 *idx, u64 n, void *out_offsets, u8 *out_data, u64 data_cap, u64 *data_bytes, u8 *out_valid);
 
@@ -662,6 +663,30 @@ extern "C" ivx_status ivx_take_utf8(ivx_ctx *ctx, int mem, int large, const void
     }
     IVX_TRY(copy_out(ctx, mem, (u8 *)out_offsets, dooff, (n + 1) * ow));
     if (out_data) IVX_TRY(copy_out(ctx, mem, out_data, dodata, total));
+    IVX_TRY(copy_out(ctx, mem, out_valid, dov, n));
+    if (mem == IVX_MEM_HOST) IVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return IVX_OK;
+}
+
+extern "C" ivx_status ivx_take_bits(ivx_ctx *ctx, int mem, const uint8_t *src_bits, uint64_t n_src, const uint8_t *src_valid_bits,
+                                    const uint32_t *idx, uint64_t n, uint8_t *out_bits, uint8_t *out_valid)
+{
+    if (!ctx) return IVX_ERR_INVALID;
+    if (mem != IVX_MEM_HOST && mem != IVX_MEM_DEVICE) return ctx->fail(IVX_ERR_INVALID, "bad mem");
+    if (n && (!idx || !out_bits)) return ctx->fail(IVX_ERR_INVALID, "take: null idx or out");
+    if (n_src && !src_bits) return ctx->fail(IVX_ERR_INVALID, "take: null source column");
+    IVX_HIP(ctx, hipSetDevice(ctx->device));
+    const u8 *dsrc, *dvalid; const u32 *didx; u8 *dout, *dov;
+    IVX_TRY(stage_in(ctx, mem, WS_IN_KEY, src_bits, (n_src + 7) / 8, &dsrc));
+    IVX_TRY(stage_in(ctx, mem, WS_IN_START, src_valid_bits, (n_src + 7) / 8, &dvalid));
+    IVX_TRY(stage_in(ctx, mem, WS_IN_END, idx, n, &didx));
+    IVX_TRY(stage_out(ctx, mem, WS_OUT_A, out_bits, (n + 7) / 8, &dout));
+    IVX_TRY(stage_out(ctx, mem, WS_OUT_B, out_valid, n, &dov));
+    {
+        KernelTimer t(ctx);
+        IVX_TRY(ivx_take_bits_device(ctx, dsrc, n_src, dvalid, didx, n, dout, dov));
+    }
+    IVX_TRY(copy_out(ctx, mem, out_bits, dout, (n + 7) / 8));
     IVX_TRY(copy_out(ctx, mem, out_valid, dov, n));
     if (mem == IVX_MEM_HOST) IVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return IVX_OK;

@@ -38,6 +38,27 @@ __global__ __launch_bounds__(TK) void k_take_fixed(const V *__restrict__ src, u6
 
 struct alignas(16) B32 { uint4 a, b; };
 
+// Boolean columns are bitmaps: one thread packs eight output bits into one byte
+__global__ __launch_bounds__(TK) void k_take_bits(const u8 *__restrict__ src, u64 n_src, const u8 *__restrict__ src_valid,
+                                                  const u32 *__restrict__ idx, u64 n, u8 *__restrict__ out, u8 *__restrict__ out_valid, u32 *bad)
+{
+    const u64 nbytes = (n + 7) / 8;
+    for (u64 b = (u64)blockIdx.x * TK + threadIdx.x; b < nbytes; b += (u64)gridDim.x * TK) {
+        u32 byte = 0;
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            const u64 i = b * 8 + t;
+            if (i >= n) break;
+            const u32 j = idx[i];
+            bool ok = j != IVX_NULL_IDX;
+            if (ok && j >= n_src) { *bad = 1; ok = false; }
+            if (ok && bit_at(src, j)) byte |= 1u << t;
+            if (out_valid) out_valid[i] = (ok && (!src_valid || bit_at(src_valid, j))) ? 1 : 0;
+        }
+        out[b] = (u8)byte;
+    }
+}
+
 template <typename O>
 __global__ __launch_bounds__(TK) void k_take_len(const O *__restrict__ off, u64 n_src, const u8 *__restrict__ src_valid,
                                                  const u32 *__restrict__ idx, u64 n, u64 *__restrict__ len, u8 *__restrict__ out_valid, u32 *bad)
@@ -121,6 +142,15 @@ ivx_status ivx_take_fixed_device(ivx_ctx *ctx, const void *src, u32 width, u64 n
 #undef IVX_TAKE
         IVX_HIP(ctx, hipGetLastError());
     }
+    return take_flag(ctx);
+}
+
+ivx_status ivx_take_bits_device(ivx_ctx *ctx, const u8 *src_bits, u64 n_src, const u8 *src_valid, const u32 *idx, u64 n, u8 *out_bits, u8 *out_valid)
+{
+    hipStream_t st = ctx->stream;
+    IVX_HIP(ctx, hipMemsetAsync(ctx->d_scalars + 8, 0, sizeof(u64), st));
+    if (n) hipLaunchKernelGGL(k_take_bits, dim3(take_grid((n + 7) / 8)), dim3(TK), 0, st, src_bits, n_src, src_valid, idx, n, out_bits, out_valid, (u32 *)(ctx->d_scalars + 8));
+    IVX_HIP(ctx, hipGetLastError());
     return take_flag(ctx);
 }
 

@@ -599,9 +599,24 @@ extern "C" int brh_take(brh_session *s, const ArrowArray *column, const ArrowSch
         p->bufs.push_back(ooff); p->bufs.push_back(odata);
         p->ptrs[1] = ooff; p->ptrs[2] = odata;
         finish_array(out, p, n, valid.data(), 3);
+    } else if (!std::strcmp(f, "b")) {                       // Boolean: bit-packed values
+        const uint8_t *src = (const uint8_t *)column->buffers[1];
+        std::vector<uint8_t> sstore;
+        if (column->offset % 8) {                             // re-base the value bitmap like the validity bitmap
+            sstore.assign((size_t)(column->length + 7) / 8, 0);
+            for (int64_t i = 0; i < column->length; i++) { const int64_t j = i + column->offset; if ((src[j >> 3] >> (j & 7)) & 1) sstore[i >> 3] |= (uint8_t)(1u << (i & 7)); }
+            src = sstore.data();
+        } else src += column->offset / 8;
+        uint8_t *o = (uint8_t *)std::calloc((size_t)(n + 7) / 8 + 1, 1);
+        const ivx_status st = ivx_take_bits(s->ctx, IVX_MEM_HOST, src, n_src, svb, ix.data(), (uint64_t)n, o, valid.data());
+        if (st != IVX_OK) { std::free(o); return fail_ivx(s, st); }
+        OutPriv *p = new OutPriv();
+        p->bufs.push_back(o);
+        p->ptrs[1] = o;
+        finish_array(out, p, n, valid.data(), 2);
     } else {
         const uint32_t w = fixed_width(f);
-        if (!w) return fail(s, "take: unsupported column type " + std::string(f) + " (fixed-width primitives and Utf8/LargeUtf8/Binary/LargeBinary only)");
+        if (!w) return fail(s, "take: unsupported column type " + std::string(f) + " (fixed-width primitives, Boolean and Utf8/LargeUtf8/Binary/LargeBinary only)");
         const uint8_t *src = (const uint8_t *)column->buffers[1] + (size_t)column->offset * w;
         void *o = std::malloc((size_t)(n ? n : 1) * w);
         const ivx_status st = ivx_take_fixed(s->ctx, IVX_MEM_HOST, src, w, n_src, svb, ix.data(), (uint64_t)n, o, valid.data());

@@ -217,6 +217,10 @@ ivx_status ivx_take_fixed(ivx_ctx *ctx, int mem, const void *src, uint32_t width
                           const uint8_t *src_valid_bits, const uint32_t *idx, uint64_t n,
                           void *out, uint8_t *out_valid);
 
+/*      Boolean columns (bit-packed, LSB first): out_bits gets (n+7)/8 bytes. */
+ivx_status ivx_take_bits(ivx_ctx *ctx, int mem, const uint8_t *src_bits, uint64_t n_src, const uint8_t *src_valid_bits,
+                         const uint32_t *idx, uint64_t n, uint8_t *out_bits, uint8_t *out_valid);
+
 /*      Utf8 / Binary (large = 0, int32 offsets) and LargeUtf8 / LargeBinary (large = 1, int64).
  *      out_offsets[n+1] is written whenever given; *data_bytes always returns the bytes needed.
  *      out_data = NULL sizes only; data_cap < *data_bytes is IVX_ERR_CAPACITY. */

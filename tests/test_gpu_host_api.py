@@ -215,6 +215,7 @@ def test_device_take_matches_arrow_take(ctx):
         "gene": pa.array([None if i % 11 == 0 else "gene%d" % i * (i % 4) for i in range(n)], pa.string()),
         "big": pa.array(["x" * (i % 50) for i in range(n)], pa.large_string()),
         "bin": pa.array([bytes([i % 256]) * (i % 6) for i in range(n)], pa.binary()),
+        "flag": pa.array([None if i % 7 == 0 else (i % 3 == 0) for i in range(n)], pa.bool_()),
     }
     t = pa.table(cols).slice(3)                                       # non-zero offsets into every buffer, bitmaps included
     idx = pa.array([None if i % 13 == 0 else (i * 7) % t.num_rows for i in range(1000)], pa.uint32())
@@ -222,7 +223,7 @@ def test_device_take_matches_arrow_take(ctx):
         got, want = ctx.take(t.column(name), idx), pc.take(t.column(name), idx)
         assert got.type == want.type and got.to_pylist() == want.combine_chunks().to_pylist(), name
     with pytest.raises(br.BioRangesError, match="unsupported column type"):
-        ctx.take(pa.array([True, False]), pa.array([0], pa.uint32()))
+        ctx.take(pa.array([[1], [2]]), pa.array([0], pa.uint32()))             # nested: stays with the caller
     with pytest.raises(br.BioRangesError, match="out of bounds"):
         ctx.take(pa.array([1, 2]), pa.array([2], pa.uint32()))
 
