@@ -375,6 +375,8 @@ ivx_status ivx_complement_device(ivx_ctx *ctx, const u32 *key, const i64 *s, con
                                  u32 *ok, i64 *os, i64 *oe, u64 cap, u64 *n_out);
 ivx_status ivx_take_fixed_device(ivx_ctx *ctx, const void *src, u32 width, u64 n_src, const u8 *src_valid,
                                  const u32 *idx, u64 n, void *out, u8 *out_valid);
+ivx_status ivx_take_view_device(ivx_ctx *ctx, const void *views, const u8 *const *bufs, u64 n_src, const u8 *src_valid,
+                                const u32 *idx, u64 n, void *out_views, u8 *out_data, u64 data_cap, u64 *data_bytes, u8 *out_valid);
 ivx_status ivx_take_bits_device(ivx_ctx *ctx, const u8 *src_bits, u64 n_src, const u8 *src_valid, const u32 *idx, u64 n, u8 *out_bits, u8 *out_valid);
 ivx_status ivx_take_utf8_device(ivx_ctx *ctx, int large, const void *offsets, const u8 *data, u64 n_src, const u8 *src_valid,
                                 const u32 *idx, u64 n, void *out_offsets, u8 *out_data, u64 data_cap, u64 *data_bytes, u8 *out_valid);
@@ -687,6 +689,59 @@ extern "C" ivx_status ivx_take_bits(ivx_ctx *ctx, int mem, const uint8_t *src_bi
         IVX_TRY(ivx_take_bits_device(ctx, dsrc, n_src, dvalid, didx, n, dout, dov));
     }
     IVX_TRY(copy_out(ctx, mem, out_bits, dout, (n + 7) / 8));
+    IVX_TRY(copy_out(ctx, mem, out_valid, dov, n));
+    if (mem == IVX_MEM_HOST) IVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return IVX_OK;
+}
+
+extern "C" ivx_status ivx_take_view(ivx_ctx *ctx, int mem, const void *views, const uint8_t *const *data_bufs, const uint64_t *data_buf_bytes,
+                                    uint32_t n_bufs, uint64_t n_src, const uint8_t *src_valid_bits, const uint32_t *idx, uint64_t n,
+                                    void *out_views, uint8_t *out_data, uint64_t data_cap, uint64_t *data_bytes, uint8_t *out_valid)
+{
+    if (!ctx) return IVX_ERR_INVALID;
+    if (!data_bytes) return ctx->fail(IVX_ERR_INVALID, "null data_bytes");
+    *data_bytes = 0;
+    if (mem != IVX_MEM_HOST && mem != IVX_MEM_DEVICE) return ctx->fail(IVX_ERR_INVALID, "bad mem");
+    if (n && !idx) return ctx->fail(IVX_ERR_INVALID, "take: null idx");
+    if ((n_src && !views) || (n_bufs && (!data_bufs || !data_buf_bytes))) return ctx->fail(IVX_ERR_INVALID, "take: null source column");
+    if (n_bufs > 4096) return ctx->fail(IVX_ERR_UNSUPPORTED, "take: more than 4096 view data buffers");
+    IVX_HIP(ctx, hipSetDevice(ctx->device));
+    const u8 *dviews, *dvalid; const u32 *didx; u8 *doviews, *dodata, *dov;
+    IVX_TRY(stage_in(ctx, mem, WS_IN_KEY, (const u8 *)views, n_src * 16, &dviews));
+    IVX_TRY(stage_in(ctx, mem, WS_IN_START, src_valid_bits, (n_src + 7) / 8, &dvalid));
+    IVX_TRY(stage_in(ctx, mem, WS_IN_END, idx, n, &didx));
+    // the variadic data buffers: device pointers in one small device table (host mode: one staging area for all)
+    std::vector<const u8 *> ptrs(n_bufs ? n_bufs : 1, nullptr);
+    if (mem == IVX_MEM_HOST) {
+        u64 tot = 0;
+        for (u32 b = 0; b < n_bufs; b++) tot += (data_buf_bytes[b] + 15) & ~15ull;
+        u8 *area;
+        IVX_TRY(ctx->get_scratch(WS_IN2_START, tot ? tot : 16, (void **)&area));
+        u64 at = 0;
+        for (u32 b = 0; b < n_bufs; b++) {
+            if (data_buf_bytes[b]) IVX_HIP(ctx, hipMemcpyAsync(area + at, data_bufs[b], data_buf_bytes[b], hipMemcpyHostToDevice, ctx->stream));
+            ptrs[b] = area + at;
+            at += (data_buf_bytes[b] + 15) & ~15ull;
+        }
+    } else {
+        for (u32 b = 0; b < n_bufs; b++) ptrs[b] = data_bufs[b];
+    }
+    const u8 **dtable;
+    IVX_TRY(ctx->get_scratch(WS_IN2_KEY, ptrs.size() * sizeof(u8 *), (void **)&dtable));
+    IVX_HIP(ctx, hipMemcpyAsync(dtable, ptrs.data(), ptrs.size() * sizeof(u8 *), hipMemcpyHostToDevice, ctx->stream));
+    IVX_HIP(ctx, hipStreamSynchronize(ctx->stream));                            // `ptrs` is pageable host memory
+    IVX_TRY(stage_out(ctx, mem, WS_OUT_A, (u8 *)out_views, n * 16, &doviews));
+    IVX_TRY(stage_out(ctx, mem, WS_OUT_B, out_data, data_cap, &dodata));
+    IVX_TRY(stage_out(ctx, mem, WS_OUT_C, out_valid, n, &dov));
+    u64 total = 0;
+    {
+        KernelTimer t(ctx);
+        ivx_status st = ivx_take_view_device(ctx, dviews, dtable, n_src, dvalid, didx, n, doviews, dodata, data_cap, &total, dov);
+        *data_bytes = total;
+        if (st != IVX_OK) return st;
+    }
+    if (out_views && (out_data || total == 0)) IVX_TRY(copy_out(ctx, mem, (u8 *)out_views, doviews, n * 16));
+    if (out_data) IVX_TRY(copy_out(ctx, mem, out_data, dodata, total));
     IVX_TRY(copy_out(ctx, mem, out_valid, dov, n));
     if (mem == IVX_MEM_HOST) IVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return IVX_OK;

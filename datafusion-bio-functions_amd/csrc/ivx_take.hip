@@ -109,6 +109,57 @@ __global__ __launch_bounds__(TK) void k_take_bytes(const O *__restrict__ off, co
     }
 }
 
+// ---- Utf8View / BinaryView: 16-byte views {len, prefix | inline bytes, buffer index, offset}.  Strings of at
+// most 12 bytes live inside the view; longer ones are gathered into ONE new data buffer (the output never
+// refers to the source's buffers) and their views are rewritten to (buffer 0, new offset).
+struct View16 { u32 len; u32 w1; u32 w2; u32 w3; };
+
+__global__ __launch_bounds__(TK) void k_view_len(const View16 *__restrict__ views, u64 n_src, const u8 *__restrict__ src_valid,
+                                                 const u32 *__restrict__ idx, u64 n, u64 *__restrict__ len, u8 *__restrict__ out_valid, u32 *bad)
+{
+    for (u64 i = (u64)blockIdx.x * TK + threadIdx.x; i <= n; i += (u64)gridDim.x * TK) {
+        if (i == n) { len[i] = 0; continue; }
+        const u32 j = idx[i];
+        bool ok = j != IVX_NULL_IDX;
+        if (ok && j >= n_src) { *bad = 1; ok = false; }
+        const u32 l = ok ? views[j].len : 0u;
+        len[i] = l > 12 ? l : 0;                                     // bytes this row needs in the new data buffer
+        if (out_valid) out_valid[i] = (ok && (!src_valid || bit_at(src_valid, j))) ? 1 : 0;
+    }
+}
+
+__global__ __launch_bounds__(TK) void k_view_copy(const View16 *__restrict__ views, const u8 *const *__restrict__ bufs, const u32 *__restrict__ idx, u64 n,
+                                                  const u64 *__restrict__ pos, View16 *__restrict__ out_views, u8 *__restrict__ out_data)
+{
+    __shared__ u64 s_ex[TK / IVX_WAVE][IVX_WAVE];
+    __shared__ const u8 *s_src[TK / IVX_WAVE][IVX_WAVE];
+    const u32 wv = threadIdx.x / IVX_WAVE, ln = lane_id();
+    const u64 ngroups = (n + IVX_WAVE - 1) / IVX_WAVE;
+    for (u64 g = (u64)blockIdx.x * (TK / IVX_WAVE) + wv; g < ngroups; g += (u64)gridDim.x * (TK / IVX_WAVE)) {
+        const u64 i = g * IVX_WAVE + ln;
+        const u64 p0 = pos[g * IVX_WAVE];
+        const u64 hi_row = (g + 1) * IVX_WAVE < n ? (g + 1) * IVX_WAVE : n;
+        const u64 total = pos[hi_row] - p0;
+        u64 ex = ~0ull; const u8 *src = nullptr;
+        if (i < n) {
+            const u32 j = idx[i];
+            View16 v{0, 0, 0, 0};
+            if (j != IVX_NULL_IDX) v = views[j];
+            ex = pos[i] - p0;
+            if (v.len > 12) { src = bufs[v.w2] + v.w3; v.w2 = 0; v.w3 = (u32)pos[i]; }   // (the prefix word stays)
+            out_views[i] = v;
+        }
+        s_ex[wv][ln] = ex; s_src[wv][ln] = src;
+        __builtin_amdgcn_wave_barrier();
+        for (u64 t = ln; t < total; t += IVX_WAVE) {
+            u32 lo = 0, hi = IVX_WAVE - 1;
+            while (lo < hi) { const u32 mid = (lo + hi + 1) >> 1; if (s_ex[wv][mid] <= t) lo = mid; else hi = mid - 1; }
+            out_data[p0 + t] = s_src[wv][lo][t - s_ex[wv][lo]];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 u32 take_grid(u64 n) { return ivx_stream_grid(n, TK * 4, 256 * 16); }
 
 ivx_status take_flag(ivx_ctx *ctx)
@@ -185,6 +236,36 @@ ivx_status ivx_take_utf8_device(ivx_ctx *ctx, int large, const void *offsets, co
         const u32 g2 = ivx_stream_grid(ngroups, TK / IVX_WAVE, 256 * 16);
         if (large) hipLaunchKernelGGL(k_take_bytes<i64>, dim3(g2), dim3(TK), 0, st, (const i64 *)offsets, data, idx, n, (const u64 *)pos, out_data);
         else hipLaunchKernelGGL(k_take_bytes<i32>, dim3(g2), dim3(TK), 0, st, (const i32 *)offsets, data, idx, n, (const u64 *)pos, out_data);
+    }
+    IVX_HIP(ctx, hipGetLastError());
+    return IVX_OK;
+}
+
+// views: [n_src] 16-byte views; bufs: device array of the n_bufs variadic data buffer pointers (device memory).
+// out_views [n] always written when given; out_data = NULL sizes only (*data_bytes = bytes of the long strings).
+ivx_status ivx_take_view_device(ivx_ctx *ctx, const void *views, const u8 *const *bufs, u64 n_src, const u8 *src_valid,
+                                const u32 *idx, u64 n, void *out_views, u8 *out_data, u64 data_cap, u64 *data_bytes, u8 *out_valid)
+{
+    hipStream_t st = ctx->stream;
+    *data_bytes = 0;
+    IVX_HIP(ctx, hipMemsetAsync(ctx->d_scalars + 8, 0, sizeof(u64), st));
+    u32 *bad = (u32 *)(ctx->d_scalars + 8);
+    u64 *pos;
+    IVX_TRY(ctx->get_scratch(WS_T0, (n + 1) * sizeof(u64), (void **)&pos));
+    const u32 grid = take_grid(n + 1);
+    hipLaunchKernelGGL(k_view_len, dim3(grid), dim3(TK), 0, st, (const View16 *)views, n_src, src_valid, idx, n, pos, out_valid, bad);
+    IVX_TRY(ivx_scan_exclusive_u64(ctx, pos, n + 1));
+    IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 5, pos + n, sizeof(u64), hipMemcpyDeviceToHost, st));
+    IVX_TRY(take_flag(ctx));
+    const u64 total = ctx->h_scalars[5];
+    *data_bytes = total;
+    if (total > 0x7FFFFFFFull) return ctx->fail(IVX_ERR_UNSUPPORTED, "take: gathered view data exceeds one 2 GiB buffer");
+    if (!out_views || (total && !out_data)) return IVX_OK;                      // sizing call
+    if (total > data_cap) return ctx->fail(IVX_ERR_CAPACITY, "take: string data buffer too small");
+    if (n) {
+        const u64 ngroups = (n + IVX_WAVE - 1) / IVX_WAVE;
+        hipLaunchKernelGGL(k_view_copy, dim3(ivx_stream_grid(ngroups, TK / IVX_WAVE, 256 * 16)), dim3(TK), 0, st, (const View16 *)views, bufs, idx, n,
+                           (const u64 *)pos, (View16 *)out_views, out_data);
     }
     IVX_HIP(ctx, hipGetLastError());
     return IVX_OK;

@@ -199,7 +199,7 @@ int build_keys(brh_session *s, const std::vector<std::pair<brh_batch, brh_column
 }
 
 // ---- Arrow output helpers
-struct OutPriv { std::vector<void *> bufs; const void *ptrs[3]; char *fmt; };
+struct OutPriv { std::vector<void *> bufs; const void *ptrs[4] = {nullptr, nullptr, nullptr, nullptr}; char *fmt = nullptr; };
 
 void release_array(ArrowArray *a)
 {
@@ -599,6 +599,28 @@ extern "C" int brh_take(brh_session *s, const ArrowArray *column, const ArrowSch
         p->bufs.push_back(ooff); p->bufs.push_back(odata);
         p->ptrs[1] = ooff; p->ptrs[2] = odata;
         finish_array(out, p, n, valid.data(), 3);
+    } else if (!std::strcmp(f, "vu") || !std::strcmp(f, "vz")) {   // Utf8View / BinaryView (DataFusion's default string type for Parquet)
+        if (column->n_buffers < 3) return fail(s, "take: malformed view array");
+        const uint32_t nb = (uint32_t)(column->n_buffers - 3);
+        const int64_t *sizes = (const int64_t *)column->buffers[column->n_buffers - 1];
+        std::vector<const uint8_t *> bufs(nb ? nb : 1, nullptr); std::vector<uint64_t> bytes(nb ? nb : 1, 0);
+        for (uint32_t b = 0; b < nb; b++) { bufs[b] = (const uint8_t *)column->buffers[2 + b]; bytes[b] = (uint64_t)sizes[b]; }
+        const uint8_t *views = (const uint8_t *)column->buffers[1] + (size_t)column->offset * 16;
+        void *oviews = std::malloc((size_t)(n ? n : 1) * 16);
+        uint64_t need = 0;
+        ivx_status st = ivx_take_view(s->ctx, IVX_MEM_HOST, views, bufs.data(), bytes.data(), nb, n_src, svb, ix.data(), (uint64_t)n,
+                                      nullptr, nullptr, 0, &need, valid.data());
+        uint8_t *odata = (uint8_t *)std::malloc((size_t)(need ? need : 1));
+        if (st == IVX_OK)
+            st = ivx_take_view(s->ctx, IVX_MEM_HOST, views, bufs.data(), bytes.data(), nb, n_src, svb, ix.data(), (uint64_t)n,
+                               oviews, odata, need ? need : 1, &need, valid.data());
+        if (st != IVX_OK) { std::free(oviews); std::free(odata); return fail_ivx(s, st); }
+        int64_t *osz = (int64_t *)std::malloc(sizeof(int64_t));
+        osz[0] = (int64_t)need;
+        OutPriv *p = new OutPriv();
+        p->bufs.push_back(oviews); p->bufs.push_back(odata); p->bufs.push_back(osz);
+        p->ptrs[1] = oviews; p->ptrs[2] = odata; p->ptrs[3] = osz;
+        finish_array(out, p, n, valid.data(), 4);
     } else if (!std::strcmp(f, "b")) {                       // Boolean: bit-packed values
         const uint8_t *src = (const uint8_t *)column->buffers[1];
         std::vector<uint8_t> sstore;
@@ -616,7 +638,7 @@ extern "C" int brh_take(brh_session *s, const ArrowArray *column, const ArrowSch
         finish_array(out, p, n, valid.data(), 2);
     } else {
         const uint32_t w = fixed_width(f);
-        if (!w) return fail(s, "take: unsupported column type " + std::string(f) + " (fixed-width primitives, Boolean and Utf8/LargeUtf8/Binary/LargeBinary only)");
+        if (!w) return fail(s, "take: unsupported column type " + std::string(f) + " (fixed-width primitives, Boolean, Utf8/LargeUtf8/Binary/LargeBinary and their views only)");
         const uint8_t *src = (const uint8_t *)column->buffers[1] + (size_t)column->offset * w;
         void *o = std::malloc((size_t)(n ? n : 1) * w);
         const ivx_status st = ivx_take_fixed(s->ctx, IVX_MEM_HOST, src, w, n_src, svb, ix.data(), (uint64_t)n, o, valid.data());

@@ -25,7 +25,7 @@ SYMBOLS = [
     "ivx_ctx_last_kernel_ms", "ivx_version", "ivx_index_build", "ivx_index_free", "ivx_index_rows",
     "ivx_index_device_bytes", "ivx_probe_overlap_count", "ivx_probe_overlap_fill", "ivx_probe_exists",
     "ivx_probe_count", "ivx_probe_coverage", "ivx_probe_nearest", "ivx_merge", "ivx_subtract",
-    "ivx_cluster", "ivx_complement", "ivx_take_fixed", "ivx_take_utf8", "ivx_take_bits",
+    "ivx_cluster", "ivx_complement", "ivx_take_fixed", "ivx_take_utf8", "ivx_take_bits", "ivx_take_view",
 ]
 
 

@@ -126,8 +126,9 @@ int brh_complement(brh_session *s, brh_batch table, brh_columns cols, brh_batch 
 /* compute::take of ONE payload column with an index array a join / nearest call returned
  * (interval_join.rs:1655-1667, nearest.rs:469-482), on the device.  column: any fixed-width primitive
  * (ints, floats, date/time/timestamp/duration, decimal128/256, fixed-size binary of 1/2/4/8/16/32 bytes),
- * Boolean, or Utf8 / LargeUtf8 / Binary / LargeBinary; idx: UInt32, nulls allowed (-> null output slots).
- * Other layouts (views, nested, dictionary) return an error: the caller keeps them on
+ * Boolean, Utf8 / LargeUtf8 / Binary / LargeBinary, or Utf8View / BinaryView (the output is compacted
+ * into one data buffer); idx: UInt32, nulls allowed (-> null output slots).
+ * Other layouts (nested, dictionary) return an error: the caller keeps them on
  * its own take.  The output has the column's type and is nullable. */
 int brh_take(brh_session *s, const struct ArrowArray *column, const struct ArrowSchema *column_schema,
              const struct ArrowArray *idx, const struct ArrowSchema *idx_schema,

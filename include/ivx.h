@@ -229,6 +229,14 @@ ivx_status ivx_take_utf8(ivx_ctx *ctx, int mem, int large, const void *offsets, 
                          void *out_offsets, uint8_t *out_data, uint64_t data_cap, uint64_t *data_bytes,
                          uint8_t *out_valid);
 
+/*      Utf8View / BinaryView: views = [n_src] 16-byte views, data_bufs[n_bufs] the variadic data buffers
+ *      with their sizes.  The output is self-contained: out_views[n] plus ONE data buffer holding the
+ *      gathered strings longer than 12 bytes (views rewritten to buffer 0).  out_data = NULL sizes only
+ *      (*data_bytes); more than 2^31-1 gathered bytes is IVX_ERR_UNSUPPORTED. */
+ivx_status ivx_take_view(ivx_ctx *ctx, int mem, const void *views, const uint8_t *const *data_bufs, const uint64_t *data_buf_bytes,
+                         uint32_t n_bufs, uint64_t n_src, const uint8_t *src_valid_bits, const uint32_t *idx, uint64_t n,
+                         void *out_views, uint8_t *out_data, uint64_t data_cap, uint64_t *data_bytes, uint8_t *out_valid);
+
 #ifdef __cplusplus
 }
 #endif

@@ -216,11 +216,21 @@ def test_device_take_matches_arrow_take(ctx):
         "big": pa.array(["x" * (i % 50) for i in range(n)], pa.large_string()),
         "bin": pa.array([bytes([i % 256]) * (i % 6) for i in range(n)], pa.binary()),
         "flag": pa.array([None if i % 7 == 0 else (i % 3 == 0) for i in range(n)], pa.bool_()),
+        "view": pa.array([None if i % 10 == 0 else ("v%d-" % i) * (i % 7) for i in range(n)], pa.string_view()),
+        "bview": pa.array([bytes([65 + i % 26]) * (i % 40) for i in range(n)], pa.binary_view()),
     }
     t = pa.table(cols).slice(3)                                       # non-zero offsets into every buffer, bitmaps included
     idx = pa.array([None if i % 13 == 0 else (i * 7) % t.num_rows for i in range(1000)], pa.uint32())
     for name in t.schema.names:
-        got, want = ctx.take(t.column(name), idx), pc.take(t.column(name), idx)
+        col = t.column(name)
+        got = ctx.take(col, idx)
+        if "view" in str(col.type):                                  # this pyarrow has no take kernel for views: spell it out
+            vals = col.to_pylist()
+            want = [None if j is None else vals[j] for j in idx.to_pylist()]
+            assert got.type == col.type and got.to_pylist() == want, name
+            got.validate(full=True)
+            continue
+        want = pc.take(col, idx)
         assert got.type == want.type and got.to_pylist() == want.combine_chunks().to_pylist(), name
     with pytest.raises(br.BioRangesError, match="unsupported column type"):
         ctx.take(pa.array([[1], [2]]), pa.array([0], pa.uint32()))             # nested: stays with the caller
