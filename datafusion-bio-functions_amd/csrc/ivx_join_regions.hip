@@ -38,10 +38,11 @@ namespace {
 // ------------------------------------------------------------------ partition pass
 
 constexpr int PA_T = 1024;
-constexpr int PA_I = 8;
-constexpr int PA_TILE = PA_T * PA_I;              // 8192 rows: ~40 rows per region and tile; one workgroup per CU keeps the open output lines within L2
-constexpr int PA_TPB = 4;
-constexpr u64 PA_CHUNK = (u64)PA_TILE * PA_TPB;   // most rows one workgroup takes (32768)
+#ifndef IVX_PA_I
+#define IVX_PA_I 12
+#endif
+constexpr int PA_I = IVX_PA_I;                    // rows per thread and tile (multiple of 4)
+constexpr int PA_TILE = PA_T * PA_I;              // 12288 rows: ~63 rows per region and tile = the length of the runs written to HBM
 constexpr int PA_ND = 256;                        // radix digits = regions (+ unused)
 constexpr u32 NO_REGION = 0xFFFFFFFFu;
 constexpr u32 KT_MAX = 256;                       // per-key tables cached in LDS up to this many keys
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(PA_T) void k_part_scatter(JoinIndexView ix, const u
                                                        u64 *__restrict__ out_se, RowT *__restrict__ out_row, u32 chunk, u32 adj, const u32 *unsorted, int dbg)
 {
     __shared__ u64 r_se[PA_TILE];
-    __shared__ RowT r_row[PA_TILE];
+    __shared__ unsigned short r_slot[PA_TILE];          // the row's slot in the tile (its row id follows from it)
     __shared__ unsigned char r_dig[PA_TILE];
     __shared__ u32 tcnt[256], dstart[256], gbase[256];
     __shared__ u32 scan_lds[PA_T / IVX_WAVE + 1];
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(PA_T) void k_part_scatter(JoinIndexView ix, const u
             if (dig[k] != NO_REGION) {
                 const u32 pos = dstart[dig[k]] + lrank[k];
                 r_se[pos] = se[k];
-                r_row[pos] = (RowT)(t0 - (sizeof(RowT) == 2 ? lo : 0) + ((u64)(k / 4) * PA_T + tid) * 4 + (k % 4));
+                r_slot[pos] = (unsigned short)(((k / 4) * PA_T + tid) * 4 + (k % 4));
                 r_dig[pos] = (unsigned char)dig[k];
             }
         }
@@ -243,8 +244,9 @@ __global__ __launch_bounds__(PA_T) void k_part_scatter(JoinIndexView ix, const u
                 const u32 d = r_dig[j];
                 const u64 g = (u64)gbase[d] + (j - dstart[d]);
                 if (!(dbg & 1)) {
-                    if (dbg & 8) { __builtin_nontemporal_store(r_se[j], &out_se[g]); __builtin_nontemporal_store(r_row[j], &out_row[g]); }
-                    else { out_se[g] = r_se[j]; out_row[g] = r_row[j]; }
+                    const RowT row = (RowT)(t0 - (sizeof(RowT) == 2 ? lo : 0) + r_slot[j]);
+                    if (dbg & 8) { __builtin_nontemporal_store(r_se[j], &out_se[g]); __builtin_nontemporal_store(row, &out_row[g]); }
+                    else { out_se[g] = r_se[j]; out_row[g] = row; }
                 }
             }
         }
@@ -691,7 +693,7 @@ static inline int fill_rows_per_lane(u64 cap, u64 n)
 }
 
 // rows one partition workgroup takes: 1, 2 or 4 tiles, so that mid-size batches still spread over all CUs
-static inline u32 part_chunk(u64 n) { return (u32)PA_TILE * (n >= (16u << 20) ? 4u : n >= (4u << 20) ? 2u : 1u); }
+static inline u32 part_chunk(u64 n, u32 max_tiles = 4) { const u32 t = n >= (16u << 20) ? 4u : n >= (4u << 20) ? 2u : 1u; return (u32)PA_TILE * (t < max_tiles ? t : max_tiles); }
 
 // ------------------------------------------------------------------ values back into input order
 // The scatter wrote, for every (region, workgroup chunk), one contiguous run, and kept each row's index
@@ -699,7 +701,7 @@ static inline u32 part_chunk(u64 n) { return (u32)PA_TILE * (n >= (16u << 20) ? 
 // (each wavefront a contiguous 1/16 of the chunk's values, coalesced inside runs), drop them at their
 // chunk-local index in LDS, write the chunk out in input order.  Rows that were never routed (unknown key,
 // key without build rows) keep the zero LDS was cleared to -- the reference's answer for them.
-constexpr u32 UP_CHUNK = (u32)PA_CHUNK;
+constexpr u32 UP_CHUNK = 2u * PA_TILE;               // the per-row-output path keeps chunks at two tiles (values of a chunk sit in LDS; u16 chunk-local ids)
 
 // OUT: UP_I64 zero-extended (count), UP_I64S sign-extended (coverage), UP_U32 (rle_right; the workgroup's sum
 // goes to *total), UP_U8 (exists = value != 0)
@@ -767,7 +769,7 @@ ivx_status ivx_rowval_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, int k
 {
     if (n == 0) return IVX_OK;
     hipStream_t st = ctx->stream;
-    const u32 chunk = part_chunk(n);
+    const u32 chunk = part_chunk(n, 2);
     const u32 nblk = (u32)((n + chunk - 1) / chunk);
     u32 *hist, *val; u64 *pse; unsigned short *cidx;
     const u64 nh = (u64)256 * nblk + 1;
