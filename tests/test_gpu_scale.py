@@ -123,3 +123,55 @@ def test_merge_subtract_200M_properties(ctx):
     ixc = ctx.build(pyivx.KIND_COUNT, rk, rs, re, n_keys=24)
     hits = ctx.count_overlaps(ixc, fk, fs.to(torch.int32).contiguous(), (fe - 1).to(torch.int32).contiguous())
     assert int(hits.sum()) == 0
+
+
+def test_cluster_complement_100M_properties(ctx):
+    n = 100_000_000
+    k, s, e = synth.gen_torch(n, 20, 24, 0x5EED000A, DEV)       # short intervals: tens of millions of clusters
+    s64, e64 = s.long(), e.long() + 1
+    del s, e
+    torch.cuda.synchronize()
+    c = ctx.cluster(k, s64, e64, n_keys=24)
+    mk, ms, me, mn = ctx.merge(k, s64, e64, n_keys=24)
+    torch.cuda.synchronize()
+    assert c["n_clusters"] == mk.numel() == int(c["cluster"].max()) + 1          # clusters are exactly merge's runs
+    assert bool((c["cluster"][1:] >= c["cluster"][:-1]).all()) and bool(((c["cluster"][1:] - c["cluster"][:-1]) <= 1).all())
+    assert bool((c["cluster_start"] <= c["start"]).all()) and bool((c["end"] <= c["cluster_end"]).all())
+    ids = c["cluster"].long()
+    assert bool((c["cluster_start"] == ms[ids]).all()) and bool((c["cluster_end"] == me[ids]).all())   # each row carries its run's extent
+    assert bool((torch.bincount(ids, minlength=mk.numel()) == mn).all())          # and the runs' sizes agree
+    rows = c["row"].long()
+    assert bool((s64[rows] == c["start"]).all()) and int(torch.bincount(rows, minlength=n).max()) == 1   # a permutation of the input
+    assert int(c["key_clusters"].sum()) == c["n_clusters"]
+    # complement against one view per contig [0, L): gaps and merged runs tile every view exactly
+    lens = torch.tensor(synth.HG38, dtype=torch.int64, device=DEV) + 1000
+    vk = torch.arange(24, dtype=torch.int32, device=DEV)
+    gk, gs, ge = ctx.complement(k, s64, e64, vk, torch.zeros(24, dtype=torch.int64, device=DEV), lens, n_keys=24)
+    torch.cuda.synchronize()
+    assert bool((gs < ge).all())
+    gaps = torch.zeros(24, dtype=torch.int64, device=DEV).index_add_(0, gk.long(), ge - gs)
+    runs = torch.zeros(24, dtype=torch.int64, device=DEV).index_add_(0, mk.long(), me - ms)
+    assert bool((gaps + runs == lens).all())
+    gkey = gk.long() * (1 << 40) + gs
+    assert bool((gkey[1:] > gkey[:-1]).all())                                      # ordered, disjoint
+    # no gap touches an input interval
+    ixc = ctx.build(pyivx.KIND_COUNT, k, s64.to(torch.int32), (e64 - 1).to(torch.int32), n_keys=24)
+    hits = ctx.count_overlaps(ixc, gk, gs.to(torch.int32).contiguous(), (ge - 1).to(torch.int32).contiguous())
+    assert int(hits.sum()) == 0
+
+
+def test_join_100M_sorted_input_same_pairs(ctx):
+    # the in-place path for sorted probe rows against the partitioned path on the same rows shuffled
+    bk, bs, be = synth.gen_torch(1_000_000, 1000, 24, 0x5EED0004, DEV)
+    pk, ps, pe = synth.gen_torch(100_000_000, 150, 24, 0x5EED0005, DEV)
+    ix = ctx.build(pyivx.KIND_OVERLAP, bk, bs, be, n_keys=24)
+    total = ctx.overlap_count(ix, pk, ps, pe)
+    o = torch.argsort(pk.long() * (1 << 32) + ps.long())
+    sk, ss, se = pk[o].contiguous(), ps[o].contiguous(), pe[o].contiguous()
+    assert ctx.overlap_count(ix, sk, ss, se) == total
+    b, p = ctx.overlap_fill(ix, sk, ss, se, cap=total)
+    assert b.numel() == total
+    bl, pl = b.long(), p.long()
+    assert bool(((bs[bl] <= se[pl]) & (be[bl] >= ss[pl]) & (bk[bl] == sk[pl])).all())       # every pair satisfies the predicate
+    per_row = ctx.overlap_count(ix, sk, ss, se, per_row=True)[1]
+    assert bool((torch.bincount(pl, minlength=sk.numel()) == per_row.long()).all())         # and each row has its rle_right pairs
