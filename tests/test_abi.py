@@ -44,3 +44,21 @@ def test_product_path_does_not_touch_oracle():
             if f.endswith((".hip", ".hpp", ".h", ".py", ".cpp")) or f == "Makefile":
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "oracle" not in txt.lower(), os.path.join(dp, f)
+
+
+def test_rust_ffi_declarations_match_the_header():
+    # integration/rust/hip_ffi.rs cannot be compiled here (no Rust toolchain): at least every function it
+    # declares exists in include/ivx.h with the same number of parameters
+    import re
+
+    def sigs(text, pat):
+        out = {}
+        for m in re.finditer(pat, text, re.S):
+            args = re.sub(r"/\*.*?\*/", "", m.group(2), flags=re.S)
+            out[m.group(1)] = 0 if args.strip() in ("", "void") else args.count(",") + 1
+        return out
+
+    hdr = sigs(open(os.path.join(ROOT, "include", "ivx.h")).read(), r"\b(ivx_\w+)\s*\(([^;{]*?)\)\s*;")
+    rust = sigs(open(os.path.join(ROOT, "integration", "rust", "hip_ffi.rs")).read(), r"pub fn (ivx_\w+)\(([^;]*?)\)\s*(?:->\s*[\w\* ]+)?;")
+    assert len(rust) >= 19
+    assert {k: hdr.get(k) for k in rust} == rust
