@@ -177,7 +177,7 @@ __global__ __launch_bounds__(PA_T) void k_part_hist(JoinIndexView ix, const u32 
 // order inside a region is irrelevant (the reference pins only the pair multiset), so the local
 // rank of a row is just the value an LDS counter held when the row arrived
 // RowT = u32: the row's index in the probe batch (join: it goes into the pair list);
-// RowT = u16: its index inside this workgroup's 32768-row chunk (per-row-output operators: k_unpermute
+// RowT = u16: its index inside this workgroup's chunk of at most two tiles (per-row-output operators: k_unpermute
 // puts the chunk back in input order through LDS, so the chunk-local index is all that is needed)
 template <bool VEC, typename RowT>
 __global__ __launch_bounds__(PA_T) void k_part_scatter(JoinIndexView ix, const u32 *__restrict__ pkey, const i32 *__restrict__ ps,
@@ -697,7 +697,7 @@ static inline u32 part_chunk(u64 n, u32 max_tiles = 4) { const u32 t = n >= (16u
 
 // ------------------------------------------------------------------ values back into input order
 // The scatter wrote, for every (region, workgroup chunk), one contiguous run, and kept each row's index
-// inside its 32768-row chunk.  So the values of one chunk are ~200 runs of the value stream: read them
+// inside its chunk (one or two tiles).  So the values of one chunk are ~200 runs of the value stream: read them
 // (each wavefront a contiguous 1/16 of the chunk's values, coalesced inside runs), drop them at their
 // chunk-local index in LDS, write the chunk out in input order.  Rows that were never routed (unknown key,
 // key without build rows) keep the zero LDS was cleared to -- the reference's answer for them.
