@@ -12,6 +12,7 @@
 ivx_status ivx_ctx::get_scratch(int slot, size_t bytes, void **out)
 {
     ivx_buf &b = scratch[slot];
+    if (sub_plan.valid && ((sub_plan.slots >> slot) & 1)) sub_plan.valid = false;
     if (bytes < 256) bytes = 256;
     if (b.cap < bytes) {
         if (b.p) { (void)hipStreamSynchronize(stream); (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
@@ -367,6 +368,7 @@ ivx_status ivx_merge_device(ivx_ctx *ctx, const u32 *key, const i64 *s, const i6
 ivx_status ivx_subtract_device(ivx_ctx *ctx, const u32 *lkey, const i64 *ls, const i64 *le, u64 nl,
                                const u32 *rkey, const i64 *rs, const i64 *re, u64 nr, u32 nkeys, int strict,
                                u32 *ok, i64 *os, i64 *oe, u32 *orow, u64 cap, u64 *n_out);
+ivx_status ivx_subtract_fill_planned(ivx_ctx *ctx, u32 *ok, i64 *os, i64 *oe, u32 *orow, u64 cap, u64 *n_out);
 ivx_status ivx_cluster_device(ivx_ctx *ctx, const u32 *key, const i64 *s, const i64 *e, u64 n, u32 nkeys,
                               i64 min_dist, int strict, const i64 *key_base,
                               u32 *ok, i64 *os, i64 *oe, u32 *orow, i64 *oc, i64 *ocs, i64 *oce, u64 *key_clusters, u64 *m);
@@ -497,13 +499,22 @@ extern "C" ivx_status ivx_subtract(ivx_ctx *ctx, int mem,
     if ((lkey == nullptr) != (rkey == nullptr) && nl && nr) return ctx->fail(IVX_ERR_INVALID, "subtract: key given for one side only");
     if (n_keys == 0 || (!lkey && !rkey)) n_keys = 1;
     IVX_HIP(ctx, hipSetDevice(ctx->device));
-    const u32 *dlk, *drk; const i64 *dls, *dle, *drs, *dre; u32 *ok, *orow; i64 *os, *oe;
-    IVX_TRY(stage_in(ctx, mem, WS_IN_KEY, lkey, nl, &dlk));
-    IVX_TRY(stage_in(ctx, mem, WS_IN_START, lstart, nl, &dls));
-    IVX_TRY(stage_in(ctx, mem, WS_IN_END, lend, nl, &dle));
-    IVX_TRY(stage_in(ctx, mem, WS_IN2_KEY, rkey, nr, &drk));
-    IVX_TRY(stage_in(ctx, mem, WS_IN2_START, rstart, nr, &drs));
-    IVX_TRY(stage_in(ctx, mem, WS_IN2_END, rend, nr, &dre));
+    const u32 *dlk = nullptr, *drk = nullptr; const i64 *dls = nullptr, *dle = nullptr, *drs = nullptr, *dre = nullptr; u32 *ok, *orow; i64 *os, *oe;
+    // a fill call right after the sizing call for the same arguments: the sorted sides, gap heads and output
+    // offsets are still in the context (nothing else ran in between), only the output pass is left
+    const void *in[6] = {lkey, lstart, lend, rkey, rstart, rend};
+    ivx_sub_plan &pl = ctx->sub_plan;
+    const bool sizing = cap == 0 && !out_key && !out_start && !out_end && !out_row;
+    const bool planned = !sizing && nl && pl.valid && pl.mem == mem && memcmp(pl.in, in, sizeof(in)) == 0 && pl.nl == nl && pl.nr == nr &&
+                         pl.nkeys == n_keys && pl.strict == strict && pl.stream == ctx->stream;
+    if (!planned) {
+        IVX_TRY(stage_in(ctx, mem, WS_IN_KEY, lkey, nl, &dlk));
+        IVX_TRY(stage_in(ctx, mem, WS_IN_START, lstart, nl, &dls));
+        IVX_TRY(stage_in(ctx, mem, WS_IN_END, lend, nl, &dle));
+        IVX_TRY(stage_in(ctx, mem, WS_IN2_KEY, rkey, nr, &drk));
+        IVX_TRY(stage_in(ctx, mem, WS_IN2_START, rstart, nr, &drs));
+        IVX_TRY(stage_in(ctx, mem, WS_IN2_END, rend, nr, &dre));
+    }
     IVX_TRY(stage_out(ctx, mem, WS_OUT_A, out_key, cap, &ok));
     IVX_TRY(stage_out(ctx, mem, WS_OUT_B, out_start, cap, &os));
     IVX_TRY(stage_out(ctx, mem, WS_OUT_C, out_end, cap, &oe));
@@ -511,9 +522,11 @@ extern "C" ivx_status ivx_subtract(ivx_ctx *ctx, int mem,
     u64 m = 0;
     {
         KernelTimer t(ctx);
-        ivx_status st = ivx_subtract_device(ctx, dlk, dls, dle, nl, drk, drs, dre, nr, n_keys, strict, ok, os, oe, orow, cap, &m);
+        ivx_status st = planned ? ivx_subtract_fill_planned(ctx, ok, os, oe, orow, cap, &m)
+                                            : ivx_subtract_device(ctx, dlk, dls, dle, nl, drk, drs, dre, nr, n_keys, strict, ok, os, oe, orow, cap, &m);
         *n_out = m;
         if (st != IVX_OK) return st;
+        if (sizing && pl.valid) { memcpy(pl.in, in, sizeof(in)); pl.mem = mem; }
     }
     if (cap) {
         IVX_TRY(copy_out(ctx, mem, out_key, ok, m));

@@ -19,6 +19,24 @@ struct ivx_buf { void *p = nullptr; size_t cap = 0; };
 
 enum { IVX_NSCRATCH = 56, IVX_NPIN = 4 };
 
+// What a subtract sizing call leaves behind for the fill call that follows it: the sorted sides, the right
+// side's running max / gap heads and the scanned per-row output counts all sit in scratch slots (`slots` =
+// bit per slot); touching any of them drops the plan.
+struct ivx_sub_plan {
+    bool valid = false;
+    u64 slots = 0;
+    int mem = 0;
+    const void *in[6] = {};             // the caller's six input columns
+    u64 nl = 0, nr = 0, nh = 0, total = 0;
+    u32 nkeys = 0;
+    int strict = 0;
+    hipStream_t stream = nullptr;
+    const u32 *lk, *lrow, *rk, *hk, *hj;
+    const i64 *lsv, *lev, *rsv, *hrs, *hpm;
+    const void *sm;
+    const u64 *offs;
+};
+
 struct ivx_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -30,6 +48,7 @@ struct ivx_ctx {
     ivx_buf pinned[IVX_NPIN];           // grow-only pinned host staging
     u64 *d_scalars = nullptr;           // 64 device words for counters / totals
     u64 *h_scalars = nullptr;           // pinned mirror
+    ivx_sub_plan sub_plan;
 
     ivx_status fail(ivx_status st, const std::string &msg) { err = msg; return st; }
     ivx_status fail_hip(const char *what, hipError_t e)

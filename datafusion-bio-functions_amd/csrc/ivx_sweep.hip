@@ -229,42 +229,66 @@ __device__ __forceinline__ u32 lex_rank(const u32 *__restrict__ kk, const i64 *_
     return lo;
 }
 
-// first j of key k whose running max of right ends is >= x (le=false) / > x (le=true); end of the key if none
-__device__ __forceinline__ u32 pm_rank(const u32 *__restrict__ kk, const SegMax64 *__restrict__ sm, u32 n, u32 k, i64 x, bool le)
+// ---- partition points with a hint.  `before(i)` is monotone (true for i < answer).
+template <class Before>
+__device__ __forceinline__ u32 bisect(u32 lo, u32 hi, Before before)
 {
-    u32 lo = 0, hi = n;
-    while (lo < hi) {
-        const u32 mid = lo + ((hi - lo) >> 1);
-        const u32 mk = kk[mid];
-        bool before;
-        if (mk != k) before = mk < k;
-        else { const i64 mv = sm[mid].v; before = le ? (mv <= x) : (mv < x); }
-        if (before) lo = mid + 1; else hi = mid;
-    }
+    while (lo < hi) { const u32 mid = lo + ((hi - lo) >> 1); if (before(mid)) lo = mid + 1; else hi = mid; }
     return lo;
 }
 
-__device__ __forceinline__ u32 lower_bound_u32(const u32 *__restrict__ a, u32 n, u32 x)
+// answer expected at or a few elements after `start`: gallop upwards (1, 2, 4, ...), then bisect the last
+// stride -- a handful of steps instead of log2(n).  If the answer lies before `start` after all, bisect [0,start).
+template <class Before>
+__device__ __forceinline__ u32 rank_near_up(u32 start, u32 n, Before before)
 {
-    u32 lo = 0, hi = n;
-    while (lo < hi) { const u32 mid = lo + ((hi - lo) >> 1); if (a[mid] < x) lo = mid + 1; else hi = mid; }
-    return lo;
+    if (start > n) start = n;
+    if (start > 0 && !before(start - 1)) return bisect(0u, start - 1, before);
+    u32 lo = start, hi = start, step = 1;
+    while (hi < n && before(hi)) { lo = hi + 1; hi = (n - hi > step) ? hi + step : n; step <<= 1; }
+    return bisect(lo, hi, before);
+}
+
+// answer expected at or a few elements before `start`
+template <class Before>
+__device__ __forceinline__ u32 rank_near_down(u32 start, u32 n, Before before)
+{
+    if (start > n) start = n;
+    if (start < n && before(start)) return bisect(start + 1, n, before);
+    u32 lo = start, hi = start, step = 1;
+    while (lo > 0 && !before(lo - 1)) { hi = lo - 1; lo = lo > step ? lo - step : 0; step <<= 1; }
+    return bisect(lo, hi, before);
 }
 
 struct SubPlan { u32 h_lo, h_hi; i64 tail_from; u32 has_tail; };
 
+// One left row [ls,le) of key k against the rights of that key (sorted by start; sm = running max of their
+// ends; heads = rights that start a new gap).  Two of the five partition points are real searches; the
+// other three sit next to them (the row's end is a few rights after its start), so they gallop from there.
 __device__ __forceinline__ SubPlan plan_row(u32 k, i64 ls, i64 le, int strict,
                                             const u32 *hk, const i64 *hrs, const u32 *hj, u32 nh,
                                             const u32 *rk, const i64 *rs, const SegMax64 *sm, u32 nr)
 {
     SubPlan p;
-    p.h_lo = lex_rank(hk, hrs, nh, k, ls, true);                       // heads with rs <= ls never emit
-    const u32 rc = pm_rank(rk, sm, nr, k, ls, strict != 0);            // right_cursor (subtract.rs:401-412)
-    const u32 hc = lower_bound_u32(hj, nh, rc);                        // heads behind the cursor are skipped
-    if (hc > p.h_lo) p.h_lo = hc;
-    p.h_hi = lex_rank(hk, hrs, nh, k, le, !strict);                    // rs <= le (strict: rs < le)
+    const bool incl = !strict;
+    const u32 h_ls = lex_rank(hk, hrs, nh, k, ls, true);               // heads with rs <= ls never emit
+    // right_cursor (subtract.rs:401-412): first right whose running max end reaches ls.  Everything before the
+    // last head at or below ls ends below that head's start, so the search starts there; it normally ends
+    // before the next head (checked, not assumed: rights with end < start break it)
+    const bool pm_le = strict != 0;
+    auto pm_before = [&](u32 i) { const u32 mk = rk[i]; if (mk != k) return mk < k; const i64 mv = sm[i].v; return pm_le ? (mv <= ls) : (mv < ls); };
+    const u32 rc_lo = h_ls > 0 ? hj[h_ls - 1] : 0u;
+    u32 rc_hi = h_ls < nh ? hj[h_ls] : nr;
+    if (rc_hi < nr && pm_before(rc_hi)) rc_hi = nr;
+    const u32 rc = bisect(rc_lo, rc_hi, pm_before);
+    // heads behind the cursor are skipped: first head at or after it, at or just before h_ls
+    const u32 hc = rank_near_down(h_ls, nh, [&](u32 i) { return hj[i] < rc; });
+    p.h_lo = hc > h_ls ? hc : h_ls;
+    // heads with rs <= le (strict: rs < le)
+    p.h_hi = rank_near_up(h_ls, nh, [&](u32 i) { const u32 mk = hk[i]; if (mk != k) return mk < k; const i64 mv = hrs[i]; return incl ? (mv <= le) : (mv < le); });
     if (p.h_hi < p.h_lo) p.h_hi = p.h_lo;
-    const u32 jhi = lex_rank(rk, rs, nr, k, le, !strict);              // rights visited by the walk
+    // rights visited by the walk: rs <= le (strict: <); they begin at the cursor
+    const u32 jhi = rank_near_up(rc, nr, [&](u32 i) { const u32 mk = rk[i]; if (mk != k) return mk < k; const i64 mv = rs[i]; return incl ? (mv <= le) : (mv < le); });
     i64 cursor = ls;
     if (jhi > 0 && rk[jhi - 1] == k) { const i64 pm = sm[jhi - 1].v; if (pm > cursor) cursor = pm; }
     p.tail_from = cursor;
@@ -498,6 +522,8 @@ ivx_status ivx_merge_device(ivx_ctx *ctx, const u32 *key, const i64 *s, const i6
     return keyflag(ctx, "merge: key id >= n_keys");
 }
 
+ivx_status ivx_subtract_fill_planned(ivx_ctx *ctx, u32 *ok, i64 *os, i64 *oe, u32 *orow, u64 cap, u64 *n_out);
+
 ivx_status ivx_subtract_device(ivx_ctx *ctx, const u32 *lkey, const i64 *ls, const i64 *le, u64 nl,
                                const u32 *rkey, const i64 *rs, const i64 *re, u64 nr, u32 nkeys, int strict,
                                u32 *ok, i64 *os, i64 *oe, u32 *orow, u64 cap, u64 *n_out)
@@ -550,11 +576,28 @@ ivx_status ivx_subtract_device(ivx_ctx *ctx, const u32 *lkey, const i64 *ls, con
     IVX_HIP(ctx, hipStreamSynchronize(st));
     const u64 total = ctx->h_scalars[5];
     *n_out = total;
-    if (cap == 0 && !ok && !os && !oe && !orow) return IVX_OK;          // count only
-    if (total > cap) return ctx->fail(IVX_ERR_CAPACITY, "subtract: output buffers too small");
-    hipLaunchKernelGGL(k_sub_fill, dim3(grid1(nl)), dim3(ST), 0, st, (const u32 *)lk, (const i64 *)lsv, (const i64 *)lev, (const u32 *)lrow, nl, strict,
-                       (const u32 *)hk, (const i64 *)hrs, (const i64 *)hpm, (const u32 *)hj, (u32)nh, (const u32 *)rk, (const i64 *)rsv, (const SegMax64 *)sm, (u32)nr,
-                       (const u64 *)cnt, cap, ok, os, oe, orow);
+    ivx_sub_plan &pl = ctx->sub_plan;
+    pl.nl = nl; pl.nr = nr; pl.nh = nh; pl.total = total; pl.nkeys = nkeys; pl.strict = strict; pl.stream = st;
+    pl.lk = lk; pl.lsv = lsv; pl.lev = lev; pl.lrow = lrow; pl.rk = rk; pl.rsv = rsv; pl.sm = sm;
+    pl.hk = hk; pl.hrs = hrs; pl.hpm = hpm; pl.hj = hj; pl.offs = cnt;
+    if (cap == 0 && !ok && !os && !oe && !orow) {                       // count only: the fill call that follows reuses all of it
+        pl.slots = 0;
+        for (int slot : {WS_T0, WS_T1, WS_T2, WS_T3, WS_T4, WS_T5, WS_T7, WS_T9, WS_RA0, WS_RA1, WS_RA2, WS_RB0}) pl.slots |= 1ull << slot;
+        pl.valid = true;
+        return IVX_OK;
+    }
+    return ivx_subtract_fill_planned(ctx, ok, os, oe, orow, cap, n_out);
+}
+
+// the output pass alone, from the plan a sizing call (or the lines above) left in the context
+ivx_status ivx_subtract_fill_planned(ivx_ctx *ctx, u32 *ok, i64 *os, i64 *oe, u32 *orow, u64 cap, u64 *n_out)
+{
+    const ivx_sub_plan &pl = ctx->sub_plan;
+    *n_out = pl.total;
+    if (pl.total > cap) return ctx->fail(IVX_ERR_CAPACITY, "subtract: output buffers too small");
+    hipLaunchKernelGGL(k_sub_fill, dim3(grid1(pl.nl)), dim3(ST), 0, ctx->stream, pl.lk, pl.lsv, pl.lev, pl.lrow, pl.nl, pl.strict,
+                       pl.hk, pl.hrs, pl.hpm, pl.hj, (u32)pl.nh, pl.rk, pl.rsv, (const SegMax64 *)pl.sm, (u32)pl.nr,
+                       pl.offs, cap, ok, os, oe, orow);
     IVX_HIP(ctx, hipGetLastError());
     return IVX_OK;
 }

@@ -276,7 +276,9 @@ class Ctx:
         m = m.value
         return ok[:m], os_[:m], oe[:m], on[:m]
 
-    def subtract(self, lkey, ls, le, rkey, rs, re, n_keys=None, strict=False):
+    def subtract(self, lkey, ls, le, rkey, rs, re, n_keys=None, strict=False, cap=None, between=None):
+        """cap=None: sizing call, then the fill call (which reuses the sizing call's sorted sides).  cap=N: one call into
+        buffers of N rows.  between: callable run between the two calls (tests)."""
         lkey, ls, le, nl, mem = _cols(lkey, ls, le, np.int64)
         rkey, rs, re, nr, mem2 = _cols(rkey, rs, re, np.int64)
         assert mem == mem2
@@ -296,9 +298,12 @@ class Ctx:
                         torch.empty(cap, dtype=torch.int64, device=dev), torch.empty(cap, dtype=torch.int32, device=dev))
             return np.empty(cap, np.uint32), np.empty(cap, np.int64), np.empty(cap, np.int64), np.empty(cap, np.uint32)
         # sizing call (counting half only), then the fill call: the fragment count has no useful a-priori bound
-        m = C.c_uint64(0)
-        self._chk(lib().ivx_subtract(self.h, *args, None, None, None, None, C.c_uint64(0), C.byref(m)))
-        cap = max(m.value, 1)
+        if cap is None:
+            m = C.c_uint64(0)
+            self._chk(lib().ivx_subtract(self.h, *args, None, None, None, None, C.c_uint64(0), C.byref(m)))
+            cap = max(m.value, 1)
+            if between is not None:
+                between()
         ok, os_, oe, orow = bufs(cap)
         m2 = C.c_uint64(0)
         self._chk(lib().ivx_subtract(self.h, *args, _ptr(ok), _ptr(os_), _ptr(oe), _ptr(orow), C.c_uint64(cap), C.byref(m2)))

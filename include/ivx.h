@@ -169,7 +169,13 @@ ivx_status ivx_merge(ivx_ctx *ctx, int mem,
 /* ---- a7+a9: SubtractStream / SubtractStreamExtra sweep
  *      (subtract.rs:390-462, :575-655).  out_row (nullable) = the left input row
  *      of each fragment (for the extra-columns `take`).  Passing cap = 0 with
- *      NULL outputs only counts. */
+ *      NULL outputs only counts (the sizing call).  The sizing call leaves its
+ *      sorted sides and per-row output offsets in the context: a fill call with
+ *      the same input pointers, sizes, n_keys, strict and stream that is the next
+ *      sort/sweep call on that context runs the output pass only -- the six input
+ *      columns must not change between the two calls (the size would be stale
+ *      anyway).  Any other call on the context drops that state; a fill call then
+ *      (or one made without a sizing call) does all the work itself. */
 ivx_status ivx_subtract(ivx_ctx *ctx, int mem,
                         const uint32_t *lkey, const int64_t *lstart, const int64_t *lend, uint64_t nl,
                         const uint32_t *rkey, const int64_t *rstart, const int64_t *rend, uint64_t nr,

@@ -285,6 +285,38 @@ def test_subtract_random(ctx, seed):
             assert len(g) == len(w) and (g == w).all()
 
 
+@pytest.mark.parametrize("device", [False, True])
+def test_subtract_sizing_then_fill_plan(ctx, device):
+    """The fill call that follows a sizing call reuses the sizing call's sorted sides; a one-call fill and a
+    fill after some other operation touched the context must give the same rows."""
+    lk, ls, le = synth(50_000, 181, nkeys=5, mean_len=1500, span=1_000_000, dtype=np.int64)
+    rk, rs, re = synth(70_000, 191, nkeys=6, mean_len=300, span=1_000_000, dtype=np.int64)
+    le += 1; re += 1
+    want = orc.subtract(lk, ls, le, rk, rs, re, strict=False)
+    if device:
+        import torch
+        cols = [torch.from_numpy(a.view(np.int32) if a.dtype == np.uint32 else a).cuda() for a in (lk, ls, le, rk, rs, re)]
+    else:
+        cols = [lk, ls, le, rk, rs, re]
+    host = lambda a: a.cpu().numpy() if device else a
+
+    def other_op():                                        # reuses the sort / temp scratch of the plan
+        ctx.merge(rk, rs, re, n_keys=6)
+        ctx.subtract(rk, rs, re, lk, ls, le, n_keys=6)     # another subtract, sizing + fill
+
+    for kw in ({}, {"cap": len(want[0]) + 7}, {"between": other_op}):
+        got = ctx.subtract(*cols, n_keys=6, **kw)
+        for g, w in zip(got, want):
+            g = host(g)
+            assert len(g) == len(w) and (g.view(w.dtype) == w).all(), kw.keys()
+    # the plan of a sizing call must not serve a fill call with other arguments (strict differs)
+    ctx.subtract(*cols, n_keys=6)
+    got = ctx.subtract(*cols, n_keys=6, strict=True, cap=2 * len(want[0]) + len(lk) + 7)
+    for g, w in zip(got, orc.subtract(lk, ls, le, rk, rs, re, strict=True)):
+        g = host(g)
+        assert len(g) == len(w) and (g.view(w.dtype) == w).all()
+
+
 def test_subtract_empty_sides(ctx):
     e64 = np.empty(0, np.int64); ek = np.empty(0, np.uint32)
     lk = np.zeros(3, np.uint32); ls = np.array([1, 5, 9], np.int64); le = np.array([3, 8, 20], np.int64)
