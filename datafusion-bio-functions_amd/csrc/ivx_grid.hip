@@ -16,7 +16,7 @@ __global__ void k_init_keystats(i32 *kmin, i32 *kmax, u32 *kcnt, u32 nkeys)
 
 // per-key min / max of v and row counts, privatised in LDS; key ids >= nkeys raise *errflag
 __global__ __launch_bounds__(GT) void k_keystats(const u32 *__restrict__ key, const i32 *__restrict__ v, u64 n,
-                                                 u32 nkeys, i32 *kmin, i32 *kmax, u32 *kcnt, u32 *errflag)
+                                                 u32 nkeys, i32 *kmin, i32 *kmax, u32 *kcnt, u32 *errflag, u32 vs)
 {
     extern __shared__ i32 sh[];
     const bool priv = nkeys <= KEYS_IN_LDS;
@@ -29,7 +29,7 @@ __global__ __launch_bounds__(GT) void k_keystats(const u32 *__restrict__ key, co
     for (u64 i = (u64)blockIdx.x * GT + threadIdx.x; i < n; i += (u64)gridDim.x * GT) {
         const u32 k = key ? key[i] : 0u;
         if (k >= nkeys) { *errflag = 1; continue; }
-        const i32 x = v[i];
+        const i32 x = v[i * vs];
         if (priv) { atomicMin(&smin[k], x); atomicMax(&smax[k], x); atomicAdd(&scnt[k], 1u); }
         else { atomicMin(&kmin[k], x); atomicMax(&kmax[k], x); atomicAdd(&kcnt[k], 1u); }
     }
@@ -111,17 +111,17 @@ __global__ __launch_bounds__(GT) void k_grid_scatter(const u32 *__restrict__ key
 // element of every non-empty cell c leaves its end index at E[c+1]; an inclusive max-scan turns E into
 // binstart (an empty cell inherits the end of the last non-empty cell before it).
 __global__ __launch_bounds__(GT) void k_grid_bounds(const u32 *__restrict__ key, const i32 *__restrict__ v, u64 n, u32 nkeys,
-                                                    const i32 *origin, const u32 *kbase, const u32 *hdr, u32 *E)
+                                                    const i32 *origin, const u32 *kbase, const u32 *hdr, u32 *E, u32 vs)
 {
     const u32 sh = hdr[0];
     for (u64 i = (u64)blockIdx.x * GT + threadIdx.x; i < n; i += (u64)gridDim.x * GT) {
         const u32 k = key ? key[i] : 0u;
         if (k >= nkeys) continue;
-        const u32 c = kbase[k] + ((u32)((i64)v[i] - (i64)origin[k]) >> sh);
+        const u32 c = kbase[k] + ((u32)((i64)v[i * vs] - (i64)origin[k]) >> sh);
         bool last = i + 1 == n;
         if (!last) {
             const u32 k2 = key ? key[i + 1] : 0u;
-            last = k2 != k || k2 >= nkeys || kbase[k2] + ((u32)((i64)v[i + 1] - (i64)origin[k2]) >> sh) != c;
+            last = k2 != k || k2 >= nkeys || kbase[k2] + ((u32)((i64)v[(i + 1) * vs] - (i64)origin[k2]) >> sh) != c;
         }
         if (last) E[c + 1] = (u32)(i + 1);
     }
@@ -139,19 +139,26 @@ struct MaxU32Op {
 ivx_status ivx_keystats(ivx_ctx *ctx, const u32 *key, const i32 *v, u64 n, u32 nkeys,
                         i32 *kmin, i32 *kmax, u32 *kcnt, u32 *errflag)
 {
+    return ivx_keystats(ctx, key, v, n, nkeys, kmin, kmax, kcnt, errflag, 1u);
+}
+
+ivx_status ivx_keystats(ivx_ctx *ctx, const u32 *key, const i32 *v, u64 n, u32 nkeys,
+                        i32 *kmin, i32 *kmax, u32 *kcnt, u32 *errflag, u32 vstride)
+{
     hipStream_t st = ctx->stream;
     hipLaunchKernelGGL(k_init_keystats, dim3((nkeys + GT - 1) / GT), dim3(GT), 0, st, kmin, kmax, kcnt, nkeys);
     if (n) {
         const u32 grid = ivx_stream_grid(n, GT * 8, 1024);
         const size_t shm = nkeys <= KEYS_IN_LDS ? (size_t)nkeys * 12 : 0;
-        hipLaunchKernelGGL(k_keystats, dim3(grid), dim3(GT), shm, st, key, v, n, nkeys, kmin, kmax, kcnt, errflag);
+        hipLaunchKernelGGL(k_keystats, dim3(grid), dim3(GT), shm, st, key, v, n, nkeys, kmin, kmax, kcnt, errflag, vstride);
     }
     IVX_HIP(ctx, hipGetLastError());
     return IVX_OK;
 }
 
-ivx_status ivx_grid_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32 *v, u64 n, u32 nkeys, RankGridView *out, bool sorted)
+ivx_status ivx_grid_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32 *v, u64 n, u32 nkeys, RankGridView *out, bool sorted, u32 vstride)
 {
+    if (!sorted && vstride != 1) return ctx->fail(IVX_ERR_INVALID, "grid: strided values need a sorted column");
     hipStream_t st = ctx->stream;
     const u64 maxcells = 2 * n + nkeys + 64;
     if (maxcells + 1 >= 0xFFFFFFFFull) return ctx->fail(IVX_ERR_INVALID, "column too large for 32-bit cell ids");
@@ -172,11 +179,11 @@ ivx_status ivx_grid_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32
     u32 *errflag = (u32 *)(ctx->d_scalars + 8);
     IVX_HIP(ctx, hipMemsetAsync(binstart, 0, (maxcells + 1) * sizeof(u32), st));
     if (!sorted) IVX_HIP(ctx, hipMemsetAsync(cursor, 0, (maxcells + 1) * sizeof(u32), st));
-    IVX_TRY(ivx_keystats(ctx, key, v, n, nkeys, kmin, kmax, kcnt, errflag));
+    IVX_TRY(ivx_keystats(ctx, key, v, n, nkeys, kmin, kmax, kcnt, errflag, vstride));
     hipLaunchKernelGGL(k_grid_layout, dim3(1), dim3(1024), 0, st, kmin, kmax, kcnt, nkeys, n, origin, span, koff, kbase, hdr);
     if (n && sorted) {
         const u32 grid = ivx_stream_grid(n, GT * 8, 2048);
-        hipLaunchKernelGGL(k_grid_bounds, dim3(grid), dim3(GT), 0, st, key, v, n, nkeys, origin, kbase, hdr, binstart);
+        hipLaunchKernelGGL(k_grid_bounds, dim3(grid), dim3(GT), 0, st, key, v, n, nkeys, origin, kbase, hdr, binstart, vstride);
         IVX_TRY(ivxscan::inclusive<MaxU32Op>(ctx, binstart, maxcells + 1));
     } else if (n) {
         const u32 grid = ivx_stream_grid(n, GT * 8, 1024);

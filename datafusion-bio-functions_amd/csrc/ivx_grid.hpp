@@ -11,7 +11,9 @@
 #pragma once
 #include "ivx_device.hpp"
 
-// position (in the grouped order, across keys) of the first value of key k that is > x
+// position (in the grouped order, across keys) of the first value of key k that is > x.
+// VS = distance between consecutive values in 32-bit words (values that live inside records)
+template <int VS = 1>
 __device__ __forceinline__ u32 grid_rank_le(const RankGridView &g, u32 sh, u32 k, i32 x)
 {
     const u32 cnt = g.kcnt[k];
@@ -23,15 +25,16 @@ __device__ __forceinline__ u32 grid_rank_le(const RankGridView &g, u32 sh, u32 k
     const u32 c = g.kbase[k] + (u32)(d >> sh);
     const u32 a = g.binstart[c], b = g.binstart[c + 1];
     u32 r = a;
-    for (u32 j = a; j < b; j++) r += g.val[j] <= x ? 1u : 0u;
+    for (u32 j = a; j < b; j++) r += g.val[(u64)j * VS] <= x ? 1u : 0u;
     return r;
 }
 
 // #{v < x}: partition_point(|v| v < x)
+template <int VS = 1>
 __device__ __forceinline__ u32 grid_rank_lt(const RankGridView &g, u32 sh, u32 k, i32 x)
 {
     if (x == INT32_MIN) return g.koff[k];
-    return grid_rank_le(g, sh, k, x - 1);
+    return grid_rank_le<VS>(g, sh, k, x - 1);
 }
 
 // host side (ivx_grid.hip)
@@ -40,5 +43,9 @@ ivx_status ivx_keystats(ivx_ctx *ctx, const u32 *key, const i32 *v, u64 n, u32 n
 // Build a rank grid over (key[i], v[i]), i < n.  Index memory is owned by ix.
 // kcnt_hint: per-key row counts are recomputed; key may be NULL (single key).
 // sorted = the rows come grouped by ascending key with non-decreasing v inside a key AND v is index memory
-// that outlives the grid: no atomics, no copy of the values.
-ivx_status ivx_grid_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32 *v, u64 n, u32 nkeys, RankGridView *out, bool sorted = false);
+// that outlives the grid: no atomics, no copy of the values.  vstride (sorted only) = words between
+// consecutive values; probe such a grid with grid_rank_le<vstride>.
+ivx_status ivx_grid_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32 *v, u64 n, u32 nkeys, RankGridView *out, bool sorted = false,
+                          u32 vstride = 1);
+ivx_status ivx_keystats(ivx_ctx *ctx, const u32 *key, const i32 *v, u64 n, u32 nkeys,
+                        i32 *kmin, i32 *kmax, u32 *kcnt, u32 *errflag, u32 vstride);

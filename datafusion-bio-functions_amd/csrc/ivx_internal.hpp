@@ -139,11 +139,14 @@ struct CoverageView {
     const i32 *nfirst, *nlast;  // [m] merged nodes in order
 };
 
+// one build row of the nearest index, 16 bytes so that a candidate is ONE load: in by_start order
+// a = start, b = end, pmax = running max of end within the key; in by_end order a = end, b = start
+struct ivx_nrec { i32 a, b; u32 row; i32 pmax; };
+
 struct NearestView {
-    RankGridView by_start, by_end, pmax;   // rank grids over start / end / prefix-max-end orders
-    const i32 *s_start, *s_end; const u32 *s_row;   // by_start order (start,end,row)
-    const i32 *e_start, *e_end; const u32 *e_row;   // by_end order (end,start,row)
-    const i32 *pmaxv;                               // prefix max of end in by_start order
+    RankGridView by_start, by_end, pmax;   // rank grids over rs[].a / re[].a / rs[].pmax (value stride 4 words)
+    const ivx_nrec *rs;                    // by_start order (start,end,row)
+    const ivx_nrec *re;                    // by_end order (end,start,row)
     JoinIndexView ov;                               // overlap index for k>1 include_overlaps
 };
 

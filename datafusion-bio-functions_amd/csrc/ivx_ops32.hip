@@ -148,28 +148,32 @@ __global__ __launch_bounds__(OT) void k_probe_coverage(CoverageView cv, const u3
 
 // ======================================================================= a6
 
+// sort words of a build row: w0 = (start,end) in unsigned order, start major; w1 = (key, row)
 __global__ __launch_bounds__(OT) void k_pack_se(const u32 *__restrict__ key, const i32 *__restrict__ s, const i32 *__restrict__ e,
-                                                u64 n, u32 nkeys, int end_major, u64 *w0, u64 *w1, u32 *flags)
+                                                u64 n, u32 nkeys, u64 *w0, u64 *w1, u32 *flags)
 {
     const u64 i = (u64)blockIdx.x * OT + threadIdx.x;
     if (i >= n) return;
     const u32 k = key ? key[i] : 0u;
     if (k >= nkeys) flags[0] = 1;
     const u64 sb = (u32)s[i] ^ SIGN, eb = (u32)e[i] ^ SIGN;
-    w0[i] = end_major ? ((eb << 32) | sb) : ((sb << 32) | eb);
+    w0[i] = (sb << 32) | eb;
     w1[i] = ((u64)k << 32) | (u32)i;
 }
 
-__global__ __launch_bounds__(OT) void k_unpack_se(const u64 *__restrict__ w0, const u64 *__restrict__ w1, u64 n, int end_major,
-                                                  u32 *ks, i32 *ss, i32 *es, u32 *rows)
+// sorted words -> records {major, minor, row} (+ the key column).  y0/y1 (nullable): the same rows re-packed
+// with the halves of w0 swapped, i.e. ready for the end-major sort
+__global__ __launch_bounds__(OT) void k_unpack_rec(const u64 *__restrict__ w0, const u64 *__restrict__ w1, u64 n,
+                                                   u32 *ks, ivx_nrec *rec, u64 *y0, u64 *y1)
 {
     const u64 i = (u64)blockIdx.x * OT + threadIdx.x;
     if (i >= n) return;
-    const i32 hi = (i32)((u32)(w0[i] >> 32) ^ SIGN), lo = (i32)((u32)w0[i] ^ SIGN);
-    ks[i] = (u32)(w1[i] >> 32);
-    rows[i] = (u32)w1[i];
-    ss[i] = end_major ? lo : hi;
-    es[i] = end_major ? hi : lo;
+    const u64 a = w0[i], b = w1[i];
+    ivx_nrec r;
+    r.a = (i32)((u32)(a >> 32) ^ SIGN); r.b = (i32)((u32)a ^ SIGN); r.row = (u32)b; r.pmax = 0;
+    rec[i] = r;
+    if (ks) ks[i] = (u32)(b >> 32);
+    if (y0) { y0[i] = (a << 32) | (a >> 32); y1[i] = b; }
 }
 
 struct SegMax { i32 v; u32 head; };
@@ -186,17 +190,17 @@ struct SegMaxOp {
     }
 };
 
-__global__ __launch_bounds__(OT) void k_segmax_in(const u32 *__restrict__ ks, const i32 *__restrict__ es, u64 n, SegMax *sm)
+__global__ __launch_bounds__(OT) void k_segmax_in(const u32 *__restrict__ ks, const ivx_nrec *__restrict__ rs, u64 n, SegMax *sm)
 {
     const u64 i = (u64)blockIdx.x * OT + threadIdx.x;
     if (i >= n) return;
-    SegMax t; t.v = es[i]; t.head = (i == 0 || ks[i] != ks[i - 1]) ? 1u : 0u;
+    SegMax t; t.v = rs[i].b; t.head = (i == 0 || ks[i] != ks[i - 1]) ? 1u : 0u;
     sm[i] = t;
 }
-__global__ __launch_bounds__(OT) void k_segmax_out(const SegMax *__restrict__ sm, u64 n, i32 *pmax)
+__global__ __launch_bounds__(OT) void k_segmax_out(const SegMax *__restrict__ sm, u64 n, ivx_nrec *rs)
 {
     const u64 i = (u64)blockIdx.x * OT + threadIdx.x;
-    if (i < n) pmax[i] = sm[i].v;
+    if (i < n) rs[i].pmax = sm[i].v;
 }
 
 struct Cand { i32 s, e; u32 row; };
@@ -222,18 +226,19 @@ __device__ __forceinline__ int cmp_cand(i32 qs, i32 qe, const Cand &a, const Can
 
 struct NearestCtx {
     NearestView nv; u32 sh_s, sh_e, sh_p;
-    __device__ __forceinline__ Cand by_start(u32 j) const { Cand c; c.s = nv.s_start[j]; c.e = nv.s_end[j]; c.row = nv.s_row[j]; return c; }
-    __device__ __forceinline__ Cand by_end(u32 j) const { Cand c; c.s = nv.e_start[j]; c.e = nv.e_end[j]; c.row = nv.e_row[j]; return c; }
+    // one 16-byte load per candidate
+    __device__ __forceinline__ Cand by_start(u32 j) const { const ivx_nrec r = nv.rs[j]; Cand c; c.s = r.a; c.e = r.b; c.row = r.row; return c; }
+    __device__ __forceinline__ Cand by_end(u32 j) const { const ivx_nrec r = nv.re[j]; Cand c; c.s = r.b; c.e = r.a; c.row = r.row; return c; }
 };
 
 // nearest_index.rs:222-234; positions are absolute (key offset included)
 __device__ __forceinline__ bool first_overlap(const NearestCtx &x, u32 k, u32 off, i32 qs, i32 qe, u32 *plen_abs, Cand *out)
 {
-    const u32 pend = grid_rank_le(x.nv.by_start, x.sh_s, k, qe);     // by_start.partition_point(first <= end)
+    const u32 pend = grid_rank_le<4>(x.nv.by_start, x.sh_s, k, qe);  // by_start.partition_point(first <= end)
     *plen_abs = pend;
     if (qe < qs) return false;
-    if (pend == off || x.nv.pmaxv[pend - 1] < qs) return false;
-    u32 idx = grid_rank_lt(x.nv.pmax, x.sh_p, k, qs);                 // prefix_max_end[..plen].partition_point(< start)
+    if (pend == off || x.nv.rs[pend - 1].pmax < qs) return false;
+    u32 idx = grid_rank_lt<4>(x.nv.pmax, x.sh_p, k, qs);              // prefix_max_end[..plen].partition_point(< start)
     if (idx > pend) idx = pend;
     *out = x.by_start(idx);
     return true;
@@ -255,9 +260,9 @@ __global__ __launch_bounds__(OT) void k_probe_nearest1(NearestView nv, const u32
             const u32 off = nv.by_start.koff[k], cnt = nv.by_start.kcnt[k];
             u32 pend;
             if (include_overlaps) found = first_overlap(x, k, off, qs, qe, &pend, &best);
-            else pend = grid_rank_le(nv.by_start, x.sh_s, k, qe);
+            else pend = grid_rank_le<4>(nv.by_start, x.sh_s, k, qe);
             if (!found) {                                                // nearest_non_overlap_one :192-220
-                const u32 li = grid_rank_lt(nv.by_end, x.sh_e, k, qs);   // by_end.partition_point(last < start)
+                const u32 li = grid_rank_lt<4>(nv.by_end, x.sh_e, k, qs);   // by_end.partition_point(last < start)
                 const bool hl = li > off, hr = pend < off + cnt;
                 if (hl && hr) {
                     const Cand l = x.by_end(li - 1), r = x.by_start(pend);
@@ -286,17 +291,19 @@ __global__ __launch_bounds__(OT) void k_probe_nearestk(NearestView nv, const u32
         u32 found = 0;
         if (k < nv.by_start.nkeys && nv.by_start.kcnt[k] != 0) {
             const u32 off = nv.by_start.koff[k], cnt_k = nv.by_start.kcnt[k];
-            const u32 pend = grid_rank_le(nv.by_start, x.sh_s, k, qe);
+            const u32 pend = grid_rank_le<4>(nv.by_start, x.sh_s, k, qe);
             // seen-set of nearest_k (:122, :134, :186): rows already taken
-            auto seen = [&](u32 row) { for (u32 q = 0; q < found; q++) { const u32 t = mine[q]; const u32 r = (t >> 31) ? nv.e_row[t & 0x7FFFFFFFu] : nv.s_row[t]; if (r == row) return true; } return false; };
-            if (include_overlaps && pend > off && nv.pmaxv[pend - 1] >= qs) {
+            auto seen = [&](u32 row) { for (u32 q = 0; q < found; q++) { const u32 t = mine[q]; const u32 r = (t >> 31) ? nv.re[t & 0x7FFFFFFFu].row : nv.rs[t].row; if (r == row) return true; } return false; };
+            if (include_overlaps && pend > off && nv.rs[pend - 1].pmax >= qs) {
                 // all overlaps in (start,end,row) order = by_start order filtered by end >= qs (:125-137)
-                u32 j = grid_rank_lt(nv.pmax, x.sh_p, k, qs);
-                for (; j < pend && found < kk; j++)
-                    if (nv.s_end[j] >= qs && !seen(nv.s_row[j])) mine[found++] = j;
+                u32 j = grid_rank_lt<4>(nv.pmax, x.sh_p, k, qs);
+                for (; j < pend && found < kk; j++) {
+                    const ivx_nrec r = nv.rs[j];
+                    if (r.b >= qs && !seen(r.row)) mine[found++] = j;
+                }
             }
             if (found < kk) {                                            // alternate the two cursors (:144-189)
-                u32 li = grid_rank_lt(nv.by_end, x.sh_e, k, qs), ri = pend;
+                u32 li = grid_rank_lt<4>(nv.by_end, x.sh_e, k, qs), ri = pend;
                 while (found < kk) {
                     const bool hl = li > off, hr = ri < off + cnt_k;
                     if (!hl && !hr) break;
@@ -338,8 +345,9 @@ __global__ __launch_bounds__(OT) void k_nearest_emit(NearestView nv, const i32 *
             const u32 t = tmp[i * (u64)kk + q];
             const u32 j = t & 0x7FFFFFFFu;
             const bool e = t >> 31;
-            const i32 s_ = e ? nv.e_start[j] : nv.s_start[j], e_ = e ? nv.e_end[j] : nv.s_end[j];
-            ob[at] = e ? nv.e_row[j] : nv.s_row[j];
+            const ivx_nrec r = e ? nv.re[j] : nv.rs[j];
+            const i32 s_ = e ? r.b : r.a, e_ = e ? r.a : r.b;
+            ob[at] = r.row;
             op[at] = (u32)i;
             if (od) od[at] = cand_dist(ps[i], pe[i], s_, e_);
         }
@@ -348,9 +356,12 @@ __global__ __launch_bounds__(OT) void k_nearest_emit(NearestView nv, const i32 *
 
 u32 grid1(u64 n) { return (u32)((n + OT - 1) / OT); }
 
-// sorted (key, start, end, row) columns from raw ones; end_major: order by (key,end,start,row)
-ivx_status sorted_columns(ivx_ctx *ctx, const u32 *key, const i32 *s, const i32 *e, u64 n, u32 nkeys, int end_major,
-                          u32 *ks, i32 *ss, i32 *es, u32 *rows)
+// The two orders of the nearest index as records: rs by (key,start,end,row) (nearest_index.rs:50-55), re by
+// (key,end,start,row) (:77-82), ks = the key column (the same in both orders).  The second order is a STABLE
+// sort of the first by (key,end) alone -- ties keep their (start,row) order -- which is 5 digit passes
+// instead of 9 for human-genome coordinates.
+ivx_status nearest_sorted_records(ivx_ctx *ctx, const u32 *key, const i32 *s, const i32 *e, u64 n, u32 nkeys,
+                                  u32 *ks, ivx_nrec *rs, ivx_nrec *re)
 {
     if (n == 0) return IVX_OK;
     u64 *a[2], *b[2];
@@ -359,12 +370,17 @@ ivx_status sorted_columns(ivx_ctx *ctx, const u32 *key, const i32 *s, const i32 
     IVX_TRY(ctx->get_scratch(WS_SB0, n * sizeof(u64), (void **)&b[0]));
     IVX_TRY(ctx->get_scratch(WS_SB1, n * sizeof(u64), (void **)&b[1]));
     u32 *flags = (u32 *)(ctx->d_scalars + 8);
-    hipLaunchKernelGGL(k_pack_se, dim3(grid1(n)), dim3(OT), 0, ctx->stream, key, s, e, n, nkeys, end_major, a[0], a[1], flags);
+    hipLaunchKernelGGL(k_pack_se, dim3(grid1(n)), dim3(OT), 0, ctx->stream, key, s, e, n, nkeys, a[0], a[1], flags);
     const ivx_sort_field f[3] = {{0, 0, 32}, {0, 32, 64}, {1, 32, 64}};
     int in_b = 0;
     IVX_TRY(ivx_radix_sort(ctx, 2, a, b, n, f, 3, &in_b));
-    u64 *const *r = in_b ? b : a;
-    hipLaunchKernelGGL(k_unpack_se, dim3(grid1(n)), dim3(OT), 0, ctx->stream, (const u64 *)r[0], (const u64 *)r[1], n, end_major, ks, ss, es, rows);
+    u64 *const *r = in_b ? b : a, *const *y = in_b ? a : b;
+    hipLaunchKernelGGL(k_unpack_rec, dim3(grid1(n)), dim3(OT), 0, ctx->stream, (const u64 *)r[0], (const u64 *)r[1], n, ks, rs, y[0], y[1]);
+    const ivx_sort_field g[2] = {{0, 32, 64}, {1, 32, 64}};
+    IVX_TRY(ivx_radix_sort(ctx, 2, y, r, n, g, 2, &in_b));
+    u64 *const *r2 = in_b ? r : y;
+    hipLaunchKernelGGL(k_unpack_rec, dim3(grid1(n)), dim3(OT), 0, ctx->stream, (const u64 *)r2[0], (const u64 *)r2[1], n, (u32 *)nullptr, re,
+                       (u64 *)nullptr, (u64 *)nullptr);
     IVX_HIP(ctx, hipGetLastError());
     return IVX_OK;
 }
@@ -447,30 +463,23 @@ ivx_status ivx_nearest_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const 
     const u32 nkeys = ix->nkeys;
     IVX_HIP(ctx, hipMemsetAsync(ctx->d_scalars + 8, 0, sizeof(u64), st));
     const u64 na = n ? n : 1;
-    i32 *s_start, *s_end, *e_start, *e_end, *pmaxv; u32 *s_row, *e_row, *ks, *ke;
-    IVX_TRY(ivx_index_alloc(ctx, ix, na * 4, (void **)&s_start));
-    IVX_TRY(ivx_index_alloc(ctx, ix, na * 4, (void **)&s_end));
-    IVX_TRY(ivx_index_alloc(ctx, ix, na * 4, (void **)&s_row));
-    IVX_TRY(ivx_index_alloc(ctx, ix, na * 4, (void **)&e_start));
-    IVX_TRY(ivx_index_alloc(ctx, ix, na * 4, (void **)&e_end));
-    IVX_TRY(ivx_index_alloc(ctx, ix, na * 4, (void **)&e_row));
-    IVX_TRY(ivx_index_alloc(ctx, ix, na * 4, (void **)&pmaxv));
+    ivx_nrec *rs, *re; u32 *ks;
+    IVX_TRY(ivx_index_alloc(ctx, ix, na * sizeof(ivx_nrec), (void **)&rs));
+    IVX_TRY(ivx_index_alloc(ctx, ix, na * sizeof(ivx_nrec), (void **)&re));
     IVX_TRY(ctx->get_scratch(WS_T0, na * 4, (void **)&ks));
-    IVX_TRY(ctx->get_scratch(WS_T1, na * 4, (void **)&ke));
-    IVX_TRY(sorted_columns(ctx, key, s, e, n, nkeys, 0, ks, s_start, s_end, s_row));   // (start,end,row)  nearest_index.rs:50-55
-    IVX_TRY(sorted_columns(ctx, key, s, e, n, nkeys, 1, ke, e_start, e_end, e_row));   // (end,start,row)  :77-82
+    IVX_TRY(nearest_sorted_records(ctx, key, s, e, n, nkeys, ks, rs, re));
     if (n) {
         SegMax *sm;
         IVX_TRY(ctx->get_scratch(WS_T2, n * sizeof(SegMax), (void **)&sm));
-        hipLaunchKernelGGL(k_segmax_in, dim3(grid1(n)), dim3(OT), 0, st, (const u32 *)ks, (const i32 *)s_end, n, sm);
+        hipLaunchKernelGGL(k_segmax_in, dim3(grid1(n)), dim3(OT), 0, st, (const u32 *)ks, (const ivx_nrec *)rs, n, sm);
         IVX_TRY(ivxscan::inclusive<SegMaxOp>(ctx, sm, n));                               // prefix_max_end :58-63
-        hipLaunchKernelGGL(k_segmax_out, dim3(grid1(n)), dim3(OT), 0, st, (const SegMax *)sm, n, pmaxv);
+        hipLaunchKernelGGL(k_segmax_out, dim3(grid1(n)), dim3(OT), 0, st, (const SegMax *)sm, n, rs);
     }
-    IVX_TRY(ivx_grid_build(ctx, ix, ks, s_start, n, nkeys, &ix->nv.by_start, true));   // sorted columns, prefix max: all ascending per key
-    IVX_TRY(ivx_grid_build(ctx, ix, ke, e_end, n, nkeys, &ix->nv.by_end, true));
-    IVX_TRY(ivx_grid_build(ctx, ix, ks, pmaxv, n, nkeys, &ix->nv.pmax, true));
-    ix->nv.s_start = s_start; ix->nv.s_end = s_end; ix->nv.s_row = s_row;
-    ix->nv.e_start = e_start; ix->nv.e_end = e_end; ix->nv.e_row = e_row; ix->nv.pmaxv = pmaxv;
+    // the records' fields are the grids' value arrays (stride 4 words): sorted columns, prefix max: all ascending per key
+    IVX_TRY(ivx_grid_build(ctx, ix, ks, &rs->a, n, nkeys, &ix->nv.by_start, true, 4));
+    IVX_TRY(ivx_grid_build(ctx, ix, ks, &re->a, n, nkeys, &ix->nv.by_end, true, 4));
+    IVX_TRY(ivx_grid_build(ctx, ix, ks, &rs->pmax, n, nkeys, &ix->nv.pmax, true, 4));
+    ix->nv.rs = rs; ix->nv.re = re;
     IVX_HIP(ctx, hipGetLastError());
     return check_keyflag(ctx);
 }

@@ -298,7 +298,11 @@ def test_subtract_sizing_then_fill_plan(ctx, device):
         cols = [torch.from_numpy(a.view(np.int32) if a.dtype == np.uint32 else a).cuda() for a in (lk, ls, le, rk, rs, re)]
     else:
         cols = [lk, ls, le, rk, rs, re]
-    host = lambda a: a.cpu().numpy() if device else a
+    def host(a):
+        if not device:
+            return a
+        ctx.synchronize()                                  # device-memory calls are asynchronous on the context's stream
+        return a.cpu().numpy()
 
     def other_op():                                        # reuses the sort / temp scratch of the plan
         ctx.merge(rk, rs, re, n_keys=6)
