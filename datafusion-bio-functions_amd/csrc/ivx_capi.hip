@@ -3,6 +3,7 @@
 // scratch management.  All arithmetic happens in the HIP kernels.
 #include "ivx_internal.hpp"
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -13,6 +14,7 @@ ivx_status ivx_ctx::get_scratch(int slot, size_t bytes, void **out)
 {
     ivx_buf &b = scratch[slot];
     if (sub_plan.valid && ((sub_plan.slots >> slot) & 1)) sub_plan.valid = false;
+    if (join_plan.valid && ((join_plan.slots >> slot) & 1)) join_plan.valid = false;
     if (bytes < 256) bytes = 256;
     if (b.cap < bytes) {
         if (b.p) { (void)hipStreamSynchronize(stream); (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
@@ -254,6 +256,8 @@ extern "C" ivx_status ivx_index_build(ivx_ctx *ctx, int kind, int mem, const uin
     if (kind == IVX_KIND_NEAREST && n >= 0x80000000ull) return ctx->fail(IVX_ERR_INVALID, "nearest index: more than 2^31-1 rows");
     IVX_HIP(ctx, hipSetDevice(ctx->device));
     ivx_index *ix = new (std::nothrow) ivx_index();
+    static std::atomic<u64> next_serial{1};
+    if (ix) ix->serial = next_serial.fetch_add(1);
     if (!ix) return ctx->fail(IVX_ERR_OOM, "host allocation failed");
     ix->kind = kind; ix->device = ctx->device; ix->n = n; ix->nkeys = n_keys;
     const u32 *dk; const i32 *ds, *de;
@@ -294,10 +298,29 @@ static ivx_status overlap_common(ivx_ctx *ctx, const ivx_index *ix, int mem, int
                                  u32 *per_row, u8 *exists, u32 *bidx, u32 *pidx, u64 cap, u64 *total)
 {
     IVX_TRY(check_probe_args(ctx, ix, IVX_KIND_OVERLAP, mem, start, end, n));
-    const u32 *dk; const i32 *ds, *de;
-    IVX_TRY(stage_in(ctx, mem, WS_IN_KEY, key, n, &dk));
-    IVX_TRY(stage_in(ctx, mem, WS_IN_START, start, n, &ds));
-    IVX_TRY(stage_in(ctx, mem, WS_IN_END, end, n, &de));
+    const u32 *dk = nullptr; const i32 *ds = nullptr, *de = nullptr;
+    // large COUNT/FILL batches: partition the probe rows by index region and probe from LDS;
+    // small batches and the per-row modes gather straight from the index
+    bool regions = ix->jv_nreg > 0 && (mode == JP_COUNT || mode == JP_FILL) && n >= (1u << 21);   // measured crossover (tools/crossover.py)
+    // the per-row modes (rle_right, semi / anti) of big batches: same partition, one value per row, un-permuted
+    bool rowval = ix->jv_nreg > 0 && ix->jv_nreg <= IVX_MAXREG && (mode == JP_PER_ROW || mode == JP_EXISTS) && n >= (1u << 21);
+    if (const char *f = getenv("IVX_JOIN_PATH")) {
+        if (!strcmp(f, "direct")) regions = rowval = false;
+        else if (!strcmp(f, "regions")) {
+            regions = ix->jv_nreg > 0 && (mode == JP_COUNT || mode == JP_FILL);
+            rowval = ix->jv_nreg > 0 && ix->jv_nreg <= IVX_MAXREG && (mode == JP_PER_ROW || mode == JP_EXISTS);
+        }
+    }
+    // a fill call right after the count call that sized it: the routed probe rows are still in the context
+    const void *in[3] = {key, start, end};
+    ivx_join_plan &pl = ctx->join_plan;
+    const bool planned = regions && mode == JP_FILL && pl.valid && pl.mem == mem && memcmp(pl.in, in, sizeof(in)) == 0 && pl.n == n &&
+                         pl.ix == (const void *)ix && pl.ix_serial == ix->serial && pl.stream == ctx->stream;
+    if (!planned) {
+        IVX_TRY(stage_in(ctx, mem, WS_IN_KEY, key, n, &dk));
+        IVX_TRY(stage_in(ctx, mem, WS_IN_START, start, n, &ds));
+        IVX_TRY(stage_in(ctx, mem, WS_IN_END, end, n, &de));
+    }
     u32 *d_row = nullptr, *d_b = nullptr, *d_p = nullptr; u8 *d_ex = nullptr;
     IVX_TRY(stage_out(ctx, mem, WS_OUT_A, per_row, n, &d_row));
     IVX_TRY(stage_out(ctx, mem, WS_OUT_B, exists, n, &d_ex));
@@ -305,21 +328,11 @@ static ivx_status overlap_common(ivx_ctx *ctx, const ivx_index *ix, int mem, int
     IVX_TRY(stage_out(ctx, mem, WS_OUT_D, pidx, cap, &d_p));
     IVX_HIP(ctx, hipMemsetAsync(ctx->d_scalars, 0, sizeof(u64), ctx->stream));
     {
-        // large COUNT/FILL batches: partition the probe rows by index region and probe from LDS;
-        // small batches and the per-row modes gather straight from the index
-        bool regions = ix->jv_nreg > 0 && (mode == JP_COUNT || mode == JP_FILL) && n >= (1u << 21);   // measured crossover (tools/crossover.py)
-        if (const char *f = getenv("IVX_JOIN_PATH")) {
-            if (!strcmp(f, "direct")) regions = false;
-            else if (!strcmp(f, "regions")) regions = ix->jv_nreg > 0 && (mode == JP_COUNT || mode == JP_FILL);
-        }
-        // the per-row modes (rle_right, semi / anti) of big batches: same partition, one value per row, un-permuted
-        bool rowval = ix->jv_nreg > 0 && ix->jv_nreg <= IVX_MAXREG && (mode == JP_PER_ROW || mode == JP_EXISTS) && n >= (1u << 21);
-        if (const char *f = getenv("IVX_JOIN_PATH")) {
-            if (!strcmp(f, "direct")) rowval = false;
-            else if (!strcmp(f, "regions")) rowval = ix->jv_nreg > 0 && ix->jv_nreg <= IVX_MAXREG && (mode == JP_PER_ROW || mode == JP_EXISTS);
-        }
         KernelTimer t(ctx);
-        if (regions) IVX_TRY(ivx_join_probe_regions(ctx, ix->jv, ix->jv_nreg, mode, dk, ds, de, n, d_b, d_p, cap, ctx->d_scalars));
+        if (regions) {
+            IVX_TRY(ivx_join_probe_regions(ctx, ix->jv, ix->jv_nreg, mode, dk, ds, de, n, d_b, d_p, cap, ctx->d_scalars, planned));
+            if (mode == JP_COUNT && pl.valid) { memcpy(pl.in, in, sizeof(in)); pl.mem = mem; pl.n = n; pl.ix = ix; pl.ix_serial = ix->serial; pl.stream = ctx->stream; }
+        }
         else if (rowval) IVX_TRY(ivx_rowval_probe_regions(ctx, ix->jv, mode == JP_PER_ROW ? IVX_RV_PER_ROW : IVX_RV_EXISTS, dk, ds, de, n, 0,
                                                           mode == JP_PER_ROW ? (void *)d_row : (void *)d_ex, ctx->d_scalars));
         else IVX_TRY(ivx_join_probe(ctx, ix->jv, mode, dk, ds, de, n, d_row, d_ex, d_b, d_p, cap, ctx->d_scalars));

@@ -37,6 +37,22 @@ struct ivx_sub_plan {
     const u64 *offs;
 };
 
+// What a region-partitioned overlap COUNT call leaves behind for the fill call that follows it: the probe
+// rows routed to their regions (tile histogram, partitioned (start,end) and row ids) -- the fill call for
+// the same index, columns and stream goes straight to its probe kernel.
+struct ivx_join_plan {
+    bool valid = false;
+    u64 slots = 0;
+    int mem = 0;
+    const void *in[3] = {};
+    u64 n = 0;
+    const void *ix = nullptr; u64 ix_serial = 0;
+    hipStream_t stream = nullptr;
+    const u32 *hist = nullptr; const u64 *pse = nullptr; const u32 *prow = nullptr;
+    const i32 *ds = nullptr, *de = nullptr;     // device copies of the start / end columns (read in place when the rows were in region order)
+    u32 chunk = 0, nblk = 0;
+};
+
 struct ivx_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -49,6 +65,7 @@ struct ivx_ctx {
     u64 *d_scalars = nullptr;           // 64 device words for counters / totals
     u64 *h_scalars = nullptr;           // pinned mirror
     ivx_sub_plan sub_plan;
+    ivx_join_plan join_plan;
 
     ivx_status fail(ivx_status st, const std::string &msg) { err = msg; return st; }
     ivx_status fail_hip(const char *what, hipError_t e)
@@ -151,6 +168,7 @@ struct NearestView {
 };
 
 struct ivx_index {
+    u64 serial = 0;             // unique per built index (a freed index's address may come back)
     int kind = 0;
     int device = 0;
     u64 n = 0;
@@ -181,7 +199,7 @@ enum { JP_COUNT = 0, JP_PER_ROW = 1, JP_EXISTS = 2, JP_FILL = 3 };
 // join_regions.hip: partition the probe rows by index region, probe each region from LDS
 ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nreg, int mode,
                                   const u32 *key, const i32 *s, const i32 *e, u64 n,
-                                  u32 *ob, u32 *op, u64 cap, u64 *d_cursor);
+                                  u32 *ob, u32 *op, u64 cap, u64 *d_cursor, bool planned = false);
 
 // per-row-output operators through the same partition (count_overlaps: jv over the build rows, no row with
 // end < start; coverage: jv over the merged nodes)

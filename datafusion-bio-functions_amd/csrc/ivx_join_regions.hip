@@ -873,32 +873,49 @@ ivx_status probe_wide(ivx_ctx *ctx, const JoinIndexView &jv, int mode, u32 nreg,
 
 ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nreg, int mode,
                                   const u32 *key, const i32 *s, const i32 *e, u64 n,
-                                  u32 *ob, u32 *op, u64 cap, u64 *d_cursor)
+                                  u32 *ob, u32 *op, u64 cap, u64 *d_cursor, bool planned)
 {
     if (n == 0) return IVX_OK;
-    if (nreg > IVX_MAXREG) return probe_wide(ctx, jv, mode, nreg, key, s, e, n, ob, op, cap, d_cursor);
+    ivx_join_plan &pl = ctx->join_plan;
+    if (nreg > IVX_MAXREG) {
+        if (planned) return ctx->fail(IVX_ERR_INVALID, "join plan for a two-digit region table");   // never recorded
+        return probe_wide(ctx, jv, mode, nreg, key, s, e, n, ob, op, cap, d_cursor);
+    }
     hipStream_t st = ctx->stream;
-    const u32 chunk = part_chunk(n);
-    const u32 nblk = (u32)((n + chunk - 1) / chunk);
-    u32 *hist; u64 *pse; u32 *prow;
-    const u64 nh = (u64)256 * nblk + 1;
-    IVX_TRY(ctx->get_scratch(WS_SORTHIST, nh * sizeof(u32), (void **)&hist));
-    IVX_TRY(ctx->get_scratch(WS_T0, n * sizeof(u64), (void **)&pse));
-    IVX_TRY(ctx->get_scratch(WS_T1, n * sizeof(u32), (void **)&prow));
-    IVX_HIP(ctx, hipMemsetAsync(hist + (nh - 1), 0, sizeof(u32), st));
 #ifdef IVX_ABLATE          // profiling builds only (tools/variant.sh <name> -DIVX_ABLATE; tools/ablate.sh): IVX_DBG bit switches
     const int dbg = getenv("IVX_DBG") ? atoi(getenv("IVX_DBG")) : 0;
 #else
     const int dbg = 0;
 #endif
-    const bool vec = (((uintptr_t)key | (uintptr_t)s | (uintptr_t)e) & 15) == 0;
     u32 *unsorted = (u32 *)(ctx->d_scalars + 10);                       // stays 0 if the rows already come in region order
-    IVX_HIP(ctx, hipMemsetAsync(unsorted, 0, sizeof(u32), st));
-    if (vec) hipLaunchKernelGGL(k_part_hist<true>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, n, nblk, chunk, hist, 0u, unsorted);
-    else hipLaunchKernelGGL(k_part_hist<false>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, n, nblk, chunk, hist, 0u, unsorted);
-    IVX_TRY(ivx_scan_exclusive_u32(ctx, hist, nh));
-    if (vec) hipLaunchKernelGGL((k_part_scatter<true, u32>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, prow, chunk, 0u, (const u32 *)unsorted, dbg);
-    else hipLaunchKernelGGL((k_part_scatter<false, u32>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, prow, chunk, 0u, (const u32 *)unsorted, dbg);
+    u32 chunk, nblk; u32 *hist; u64 *pse; u32 *prow;
+    if (planned) {
+        // the count call that sized this fill call routed the rows already (and left `unsorted` as it is)
+        chunk = pl.chunk; nblk = pl.nblk;
+        hist = const_cast<u32 *>(pl.hist); pse = const_cast<u64 *>(pl.pse); prow = const_cast<u32 *>(pl.prow);
+        s = pl.ds; e = pl.de;
+    } else {
+        chunk = part_chunk(n);
+        nblk = (u32)((n + chunk - 1) / chunk);
+        const u64 nh = (u64)256 * nblk + 1;
+        IVX_TRY(ctx->get_scratch(WS_SORTHIST, nh * sizeof(u32), (void **)&hist));
+        IVX_TRY(ctx->get_scratch(WS_T0, n * sizeof(u64), (void **)&pse));
+        IVX_TRY(ctx->get_scratch(WS_T1, n * sizeof(u32), (void **)&prow));
+        IVX_HIP(ctx, hipMemsetAsync(hist + (nh - 1), 0, sizeof(u32), st));
+        const bool vec = (((uintptr_t)key | (uintptr_t)s | (uintptr_t)e) & 15) == 0;
+        IVX_HIP(ctx, hipMemsetAsync(unsorted, 0, sizeof(u32), st));
+        if (vec) hipLaunchKernelGGL(k_part_hist<true>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, n, nblk, chunk, hist, 0u, unsorted);
+        else hipLaunchKernelGGL(k_part_hist<false>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, n, nblk, chunk, hist, 0u, unsorted);
+        IVX_TRY(ivx_scan_exclusive_u32(ctx, hist, nh));
+        if (vec) hipLaunchKernelGGL((k_part_scatter<true, u32>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, prow, chunk, 0u, (const u32 *)unsorted, dbg);
+        else hipLaunchKernelGGL((k_part_scatter<false, u32>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, prow, chunk, 0u, (const u32 *)unsorted, dbg);
+        if (mode == JP_COUNT) {
+            // leave the routed rows for the fill call (ivx_capi.hip fills in whose columns they are)
+            pl.hist = hist; pl.pse = pse; pl.prow = prow; pl.ds = s; pl.de = e; pl.chunk = chunk; pl.nblk = nblk;
+            pl.slots = (1ull << WS_SORTHIST) | (1ull << WS_T0) | (1ull << WS_T1) | (1ull << WS_IN_START) | (1ull << WS_IN_END);
+            pl.valid = true;
+        }
+    }
     unsigned long long *cur = (unsigned long long *)d_cursor;
     if (mode == JP_FILL) {   // single walk: pairs staged per wavefront, one output reservation per workgroup and round
         // rows per lane and batch by the expected matches per row (cap / n: callers size the output from the

@@ -121,7 +121,13 @@ ivx_status ivx_probe_overlap_count(ivx_ctx *ctx, const ivx_index *ix, int mem,
  *       nothing useful is written, *written = pairs needed and the call
  *       returns IVX_ERR_CAPACITY.  cap also serves as the hint for the expected
  *       pairs per row (cap / n): size it from ivx_probe_overlap_count, not with
- *       a blanket maximum, or large batches run with needlessly small rounds. */
+ *       a blanket maximum, or large batches run with needlessly small rounds.
+ *       A total-only count call (per_row = NULL) of a large batch leaves the
+ *       probe rows routed to the index regions (and, for IVX_MEM_HOST, copied to
+ *       the device) in the context: the fill call for the same index, column
+ *       pointers, n and stream that is the next call on that context skips that
+ *       work -- the three columns must not change between the two calls.  Any
+ *       other call drops that state and the fill call does everything itself. */
 ivx_status ivx_probe_overlap_fill(ivx_ctx *ctx, const ivx_index *ix, int mem,
                                   const uint32_t *key, const int32_t *start, const int32_t *end, uint64_t n,
                                   uint32_t *build_idx, uint32_t *probe_idx, uint64_t cap, uint64_t *written);

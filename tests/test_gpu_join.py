@@ -240,3 +240,59 @@ def test_join_sorted_probe_input_skips_the_scatter(ctx):
     _check_join(ctx, bk, bs, be, pk2, ps2, pe2, 5)
     pk3 = pk.copy(); pk3[-7:] = 9                            # trailing rows of a key the build side does not have
     _check_join(ctx, bk, bs, be, pk3, ps, pe, 5)
+
+
+@pytest.mark.parametrize("device", [False, True])
+def test_join_count_then_fill_reuses_the_routed_rows(ctx, device):
+    """A fill call right after the count call that sized it skips the partition (ivx_join_plan).  It must not
+    do so after anything else ran on the context, for other columns, or for another index."""
+    bk, bs, be = synth(60_000, 301, nkeys=4, mean_len=800, span=8_000_000)
+    bk2, bs2, be2 = synth(50_000, 302, nkeys=4, mean_len=300, span=8_000_000)
+    pk, ps, pe = synth(300_000, 303, nkeys=5, mean_len=150, span=8_000_000)
+    qk, qs, qe = _sorted_by_key_start(*synth(250_000, 304, nkeys=4, mean_len=150, span=8_000_000))
+    want = {}
+    for name, (b, p) in {"ap": ((bk, bs, be), (pk, ps, pe)), "aq": ((bk, bs, be), (qk, qs, qe)),
+                         "bp": ((bk2, bs2, be2), (pk, ps, pe))}.items():
+        wb, wp = orc.join(*b, *p, threads=4)
+        want[name] = pair_set(wb, wp)
+    if device:
+        import torch
+        dev = lambda *a: [torch.from_numpy(x.view(np.int32) if x.dtype == np.uint32 else x).cuda() for x in a]
+        P, Q = dev(pk, ps, pe), dev(qk, qs, qe)
+    else:
+        P, Q = (pk, ps, pe), (qk, qs, qe)
+
+    def pairs(ob, op):
+        if device:
+            ctx.synchronize()
+            ob, op = ob.cpu().numpy().view(np.uint32), op.cpu().numpy().view(np.uint32)
+        return pair_set(ob, op)
+
+    os.environ["IVX_JOIN_PATH"] = "regions"
+    try:
+        ix = ctx.build(pyivx.KIND_OVERLAP, bk, bs, be, n_keys=5)
+        n_ap, n_aq = len(want["ap"]), len(want["aq"])
+        # fill with no count call before it (another operation ran last)
+        ctx.merge(bk, bs.astype(np.int64), be.astype(np.int64), n_keys=5)
+        assert (pairs(*ctx.overlap_fill(ix, *P, cap=n_ap + 5)) == want["ap"]).all()
+        # count, then fill: the planned path; unsorted and sorted (read in place) probe rows
+        for cols, key in ((P, "ap"), (Q, "aq")):
+            assert ctx.overlap_count(ix, *cols) == len(want[key])
+            assert (pairs(*ctx.overlap_fill(ix, *cols, cap=len(want[key]))) == want[key]).all(), key
+            assert (pairs(*ctx.overlap_fill(ix, *cols, cap=len(want[key]))) == want[key]).all(), key   # a second fill
+        # the plan belongs to the LAST count call
+        assert ctx.overlap_count(ix, *P) == n_ap
+        assert ctx.overlap_count(ix, *Q) == n_aq
+        assert (pairs(*ctx.overlap_fill(ix, *P, cap=n_ap)) == want["ap"]).all()
+        # something else in between drops it
+        assert ctx.overlap_count(ix, *P) == n_ap
+        ctx.exists(ix, *Q)
+        assert (pairs(*ctx.overlap_fill(ix, *P, cap=n_ap)) == want["ap"]).all()
+        # another index, same probe columns
+        assert ctx.overlap_count(ix, *P) == n_ap
+        ix.free()
+        ix = ctx.build(pyivx.KIND_OVERLAP, bk2, bs2, be2, n_keys=5)
+        assert (pairs(*ctx.overlap_fill(ix, *P, cap=len(want["bp"]) + 3)) == want["bp"]).all()
+        ix.free()
+    finally:
+        del os.environ["IVX_JOIN_PATH"]
