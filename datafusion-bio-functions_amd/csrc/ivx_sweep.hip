@@ -22,6 +22,7 @@
 // whatever came before.  The gap heads form a sorted array and each left row owns
 // a contiguous slice of it.  (For well-formed rights the cursor bound is implied
 // by rs_j > ls; it matters only when a right row has end < start.)
+#include <cstdlib>
 #include "ivx_runs.hpp"
 #include "ivx_scan.hpp"
 #include "ivx_sort.hpp"
@@ -59,19 +60,25 @@ __global__ __launch_bounds__(ST) void k_unpack64(const u64 *__restrict__ w0, con
 // ---- packed variant: when (key, start - min start, end - min end) fit 64 bits together -- genomic
 // coordinates always do -- the sort key is ONE word and the record 16 bytes instead of 24, with fewer
 // radix digits in total
-struct Range64 { long long min_s, max_s, min_e, max_e; };
+struct Range64 { long long min_s, max_s, min_e, max_e; unsigned long long unsorted; };   // unsorted: some row sorts before its predecessor
 
 __global__ __launch_bounds__(ST) void k_range64(const u32 *__restrict__ key, const i64 *__restrict__ s, const i64 *__restrict__ e,
                                                 u64 n, u32 nkeys, Range64 *out, u32 *flags)
 {
     __shared__ i64 red[4][ST / IVX_WAVE];
     i64 lo_s = INT64_MAX, hi_s = INT64_MIN, lo_e = INT64_MAX, hi_e = INT64_MIN;
-    bool bad = false;
+    bool bad = false, inv = false;
     for (u64 i = (u64)blockIdx.x * ST + threadIdx.x; i < n; i += (u64)gridDim.x * ST) {
         const i64 a = s[i], b = e[i];
         lo_s = a < lo_s ? a : lo_s; hi_s = a > hi_s ? a : hi_s;
         lo_e = b < lo_e ? b : lo_e; hi_e = b > hi_e ? b : hi_e;
-        bad |= key && key[i] >= nkeys;
+        const u32 k = key ? key[i] : 0u;
+        bad |= k >= nkeys;
+        if (i) {                                                        // (key,start,end) below the row before it?
+            const u32 pk = key ? key[i - 1] : 0u;
+            const i64 pa = s[i - 1], pb = e[i - 1];
+            inv |= k != pk ? k < pk : (a != pa ? a < pa : b < pb);
+        }
     }
 #pragma unroll
     for (int d = IVX_WAVE / 2; d > 0; d >>= 1) {
@@ -84,6 +91,7 @@ __global__ __launch_bounds__(ST) void k_range64(const u32 *__restrict__ key, con
     const u32 wv = threadIdx.x / IVX_WAVE;
     if (lane_id() == 0) { red[0][wv] = lo_s; red[1][wv] = hi_s; red[2][wv] = lo_e; red[3][wv] = hi_e; }
     if (bad) flags[0] = 1;
+    if (inv) out->unsorted = 1;
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < ST / IVX_WAVE; w++) {
@@ -122,6 +130,16 @@ __global__ __launch_bounds__(ST) void k_unpack1(const u64 *__restrict__ w0, cons
     if (rows) rows[i] = (u32)w1[i];
 }
 
+// rows that already are in (key,start,end) order: the sorted columns are the input columns, row ids 0..n-1
+__global__ __launch_bounds__(ST) void k_copy_sorted(const u32 *__restrict__ key, const i64 *__restrict__ s, const i64 *__restrict__ e, u64 n,
+                                                    u32 *ks, i64 *ss, i64 *es, u32 *rows)
+{
+    const u64 i = (u64)blockIdx.x * ST + threadIdx.x;
+    if (i >= n) return;
+    ks[i] = key ? key[i] : 0u; ss[i] = s[i]; es[i] = e[i];
+    if (rows) rows[i] = (u32)i;
+}
+
 u32 bits_of(u64 x) { u32 b = 0; while (x) { b++; x >>= 1; } return b; }
 
 // sort (key,start,end,row) ascending; rows of equal (key,start,end) keep input order = ascending row
@@ -132,13 +150,20 @@ ivx_status sort64(ivx_ctx *ctx, int slot_a, int slot_b, const u32 *key, const i6
     hipStream_t st = ctx->stream;
     u32 *flags = (u32 *)(ctx->d_scalars + 8);
     Range64 *d_rng = (Range64 *)(ctx->d_scalars + 24);
-    Range64 *h_init = (Range64 *)(ctx->h_scalars + 28);                   // pinned, so the async copy may read it later
-    *h_init = Range64{INT64_MAX, INT64_MIN, INT64_MAX, INT64_MIN};
+    Range64 *h_init = (Range64 *)(ctx->h_scalars + 48);                   // pinned, so the async copy may read it later
+    *h_init = Range64{INT64_MAX, INT64_MIN, INT64_MAX, INT64_MIN, 0ull};
     IVX_HIP(ctx, hipMemcpyAsync(d_rng, h_init, sizeof(Range64), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_range64, dim3(ivx_stream_grid(n, ST * 8, 2048)), dim3(ST), 0, st, key, s, e, n, nkeys, d_rng, flags);
     IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 24, d_rng, sizeof(Range64), hipMemcpyDeviceToHost, st));
     IVX_HIP(ctx, hipStreamSynchronize(st));
     const Range64 r = *(const Range64 *)(ctx->h_scalars + 24);
+    if (!r.unsorted && !getenv("IVX_FORCE_SORT")) {
+        // coordinate-sorted input (the usual state of BED / VCF / BAM-derived tables): nothing to sort, and equal
+        // rows already are in ascending row order
+        hipLaunchKernelGGL(k_copy_sorted, dim3(grid1(n)), dim3(ST), 0, st, key, s, e, n, ks, ss, es, rows);
+        IVX_HIP(ctx, hipGetLastError());
+        return IVX_OK;
+    }
     Pack64 p;
     p.min_s = r.min_s; p.min_e = r.min_e;
     p.bits_s = bits_of((u64)r.max_s - (u64)r.min_s); p.bits_e = bits_of((u64)r.max_e - (u64)r.min_e);

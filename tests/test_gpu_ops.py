@@ -253,6 +253,42 @@ def test_merge_random(ctx, seed):
             assert len(g) == len(w) and (g == w).all()
 
 
+@pytest.mark.parametrize("variant", ["sorted", "one_inversion", "all_equal", "sorted_by_start_only"])
+def test_sweeps_on_coordinate_sorted_input(ctx, variant):
+    """merge / cluster / complement / subtract detect input that already is in (key,start,end) order and skip the
+    radix sort (k_copy_sorted); one row out of place, or end-order ties broken the other way, must sort."""
+    k, s, e = synth(150_000, 411, nkeys=6, mean_len=400, span=2_000_000, dtype=np.int64)
+    e += 1
+    s[::9] = s[1::9][: len(s[::9])]; e[::9] = np.maximum(e[::9], s[::9] + 1)      # equal starts, different ends
+    k[::50], s[::50], e[::50] = k[1::50][: len(k[::50])], s[1::50][: len(k[::50])], e[1::50][: len(k[::50])]   # fully equal rows
+    if variant == "sorted_by_start_only":
+        o = np.lexsort((-e, s, k))                          # ends DEscending inside equal (key,start): not sorted
+    else:
+        o = np.lexsort((e, s, k))
+    k, s, e = k[o].copy(), s[o].copy(), e[o].copy()
+    if variant == "one_inversion":
+        s[70_000], e[70_000] = s[70_000] - 100_000, e[70_000] - 100_000
+    if variant == "all_equal":
+        k[:] = 2; s[:] = 77; e[:] = 99
+    rk, rs, re = synth(40_000, 412, nkeys=7, mean_len=150, span=2_000_000, dtype=np.int64)
+    re += 1
+    ro = np.lexsort((re, rs, rk)); rk, rs, re = rk[ro].copy(), rs[ro].copy(), re[ro].copy()
+    for force in (False, True):                            # IVX_FORCE_SORT: the same answers through the radix sort
+        if force:
+            os.environ["IVX_FORCE_SORT"] = "1"
+        try:
+            for strict in (False, True):
+                for g, w in zip(ctx.merge(k, s, e, n_keys=7, min_dist=3, strict=strict), orc.merge(k, s, e, min_dist=3, strict=strict)):
+                    assert len(g) == len(w) and (g == w).all()
+                _same_cluster(ctx.cluster(k, s, e, n_keys=7, min_dist=0, strict=strict), orc.cluster(k, s, e, min_dist=0, strict=strict, n_keys=7))
+                for g, w in zip(ctx.complement(k, s, e, rk, rs, re, n_keys=7, strict=strict), orc.complement(k, s, e, rk, rs, re, strict=strict)):
+                    assert len(g) == len(w) and (g == w).all()
+                for g, w in zip(ctx.subtract(k, s, e, rk, rs, re, n_keys=7, strict=strict), orc.subtract(k, s, e, rk, rs, re, strict=strict)):
+                    assert len(g) == len(w) and (g == w).all()
+        finally:
+            os.environ.pop("IVX_FORCE_SORT", None)
+
+
 def test_merge_i64_extremes(ctx):
     big = np.iinfo(np.int64).max
     k = np.zeros(6, np.uint32)

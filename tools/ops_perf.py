@@ -47,6 +47,10 @@ if "merge" in which or "subtract" in which or "cluster" in which or "complement"
     k, s, e = synth.gen_torch(n, 1000, 24, 0x5EED0008, dev)
     s64, e64 = s.to(torch.int64), e.to(torch.int64) + 1
     del s, e
+    if os.environ.get("SORTED"):                           # coordinate-sorted input (the sweeps then skip their radix sort)
+        o = torch.argsort((k.to(torch.int64) << 58) | (s64 << 29) | e64)
+        k, s64, e64 = k[o].contiguous(), s64[o].contiguous(), e64[o].contiguous()
+        del o
     if "merge" in which:
         tm, out = timed(lambda: ctx.merge(k, s64, e64, n_keys=24), reps=2)
         m = out[0].numel()
