@@ -159,6 +159,11 @@ __global__ __launch_bounds__(OT) void k_pack_se(const u32 *__restrict__ key, con
     const u64 sb = (u32)s[i] ^ SIGN, eb = (u32)e[i] ^ SIGN;
     w0[i] = (sb << 32) | eb;
     w1[i] = ((u64)k << 32) | (u32)i;
+    if (i) {                                                            // below the row before it? (flags[1]: input not sorted)
+        const u32 pk = key ? key[i - 1] : 0u;
+        const u64 pw = (((u64)((u32)s[i - 1] ^ SIGN)) << 32) | ((u32)e[i - 1] ^ SIGN);
+        if (k != pk ? k < pk : w0[i] < pw) flags[1] = 1;
+    }
 }
 
 // sorted words -> records {major, minor, row} (+ the key column).  y0/y1 (nullable): the same rows re-packed
@@ -371,9 +376,16 @@ ivx_status nearest_sorted_records(ivx_ctx *ctx, const u32 *key, const i32 *s, co
     IVX_TRY(ctx->get_scratch(WS_SB1, n * sizeof(u64), (void **)&b[1]));
     u32 *flags = (u32 *)(ctx->d_scalars + 8);
     hipLaunchKernelGGL(k_pack_se, dim3(grid1(n)), dim3(OT), 0, ctx->stream, key, s, e, n, nkeys, a[0], a[1], flags);
-    const ivx_sort_field f[3] = {{0, 0, 32}, {0, 32, 64}, {1, 32, 64}};
+    // build rows that already come in (key,start,end) order need no first sort
+    IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 8, flags, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+    IVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (((const u32 *)(ctx->h_scalars + 8))[0]) return ctx->fail(IVX_ERR_INVALID, "build key id >= n_keys");
+    const bool presorted = ((const u32 *)(ctx->h_scalars + 8))[1] == 0 && !getenv("IVX_FORCE_SORT");
     int in_b = 0;
-    IVX_TRY(ivx_radix_sort(ctx, 2, a, b, n, f, 3, &in_b));
+    if (!presorted) {
+        const ivx_sort_field f[3] = {{0, 0, 32}, {0, 32, 64}, {1, 32, 64}};
+        IVX_TRY(ivx_radix_sort(ctx, 2, a, b, n, f, 3, &in_b));
+    }
     u64 *const *r = in_b ? b : a, *const *y = in_b ? a : b;
     hipLaunchKernelGGL(k_unpack_rec, dim3(grid1(n)), dim3(OT), 0, ctx->stream, (const u64 *)r[0], (const u64 *)r[1], n, ks, rs, y[0], y[1]);
     const ivx_sort_field g[2] = {{0, 32, 64}, {1, 32, 64}};

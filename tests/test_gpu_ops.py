@@ -229,6 +229,25 @@ def test_nearest_random(ctx, seed):
         assert (gb == wb).all() and (gp == wp).all() and (gd == wd).all(), (k, ovl, strict)
 
 
+@pytest.mark.parametrize("variant", ["sorted", "one_inversion", "ends_descending"])
+def test_nearest_build_rows_already_sorted(ctx, variant):
+    # build rows in (key,start,end) order skip the first radix sort of the index build; duplicates keep row order
+    bk, bs, be = synth(50_000, 511, nkeys=5, mean_len=400, span=500_000)
+    bs[::11] = bs[1::11][: len(bs[::11])]; be[::11] = np.maximum(be[::11], bs[::11])
+    bk[::40], bs[::40], be[::40] = bk[1::40][: len(bk[::40])], bs[1::40][: len(bk[::40])], be[1::40][: len(bk[::40])]
+    o = np.lexsort((-be, bs, bk)) if variant == "ends_descending" else np.lexsort((be, bs, bk))
+    bk, bs, be = bk[o].copy(), bs[o].copy(), be[o].copy()
+    if variant == "one_inversion":
+        bs[30_000] -= 40_000; be[30_000] -= 40_000
+    pk, ps, pe = synth(40_000, 512, nkeys=6, mean_len=100, span=500_000)
+    ix = ctx.build(pyivx.KIND_NEAREST, bk, bs, be, n_keys=6)
+    for k, ovl in [(1, True), (1, False), (3, True)]:
+        gb, gp, gd = ctx.nearest(ix, pk, ps, pe, k=k, overlap=ovl)
+        wb, wp, wd = orc.nearest(bk, bs, be, pk, ps, pe, k=k, overlap=ovl)
+        assert len(gb) == len(wb) and (gb == wb).all() and (gp == wp).all() and (gd == wd).all(), (k, ovl)
+    ix.free()
+
+
 def test_nearest_empty_build_and_k0(ctx):
     e = np.empty(0, np.int32)
     ix = ctx.build(pyivx.KIND_NEAREST, np.empty(0, np.uint32), e, e, n_keys=3)

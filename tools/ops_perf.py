@@ -35,6 +35,12 @@ if "nearest" in which:
     nb, npr = int(50_000_000 * scale), int(50_000_000 * scale)
     bk, bs, be = synth.gen_torch(nb, 1000, 24, 0x5EED0006, dev)
     pk, ps, pe = synth.gen_torch(npr, 150, 24, 0x5EED0007, dev)
+    if os.environ.get("SORTED"):
+        o = torch.argsort((bk.to(torch.int64) << 58) | (bs.to(torch.int64) << 29) | be.to(torch.int64))
+        bk, bs, be = bk[o].contiguous(), bs[o].contiguous(), be[o].contiguous()
+        o = torch.argsort((pk.to(torch.int64) << 58) | (ps.to(torch.int64) << 29) | pe.to(torch.int64))
+        pk, ps, pe = pk[o].contiguous(), ps[o].contiguous(), pe[o].contiguous()
+        del o
     tb, ix = timed(lambda: ctx.build(pyivx.KIND_NEAREST, bk, bs, be, n_keys=24), reps=2)
     report(f"nearest build {nb}", tb, 12 * nb, f"index {ix.device_bytes/1e9:.2f} GB")
     tp, out = timed(lambda: ctx.nearest(ix, pk, ps, pe, k=1))
