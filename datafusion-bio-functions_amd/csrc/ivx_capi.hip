@@ -314,7 +314,7 @@ static ivx_status overlap_common(ivx_ctx *ctx, const ivx_index *ix, int mem, int
     // a fill call right after the count call that sized it: the routed probe rows are still in the context
     const void *in[3] = {key, start, end};
     ivx_join_plan &pl = ctx->join_plan;
-    const bool planned = regions && mode == JP_FILL && pl.valid && pl.mem == mem && memcmp(pl.in, in, sizeof(in)) == 0 && pl.n == n &&
+    const bool planned = regions && mode == JP_FILL && pl.valid && !getenv("IVX_NO_PLAN") && pl.mem == mem && memcmp(pl.in, in, sizeof(in)) == 0 && pl.n == n &&
                          pl.ix == (const void *)ix && pl.ix_serial == ix->serial && pl.stream == ctx->stream;
     if (!planned) {
         IVX_TRY(stage_in(ctx, mem, WS_IN_KEY, key, n, &dk));
@@ -518,7 +518,7 @@ extern "C" ivx_status ivx_subtract(ivx_ctx *ctx, int mem,
     const void *in[6] = {lkey, lstart, lend, rkey, rstart, rend};
     ivx_sub_plan &pl = ctx->sub_plan;
     const bool sizing = cap == 0 && !out_key && !out_start && !out_end && !out_row;
-    const bool planned = !sizing && nl && pl.valid && pl.mem == mem && memcmp(pl.in, in, sizeof(in)) == 0 && pl.nl == nl && pl.nr == nr &&
+    const bool planned = !sizing && nl && pl.valid && !getenv("IVX_NO_PLAN") && pl.mem == mem && memcmp(pl.in, in, sizeof(in)) == 0 && pl.nl == nl && pl.nr == nr &&
                          pl.nkeys == n_keys && pl.strict == strict && pl.stream == ctx->stream;
     if (!planned) {
         IVX_TRY(stage_in(ctx, mem, WS_IN_KEY, lkey, nl, &dlk));

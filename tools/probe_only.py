@@ -4,6 +4,7 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "datafusion-bio-functions_amd"))
 import pyivx, synth
+os.environ.setdefault("IVX_NO_PLAN", "1")      # every fill call does its own routing here
 dev = torch.device("cuda:0")
 npb = int(os.environ.get("NP", 100_000_000)); nb = int(os.environ.get("NB", 1_000_000)); nk = int(os.environ.get("NK", 24))
 mode = os.environ.get("MODE", "count")
