@@ -330,7 +330,9 @@ static ivx_status overlap_common(ivx_ctx *ctx, const ivx_index *ix, int mem, int
     {
         KernelTimer t(ctx);
         if (regions) {
-            IVX_TRY(ivx_join_probe_regions(ctx, ix->jv, ix->jv_nreg, mode, dk, ds, de, n, d_b, d_p, cap, ctx->d_scalars, planned));
+            if (!planned) pl.valid = false;                 // whatever an earlier count call left is gone now
+            const ivx_status st = ivx_join_probe_regions(ctx, ix->jv, ix->jv_nreg, mode, dk, ds, de, n, d_b, d_p, cap, ctx->d_scalars, planned);
+            if (st != IVX_OK) { pl.valid = false; return st; }
             if (mode == JP_COUNT && pl.valid) { memcpy(pl.in, in, sizeof(in)); pl.mem = mem; pl.n = n; pl.ix = ix; pl.ix_serial = ix->serial; pl.stream = ctx->stream; }
         }
         else if (rowval) IVX_TRY(ivx_rowval_probe_regions(ctx, ix->jv, mode == JP_PER_ROW ? IVX_RV_PER_ROW : IVX_RV_EXISTS, dk, ds, de, n, 0,
@@ -535,10 +537,11 @@ extern "C" ivx_status ivx_subtract(ivx_ctx *ctx, int mem,
     u64 m = 0;
     {
         KernelTimer t(ctx);
+        if (!planned) pl.valid = false;                     // whatever an earlier sizing call left is gone now
         ivx_status st = planned ? ivx_subtract_fill_planned(ctx, ok, os, oe, orow, cap, &m)
-                                            : ivx_subtract_device(ctx, dlk, dls, dle, nl, drk, drs, dre, nr, n_keys, strict, ok, os, oe, orow, cap, &m);
+                                : ivx_subtract_device(ctx, dlk, dls, dle, nl, drk, drs, dre, nr, n_keys, strict, ok, os, oe, orow, cap, &m);
         *n_out = m;
-        if (st != IVX_OK) return st;
+        if (st != IVX_OK) { if (st != IVX_ERR_CAPACITY) pl.valid = false; return st; }
         if (sizing && pl.valid) { memcpy(pl.in, in, sizeof(in)); pl.mem = mem; }
     }
     if (cap) {
