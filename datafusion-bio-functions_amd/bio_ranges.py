@@ -180,6 +180,10 @@ class Session:
         names = [f"l.{n}" for n in build.schema.names] + [f"r.{n}" for n in probe.schema.names]
         return pa.table(cols, names=names)
 
+    def join_stream(self, build, cols_build=DEFAULT_COLS, cols_probe=DEFAULT_COLS, strict_predicate=False, coalesce_rows=0):
+        """IntervalJoinStream as a push interface: index `build` once, then push probe batches; see JoinStream."""
+        return JoinStream(self, build, cols_build, cols_probe, strict_predicate, coalesce_rows)
+
     # ---- overlap UDTF (overlap.rs:154-226): FROM right AS b, left AS a  => the user's RIGHT table is the build side
     def overlap(self, left, right, mode="join", cols_left=DEFAULT_COLS, cols_right=DEFAULT_COLS, strict=False):
         if mode == "left":                                   # LeftDistinct: RIGHT SEMI JOIN, left rows that have a match
@@ -281,6 +285,52 @@ class Session:
                 V.close()
         key = cols[0] if isinstance(cols[0], str) else cols[0][0]
         return pa.table([_import(*o) for o in outs], names=[key, cols[1], cols[2]])
+
+
+class JoinStream:
+    """brh_join_stream: the build side indexed once, probe RecordBatches pushed one by one and coalesced into
+    groups before they go to the GPU.  push()/finish() return the results that became ready, each a dict
+    first_batch, n_batches, build_idx, probe_idx (rows counted over the group's concatenated batches), batch_offsets."""
+
+    def __init__(self, session, build, cols_build, cols_probe, strict_predicate, coalesce_rows):
+        self.session = session
+        self.h = C.c_void_p()
+        B = _Exported(build)
+        try:
+            session._chk(lib().brh_join_stream_open(session.h, B.c, _cols(cols_build), _cols(cols_probe), C.c_int(int(strict_predicate)),
+                                                    C.c_uint64(int(coalesce_rows)), C.byref(self.h)))
+        finally:
+            B.close()
+
+    def _drain(self, n):
+        out = []
+        for _ in range(n):
+            first, nb = C.c_uint64(0), C.c_uint64(0)
+            (ba, bs), (pa_, ps), (oa, os_) = _out(), _out(), _out()
+            self.session._chk(lib().brh_join_stream_next(self.h, C.byref(first), C.byref(nb), C.byref(ba), C.byref(bs),
+                                                         C.byref(pa_), C.byref(ps), C.byref(oa), C.byref(os_)))
+            out.append({"first_batch": first.value, "n_batches": nb.value, "build_idx": _import(ba, bs),
+                        "probe_idx": _import(pa_, ps), "batch_offsets": _import(oa, os_)})
+        return out
+
+    def push(self, batch):
+        P = _Exported(batch if isinstance(batch, pa.Table) else pa.Table.from_batches([batch]))
+        n = C.c_int(0)
+        try:
+            self.session._chk(lib().brh_join_stream_push(self.h, P.c, C.byref(n)))
+        finally:
+            P.close()
+        return self._drain(n.value)
+
+    def finish(self):
+        n = C.c_int(0)
+        self.session._chk(lib().brh_join_stream_finish(self.h, C.byref(n)))
+        return self._drain(n.value)
+
+    def close(self):
+        if self.h:
+            lib().brh_join_stream_close(self.h)
+            self.h = C.c_void_p()
 
 
 def check_position_column(table, column, as_i64=False):

@@ -7,6 +7,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <memory>
 #include <string>
 #include <string_view>
 #include <unordered_map>
@@ -651,3 +653,159 @@ extern "C" int brh_take(brh_session *s, const ArrowArray *column, const ArrowSch
     make_schema(out_schema, f, column_schema->name ? column_schema->name : "", true);
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// IntervalJoinStream as a push interface (interval_join.rs:934-1140, :1418-1677): the build side is indexed
+// once (WaitBuildSide / collect_left_input :584-700), probe RecordBatches arrive one by one (FetchProbeBatch)
+// and each is joined against the index (ProcessProbeBatch).  A GPU call per 8192-row batch would be all launch
+// latency, so the probe batches are COALESCED here -- what DataFusion's CoalesceBatchesExec does in front of
+// an operator -- into groups of `coalesce_rows` rows; a group is probed in one count + fill pair (its columns
+// cross PCIe once, ivx.h "two-call protocol") and yields ONE result: pairs (build_idx, probe_idx) with
+// probe_idx counted over the group's concatenated rows, and the row offset of every batch in the group.
+struct brh_join_stream {
+    brh_session *s = nullptr;
+    ivx_index *ix = nullptr;
+    std::vector<std::string> pkeys; std::string pstart, pend;      // the probe side's column names (owned)
+    std::unordered_map<std::string, uint32_t> dict;                 // build-side key -> id; unknown keys get id nk (no build rows)
+    uint32_t nk = 0;
+    uint64_t short_keys[1024] = {}; uint32_t short_ids[1024] = {}; uint32_t n_short = 0;   // packed short names -> id
+    bool strict = false;
+    uint64_t coalesce_rows = 0;
+    // the open group
+    std::vector<uint32_t> gk; std::vector<int32_t> gs, ge; std::vector<int64_t> goff;
+    uint64_t first_batch = 0, n_pushed = 0;
+    struct Result { uint64_t first_batch, n_batches; std::vector<uint32_t> bi, pi; std::vector<int64_t> off; };
+    std::deque<Result> ready;
+    ~brh_join_stream() { if (ix) ivx_index_free(ix); }
+};
+
+namespace {
+
+int stream_flush(brh_join_stream *js)
+{
+    brh_session *s = js->s;
+    if (js->goff.empty()) return 0;
+    brh_join_stream::Result r;
+    r.first_batch = js->first_batch; r.n_batches = js->goff.size();
+    r.off = js->goff; r.off.push_back((int64_t)js->gs.size());
+    const uint64_t np = js->gs.size();
+    uint64_t total = 0, written = 0;
+    ivx_status st = ivx_probe_overlap_count(s->ctx, js->ix, IVX_MEM_HOST, js->gk.data(), js->gs.data(), js->ge.data(), np, nullptr, &total);
+    if (st != IVX_OK) return fail_ivx(s, st);
+    r.bi.resize(total ? total : 1); r.pi.resize(total ? total : 1);
+    st = ivx_probe_overlap_fill(s->ctx, js->ix, IVX_MEM_HOST, js->gk.data(), js->gs.data(), js->ge.data(), np, r.bi.data(), r.pi.data(), total, &written);
+    if (st != IVX_OK) return fail_ivx(s, st);
+    r.bi.resize(written); r.pi.resize(written);
+    js->ready.push_back(std::move(r));
+    js->first_batch = js->n_pushed;
+    js->gk.clear(); js->gs.clear(); js->ge.clear(); js->goff.clear();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int brh_join_stream_open(brh_session *s, brh_batch build, brh_columns bcols, brh_columns pcols, int strict_predicate,
+                                    uint64_t coalesce_rows, brh_join_stream **out)
+{
+    if (!s || !out) return 1;
+    *out = nullptr;
+    if (pcols.n_keys != bcols.n_keys || pcols.n_keys < 1) return fail(s, "both sides need the same number (>= 1) of key columns");
+    KeyDict kd; Side32 B;
+    if (build_keys(s, {{build, bcols}}, &kd) || load_side32(s, build, bcols, &B)) return 1;
+    if (strict_predicate) for (auto &v : B.e) v = (int32_t)((uint32_t)v - 1u);          // intervals.rs:85-115
+    std::unique_ptr<brh_join_stream> js(new brh_join_stream());
+    js->s = s; js->strict = strict_predicate != 0;
+    js->coalesce_rows = coalesce_rows ? coalesce_rows : (4u << 20);
+    js->nk = (uint32_t)kd.names.size();
+    for (uint32_t i = 0; i < js->nk; i++) js->dict.emplace(kd.names[i], i);
+    for (int k = 0; k < pcols.n_keys; k++) js->pkeys.emplace_back(pcols.keys[k]);
+    js->pstart = pcols.start; js->pend = pcols.end;
+    // one key id more than the build side has: "contig the build side does not know", never matches
+    ivx_status st = ivx_index_build(s->ctx, IVX_KIND_OVERLAP, IVX_MEM_HOST, kd.ids[0].data(), B.s.data(), B.e.data(), B.s.size(), js->nk + 1, &js->ix);
+    if (st != IVX_OK) return fail_ivx(s, st);
+    *out = js.release();
+    return 0;
+}
+
+extern "C" int brh_join_stream_push(brh_join_stream *js, brh_batch probe, int *n_ready)
+{
+    if (!js) return 1;
+    brh_session *s = js->s;
+    std::vector<const char *> keyp;
+    for (auto &k : js->pkeys) keyp.push_back(k.c_str());
+    const brh_columns pc{keyp.data(), (int)keyp.size(), js->pstart.c_str(), js->pend.c_str()};
+    std::vector<StrCol> cols(pc.n_keys);
+    for (int k = 0; k < pc.n_keys; k++) if (get_contig(s, probe, pc.keys[k], &cols[k])) return 1;
+    Side32 P;
+    if (load_side32(s, probe, pc, &P)) return 1;
+    const int64_t n = probe.array->length;
+    const size_t base = js->gs.size();
+    js->goff.push_back((int64_t)base);
+    js->gk.resize(base + (size_t)n); js->gs.resize(base + (size_t)n); js->ge.resize(base + (size_t)n);
+    // key ids.  Rows of one contig come in runs (coordinate-sorted files), so the previous row's answer is tried
+    // first; names of up to 7 bytes ("chr1" ... "chrUn") are looked up as one packed 64-bit word in a small
+    // open-addressing table (short_ids, filled as names are met), anything longer in the string dictionary
+    std::string scratch, last; uint32_t last_id = 0; bool have_last = false; uint64_t last_packed = 0;
+    for (int64_t i = 0; i < n; i++) {
+        std::string_view k;
+        if (cols.size() == 1) k = cols[0].at(i);
+        else { scratch.clear(); for (size_t c = 0; c < cols.size(); c++) { if (c) scratch.push_back('\x1f'); scratch.append(cols[c].at(i)); } k = scratch; }
+        if (k.size() <= 7) {
+            uint64_t packed = 0;
+            std::memcpy(&packed, k.data(), k.size());
+            packed |= (uint64_t)(k.size() + 1) << 56;                    // never 0: 0 marks an empty slot
+            if (packed != last_packed) {
+                bool hit = false;
+                uint32_t h = (uint32_t)((packed * 0x9E3779B97F4A7C15ull) >> 54);
+                for (;; h = (h + 1) & 1023u) {
+                    if (js->short_keys[h] == packed) { last_id = js->short_ids[h]; hit = true; break; }
+                    if (js->short_keys[h] == 0) break;
+                }
+                if (!hit) {
+                    auto it = js->dict.find(std::string(k));
+                    last_id = it == js->dict.end() ? js->nk : it->second;
+                    if (js->n_short < 512) { js->short_keys[h] = packed; js->short_ids[h] = last_id; js->n_short++; }   // h = the empty slot found
+                }
+                last_packed = packed; have_last = false;
+            }
+        } else if (!have_last || k != std::string_view(last)) {
+            last.assign(k.data(), k.size());
+            auto it = js->dict.find(last);
+            last_id = it == js->dict.end() ? js->nk : it->second;
+            have_last = true; last_packed = 0;
+        }
+        js->gk[base + (size_t)i] = last_id;
+        js->gs[base + (size_t)i] = P.s[(size_t)i];
+        js->ge[base + (size_t)i] = js->strict ? (int32_t)((uint32_t)P.e[(size_t)i] - 1u) : P.e[(size_t)i];
+    }
+    js->n_pushed++;
+    if (js->gs.size() >= js->coalesce_rows && stream_flush(js)) return 1;
+    if (n_ready) *n_ready = (int)js->ready.size();
+    return 0;
+}
+
+extern "C" int brh_join_stream_finish(brh_join_stream *js, int *n_ready)
+{
+    if (!js) return 1;
+    if (stream_flush(js)) return 1;
+    if (n_ready) *n_ready = (int)js->ready.size();
+    return 0;
+}
+
+extern "C" int brh_join_stream_next(brh_join_stream *js, uint64_t *first_batch, uint64_t *n_batches,
+                                    ArrowArray *build_idx, ArrowSchema *build_idx_schema, ArrowArray *probe_idx, ArrowSchema *probe_idx_schema,
+                                    ArrowArray *batch_offsets, ArrowSchema *batch_offsets_schema)
+{
+    if (!js) return 1;
+    if (js->ready.empty()) return fail(js->s, "join stream: no result is ready");
+    brh_join_stream::Result &r = js->ready.front();
+    if (first_batch) *first_batch = r.first_batch;
+    if (n_batches) *n_batches = r.n_batches;
+    make_primitive<uint32_t>(build_idx, r.bi.data(), (int64_t)r.bi.size(), nullptr); make_schema(build_idx_schema, "I", "build_idx", false);
+    make_primitive<uint32_t>(probe_idx, r.pi.data(), (int64_t)r.pi.size(), nullptr); make_schema(probe_idx_schema, "I", "probe_idx", false);
+    make_primitive<int64_t>(batch_offsets, r.off.data(), (int64_t)r.off.size(), nullptr); make_schema(batch_offsets_schema, "l", "batch_offsets", false);
+    js->ready.pop_front();
+    return 0;
+}
+
+extern "C" void brh_join_stream_close(brh_join_stream *js) { delete js; }

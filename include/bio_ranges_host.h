@@ -134,6 +134,26 @@ int brh_take(brh_session *s, const struct ArrowArray *column, const struct Arrow
              const struct ArrowArray *idx, const struct ArrowSchema *idx_schema,
              struct ArrowArray *out, struct ArrowSchema *out_schema);
 
+/* IntervalJoinStream as a push interface (interval_join.rs:934-1140, :1418-1677), Inner join.  open indexes the
+ * build side once (collect_left_input, :584-700); push takes one probe RecordBatch (FetchProbeBatch /
+ * ProcessProbeBatch).  Probe batches are coalesced into groups of at least `coalesce_rows` rows (0 = 4 Mi) before
+ * they go to the GPU -- the job of CoalesceBatchesExec in a DataFusion plan: a device call per 8192-row batch would
+ * be all launch latency.  Every group gives ONE result (next): build_idx / probe_idx UInt32 pairs, probe_idx
+ * counted over the group's concatenated rows, plus batch_offsets Int64 [n_batches + 1] = the first row of each of
+ * the group's batches, so the caller can concatenate its buffered batches (or split the pairs) and `take` the
+ * payload columns as the reference does (:1655-1667).  *n_ready = results waiting in the queue.  Probe rows whose
+ * key the build side does not have never match.  finish flushes the last, partial group. */
+typedef struct brh_join_stream brh_join_stream;
+int  brh_join_stream_open(brh_session *s, brh_batch build, brh_columns bcols, brh_columns pcols, int strict_predicate,
+                          uint64_t coalesce_rows, brh_join_stream **out);
+int  brh_join_stream_push(brh_join_stream *js, brh_batch probe, int *n_ready);
+int  brh_join_stream_finish(brh_join_stream *js, int *n_ready);
+int  brh_join_stream_next(brh_join_stream *js, uint64_t *first_batch, uint64_t *n_batches,
+                          struct ArrowArray *build_idx, struct ArrowSchema *build_idx_schema,
+                          struct ArrowArray *probe_idx, struct ArrowSchema *probe_idx_schema,
+                          struct ArrowArray *batch_offsets, struct ArrowSchema *batch_offsets_schema);
+void brh_join_stream_close(brh_join_stream *js);
+
 /* the checks alone (no GPU): resolve a position column like PosArray::resolve / resolve_i64 would;
  * 0 = fine, else the error text is set.  Used by the CPU-only tests. */
 int brh_check_position_column(brh_session *s_or_null, brh_batch table, const char *column, int as_i64,

@@ -277,3 +277,72 @@ def test_overlap_udtf_custom_columns(ctx):
     b = pa.table({"chr": ["a"], "s": [150], "e": [250]})
     out = ctx.overlap(a, b, cols_left=("chr", "s", "e"), cols_right=("chr", "s", "e"))
     assert out.num_rows == 1 and out.schema.names[0] == "left_chr" and out.schema.names[3] == "right_chr"
+
+
+def _stream_pairs(js, batches):
+    """push the batches, finish, and return the pairs as (build_idx, global probe row) + the number of results"""
+    import numpy as np
+    starts = np.cumsum([0] + [b.num_rows for b in batches])
+    results = []
+    for b in batches:
+        results += js.push(b)
+    results += js.finish()
+    bi, pi, seen = [], [], 0
+    for r in results:
+        assert r["first_batch"] == seen                          # results come in push order, every batch in exactly one group
+        off = r["batch_offsets"].to_numpy()
+        assert len(off) == r["n_batches"] + 1 and off[0] == 0
+        assert (np.diff(off) == [batches[seen + j].num_rows for j in range(r["n_batches"])]).all()
+        bi.append(r["build_idx"].to_numpy()); pi.append(r["probe_idx"].to_numpy().astype(np.int64) + starts[seen])
+        seen += r["n_batches"]
+    assert seen == len(batches)
+    return (np.concatenate(bi) if bi else np.empty(0, np.uint32)), (np.concatenate(pi) if pi else np.empty(0, np.int64)), len(results)
+
+
+def test_join_stream_golden_tables_in_small_batches(ctx, golden):
+    # the 12 reads x 10 targets join (integration_test.rs:61-84) with the probe side pushed three rows at a time
+    reads, targets = table(golden.tables["reads"]), table(golden.tables["targets"])
+    want_b, want_p = ctx.interval_join(reads, targets)
+    want = sorted(zip(want_b.to_pylist(), want_p.to_pylist()))
+    for coalesce in (1, 5, 0):
+        js = ctx.join_stream(reads, coalesce_rows=coalesce)
+        bi, pi, nres = _stream_pairs(js, [targets.slice(i, 3) for i in range(0, targets.num_rows, 3)])
+        js.close()
+        assert sorted(zip(bi.tolist(), pi.tolist())) == want and len(want) == 16
+        assert nres == {1: 4, 5: 2, 0: 1}[coalesce]
+
+
+@pytest.mark.parametrize("strict", [False, True])
+def test_join_stream_matches_one_shot_join(ctx, strict):
+    import numpy as np
+    rng = np.random.default_rng(5)
+    names = np.array(["chr1", "chr10", "chr2", "chrX", "scaffold_77"])
+
+    def tab(n, keys, mean):
+        s = rng.integers(0, 3_000_000, n)
+        return pa.table({"contig": pa.array(names[rng.integers(0, keys, n)]), "pos_start": pa.array(s, pa.int64()),
+                         "pos_end": pa.array(s + rng.integers(1, 2 * mean, n), pa.int64())})
+
+    build = tab(40_000, 4, 800)                                  # the build side never sees "scaffold_77"
+    probe = tab(2_600_000, 5, 150)
+    cuts = [0, 0, 10, 8_202, 70_000, 70_000, 1_000_000, 2_400_000, 2_600_000]      # empty batches, a tiny one, big ones
+    batches = [probe.slice(a, b - a) for a, b in zip(cuts[:-1], cuts[1:])]
+    wb, wp = ctx.interval_join(build, probe, strict_predicate=strict)
+    want = np.sort((wb.to_numpy().astype(np.uint64) << np.uint64(32)) | wp.to_numpy().astype(np.uint64))
+    for coalesce in (50_000, 2_200_000, 0):                      # many small groups; one group on the region-partitioned path; one at finish
+        js = ctx.join_stream(build, strict_predicate=strict, coalesce_rows=coalesce)
+        bi, pi, nres = _stream_pairs(js, batches)
+        js.close()
+        got = np.sort((bi.astype(np.uint64) << np.uint64(32)) | pi.astype(np.uint64))
+        assert len(got) == len(want) and (got == want).all(), coalesce
+
+
+def test_join_stream_errors(ctx, golden):
+    reads, targets = table(golden.tables["reads"]), table(golden.tables["targets"])
+    js = ctx.join_stream(reads)
+    with pytest.raises(br.BioRangesError, match="contig column 'contig' not found"):
+        js.push(targets.rename_columns(["chrom", "pos_start", "pos_end"]))
+    with pytest.raises(br.BioRangesError, match=r"overflows i32"):
+        js.push(pa.table({"contig": ["chr1"], "pos_start": pa.array([2**31], pa.int64()), "pos_end": pa.array([2**31 + 5], pa.int64())}))
+    assert js.finish() == []                                     # nothing was accepted
+    js.close()
