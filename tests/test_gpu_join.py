@@ -296,3 +296,36 @@ def test_join_count_then_fill_reuses_the_routed_rows(ctx, device):
         ix.free()
     finally:
         del os.environ["IVX_JOIN_PATH"]
+
+
+def test_two_contexts_in_two_threads():
+    """One ivx_ctx per DataFusion partition: two host threads, each with its own context (own stream and scratch),
+    join different data at the same time on one GPU (ctypes drops the GIL inside the calls)."""
+    import threading
+    jobs = []
+    for t in range(2):
+        bk, bs, be = synth(80_000, 900 + t, nkeys=6, mean_len=700, span=6_000_000)
+        pk, ps, pe = synth(2_300_000, 910 + t, nkeys=6, mean_len=150, span=6_000_000)      # above the region-path threshold
+        wb, wp = orc.join(bk, bs, be, pk, ps, pe, threads=4)
+        jobs.append(((bk, bs, be), (pk, ps, pe), pair_set(wb, wp)))
+    errors = []
+
+    def run(job):
+        try:
+            b, p, want = job
+            c = pyivx.Ctx(0)
+            for _ in range(4):
+                ix = c.build(pyivx.KIND_OVERLAP, *b, n_keys=6)
+                ob, op = c.overlap_fill(ix, *p)                      # count + fill
+                assert (pair_set(ob, op) == want).all()
+                ix.free()
+            c.close()
+        except BaseException as e:                                    # noqa: BLE001 -- reported by the main thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=run, args=(j,)) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
