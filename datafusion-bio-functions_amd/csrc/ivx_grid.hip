@@ -14,12 +14,18 @@ __global__ void k_init_keystats(i32 *kmin, i32 *kmax, u32 *kcnt, u32 nkeys)
     if (i < nkeys) { kmin[i] = INT32_MAX; kmax[i] = INT32_MIN; kcnt[i] = 0; }
 }
 
-// per-key min / max of v and row counts, privatised in LDS; key ids >= nkeys raise *errflag
+// per-key min / max of v and row counts, privatised in LDS; key ids >= nkeys raise *errflag.
+// vend + lenhist (both nullable; vs == 1): also the histogram of the rows' length classes for the overlap
+// index layout, lenhist[b] = rows whose (vend - v) has b significant bits (0 for vend <= v), b = 0..32
 __global__ __launch_bounds__(GT) void k_keystats(const u32 *__restrict__ key, const i32 *__restrict__ v, u64 n,
-                                                 u32 nkeys, i32 *kmin, i32 *kmax, u32 *kcnt, u32 *errflag, u32 vs)
+                                                 u32 nkeys, i32 *kmin, i32 *kmax, u32 *kcnt, u32 *errflag, u32 vs,
+                                                 const i32 *__restrict__ vend, u32 *lenhist)
 {
     extern __shared__ i32 sh[];
+    __shared__ u32 s_len[33];
+    if (lenhist && threadIdx.x < 33) s_len[threadIdx.x] = 0;
     const bool priv = nkeys <= KEYS_IN_LDS;
+    if (!priv && lenhist) __syncthreads();
     i32 *smin = sh, *smax = sh + nkeys;
     u32 *scnt = (u32 *)(sh + 2 * nkeys);
     if (priv) {
@@ -30,6 +36,10 @@ __global__ __launch_bounds__(GT) void k_keystats(const u32 *__restrict__ key, co
         const u32 k = key ? key[i] : 0u;
         if (k >= nkeys) { *errflag = 1; continue; }
         const i32 x = v[i * vs];
+        if (lenhist) {
+            const i64 len = (i64)vend[i] - (i64)x;
+            atomicAdd(&s_len[len <= 0 ? 0u : 64u - (u32)__clzll((u64)len)], 1u);
+        }
         if (priv) { atomicMin(&smin[k], x); atomicMax(&smax[k], x); atomicAdd(&scnt[k], 1u); }
         else { atomicMin(&kmin[k], x); atomicMax(&kmax[k], x); atomicAdd(&kcnt[k], 1u); }
     }
@@ -37,6 +47,10 @@ __global__ __launch_bounds__(GT) void k_keystats(const u32 *__restrict__ key, co
         __syncthreads();
         for (u32 k = threadIdx.x; k < nkeys; k += GT)
             if (scnt[k]) { atomicMin(&kmin[k], smin[k]); atomicMax(&kmax[k], smax[k]); atomicAdd(&kcnt[k], scnt[k]); }
+    }
+    if (lenhist) {
+        __syncthreads();
+        if (threadIdx.x < 33 && s_len[threadIdx.x]) atomicAdd(&lenhist[threadIdx.x], s_len[threadIdx.x]);
     }
 }
 
@@ -145,12 +159,18 @@ ivx_status ivx_keystats(ivx_ctx *ctx, const u32 *key, const i32 *v, u64 n, u32 n
 ivx_status ivx_keystats(ivx_ctx *ctx, const u32 *key, const i32 *v, u64 n, u32 nkeys,
                         i32 *kmin, i32 *kmax, u32 *kcnt, u32 *errflag, u32 vstride)
 {
+    return ivx_keystats_len(ctx, key, v, n, nkeys, kmin, kmax, kcnt, errflag, vstride, nullptr, nullptr);
+}
+
+ivx_status ivx_keystats_len(ivx_ctx *ctx, const u32 *key, const i32 *v, u64 n, u32 nkeys,
+                            i32 *kmin, i32 *kmax, u32 *kcnt, u32 *errflag, u32 vstride, const i32 *vend, u32 *lenhist)
+{
     hipStream_t st = ctx->stream;
     hipLaunchKernelGGL(k_init_keystats, dim3((nkeys + GT - 1) / GT), dim3(GT), 0, st, kmin, kmax, kcnt, nkeys);
     if (n) {
         const u32 grid = ivx_stream_grid(n, GT * 8, 1024);
         const size_t shm = nkeys <= KEYS_IN_LDS ? (size_t)nkeys * 12 : 0;
-        hipLaunchKernelGGL(k_keystats, dim3(grid), dim3(GT), shm, st, key, v, n, nkeys, kmin, kmax, kcnt, errflag, vstride);
+        hipLaunchKernelGGL(k_keystats, dim3(grid), dim3(GT), shm, st, key, v, n, nkeys, kmin, kmax, kcnt, errflag, vstride, vend, lenhist);
     }
     IVX_HIP(ctx, hipGetLastError());
     return IVX_OK;

@@ -49,3 +49,6 @@ ivx_status ivx_grid_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32
                           u32 vstride = 1);
 ivx_status ivx_keystats(ivx_ctx *ctx, const u32 *key, const i32 *v, u64 n, u32 nkeys,
                         i32 *kmin, i32 *kmax, u32 *kcnt, u32 *errflag, u32 vstride);
+// ... and the histogram of the length classes of [v, vend] (33 counters, zeroed by the caller; vstride must be 1)
+ivx_status ivx_keystats_len(ivx_ctx *ctx, const u32 *key, const i32 *v, u64 n, u32 nkeys,
+                            i32 *kmin, i32 *kmax, u32 *kcnt, u32 *errflag, u32 vstride, const i32 *vend, u32 *lenhist);

@@ -119,6 +119,9 @@ enum { HDR_SH0 = 0, HDR_NLEV = 1, HDR_NBINS = 2, HDR_CS = 3, HDR_NREG = 4, HDR_L
 
 // what a probe workgroup needs to stage one region's slice of level 0 (ivx_join_regions.hip), precomputed at
 // build time so that staging starts with ONE load instead of a chain of four dependent ones
+#ifndef IVX_RP_ECAP
+#define IVX_RP_ECAP 6144          // level-0 entries a region's LDS slice holds (ivx_join_regions.hip)
+#endif
 #define IVX_RP_HALO 8u      // slice cells past the region's last cell
 struct ivx_regdesc { u32 k; i32 origin; u32 span, lb, slo, shi, e0, ne; };
 

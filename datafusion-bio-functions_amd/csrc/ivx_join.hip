@@ -15,8 +15,10 @@
 //   binstart words bracketing cells [bin(qs - 2^sh + 1) .. bin(qe)] and tests
 //   the entries between them with the literal predicate
 //   start <= qe && end >= qs.
-//   sh0 is picked on the device from the per-key coordinate spans so that the
-//   finest level has at most ~2 cells per build row.
+//   sh0 is picked on the device: at least the shift at which the finest level
+//   has ~2 cells per build row (per-key coordinate spans), and above that the
+//   one with the smallest expected probe cost given the rows' length classes
+//   (k_join_layout) -- level 0 is the level the region probe keeps in LDS.
 #include "ivx_device.hpp"
 #include "ivx_grid.hpp"
 #include "ivx_join.hpp"
@@ -33,7 +35,7 @@ __device__ __forceinline__ u32 cells_of(u32 cnt, u32 span, u32 sh) { return cnt 
 // lay out the (level,key) cell ranges.  hdr: sh0, #levels, #cells.
 __global__ __launch_bounds__(1024) void k_join_layout(const i32 *kmin, const i32 *kmax, const u32 *kcnt, u32 nkeys, u64 n,
                                                       i32 *origin, u32 *span, u32 *lbase, u32 *hdr, u64 maxcells,
-                                                      u32 *kreg, u32 *rkey)
+                                                      u32 *kreg, u32 *rkey, const u32 *lenhist)
 {
     __shared__ u64 red[1024 / IVX_WAVE + 1];
     __shared__ u32 s_sh0;
@@ -59,10 +61,52 @@ __global__ __launch_bounds__(1024) void k_join_layout(const i32 *kmin, const i32
         if (ln == 0) s_tot[sh] = a;
     }
     __syncthreads();
+    __shared__ float s_occ0;                                           // level-0 rows per level-0 cell at the chosen shift
+    __shared__ u64 s_cum[34];                                          // s_cum[b + 1] = build rows with at most b length bits
+    __shared__ float s_cost[32], s_cocc[32];
+    __shared__ u32 s_shb;
+    if (t <= 32) s_cum[t + 1] = lenhist[t];
+    __syncthreads();
     if (t == 0) {
-        u32 sh = IVX_SH_MIN;
-        while (sh < 31 && s_tot[sh] > budget0) sh++;
-        s_sh0 = sh;
+        u32 shb = IVX_SH_MIN;
+        while (shb < 31 && s_tot[shb] > budget0) shb++;
+        s_shb = shb;
+        u64 run = 0;
+        s_cum[0] = 0;
+        for (u32 b = 0; b <= 32; b++) { run += s_cum[b + 1]; s_cum[b + 1] = run; }
+    }
+    __syncthreads();
+    // The budget gives the FINEST usable grid (shb).  When most build rows are longer than its cells they all land
+    // in the upper levels, which a probe row reads with dependent global gathers, while level 0 is what the
+    // region probe stages in LDS.  So among the shifts >= shb take the one with the smallest expected probe cost:
+    // per non-empty level a visit plus ~2.2 cells' worth of candidates (a short query reaches into the cell before
+    // its own), upper levels weighted as global reads.  One thread per candidate shift.
+    if (t < 32) {
+        const u32 sh = s_shb + t;
+        float cost = 3.0e38f, occ0 = 0.f;
+        if (sh <= 31) {
+            cost = 0.f;
+            u32 lo_bits = 0;                                            // smallest length-bit count not yet covered by a lower level
+            for (u32 l = 0; l < IVX_MAXL; l++) {
+                const u32 lsh = sh + IVX_LSTEP * l;
+                const bool last = lsh >= 32 || l + 1 == IVX_MAXL;
+                const u32 hi_bits = last ? 32u : lsh;
+                const u64 rows = hi_bits >= lo_bits ? s_cum[hi_bits + 1] - s_cum[lo_bits] : 0;
+                const float cells = lsh >= 32 ? (float)(nkeys ? nkeys : 1u) : (float)(s_tot[lsh] ? s_tot[lsh] : 1);
+                const float occ = (float)rows / cells;
+                if (l == 0) { occ0 = occ; cost += 1.f + 2.2f * occ; }
+                else if (rows) cost += 8.f + 2.2f * occ * 4.f;
+                if (last) break;
+                lo_bits = lsh + 1;
+            }
+        }
+        s_cost[t] = cost; s_cocc[t] = occ0;
+    }
+    __syncthreads();
+    if (t == 0) {
+        u32 bi = 0;
+        for (u32 c = 1; c < 32; c++) if (s_cost[c] < s_cost[bi]) bi = c;
+        s_sh0 = s_shb + bi; s_occ0 = s_cocc[bi];
     }
     __syncthreads();
     const u32 sh0 = s_sh0;
@@ -111,6 +155,14 @@ __global__ __launch_bounds__(1024) void k_join_layout(const i32 *kmin, const i32
     // regions wider than 2^IVX_REG_CS_MAX cells cannot be staged in LDS: take more, narrower regions instead
     // (the probe rows are then routed by a two-digit sort), as long as their number stays within IVX_MAXREG2
     if (clo > IVX_REG_CS_MAX && clo <= 32 && s_tot[IVX_REG_CS_MAX] <= IVX_MAXREG2) clo = IVX_REG_CS_MAX;
+    // ... and so can regions that hold more level-0 rows than the slice has room for (IVX_RP_ECAP): when an
+    // average region would overflow, shrink the regions until ~0.7 of the capacity is used on average
+    if (clo < 32 && s_occ0 * (float)(1u << clo) > (float)IVX_RP_ECAP) {
+        u32 c = clo;
+        while (c > 0 && s_occ0 * (float)(1u << c) > 0.7f * (float)IVX_RP_ECAP) c--;
+        while (c < clo && s_tot[c] > IVX_MAXREG2) c++;
+        clo = c;
+    }
     const u32 cs = clo;                                             // 32 = not even one region per key fits
     u64 rrun = 0;
     for (u32 k0 = 0; k0 < nkeys; k0 += 1024) {
@@ -290,13 +342,15 @@ ivx_status ivx_join_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32
     IVX_TRY(ctx->get_scratch(WS_GRID2, (n ? n : 1) * sizeof(u32), (void **)&cellid));
     IVX_TRY(ctx->get_scratch(WS_T9, (n ? n : 1) * sizeof(u32), (void **)&rank));
     errflag = (u32 *)(ctx->d_scalars + 8);
+    u32 *lenhist = (u32 *)(ctx->d_scalars + 32);                        // 33 counters
 
     IVX_HIP(ctx, hipMemsetAsync(errflag, 0, sizeof(u32), st));
+    IVX_HIP(ctx, hipMemsetAsync(lenhist, 0, 34 * sizeof(u32), st));
     IVX_HIP(ctx, hipMemsetAsync(binstart, 0, (maxcells + 1) * sizeof(u32), st));
     IVX_HIP(ctx, hipMemsetAsync(hdr, 0, HDR_WORDS * sizeof(u32), st));
-    IVX_TRY(ivx_keystats(ctx, key, s, n, nkeys, kmin, kmax, kcnt, errflag));
+    IVX_TRY(ivx_keystats_len(ctx, key, s, n, nkeys, kmin, kmax, kcnt, errflag, 1u, e, lenhist));   // + the length classes for the layout
     const u32 grid = ivx_stream_grid(n, BT * 8, 1024);
-    hipLaunchKernelGGL(k_join_layout, dim3(1), dim3(1024), 0, st, kmin, kmax, kcnt, nkeys, n, origin, span, lbase, hdr, maxcells, kreg, rkey);
+    hipLaunchKernelGGL(k_join_layout, dim3(1), dim3(1024), 0, st, kmin, kmax, kcnt, nkeys, n, origin, span, lbase, hdr, maxcells, kreg, rkey, (const u32 *)lenhist);
     hipLaunchKernelGGL(k_join_count, dim3(grid), dim3(BT), 0, st, key, s, e, n, nkeys, origin, lbase, hdr, binstart, cellid, rank);
     IVX_TRY(ivx_scan_exclusive_u32(ctx, binstart, maxcells + 1));
     hipLaunchKernelGGL(k_join_scatter, dim3(grid), dim3(BT), 0, st, s, e, n, (const u32 *)binstart, (const u32 *)cellid, (const u32 *)rank, ent);
