@@ -6,7 +6,7 @@
 //
 // Index layout in HBM (all integer/index work, HBM/L2-latency bound, no MFMA):
 //   Build rows are classed by length into levels l = 0..L-1; level l holds the
-//   rows with (end-start) < 2^(sh0 + 4l) and is cut into bins 2^(sh0+4l) wide
+//   rows with (end-start) < 2^(sh0 + IVX_LSTEP*l) and is cut into bins 2^(sh0 + IVX_LSTEP*l) wide
 //   per key, so a row starts at most one bin before the bin its end falls in.
 //   All (level,key,bin) cells are laid out in one CSR: binstart[] -> ent[]
 //   (12-byte {start,end,row} entries grouped by cell by a counting sort with
