@@ -112,8 +112,10 @@ enum {
 struct ivx_ent { i32 s, e; u32 row; };          // 12-byte AoS entry of the overlap index
 
 // header words written by the layout kernel (device resident, read by probes)
-enum { HDR_SH0 = 0, HDR_NLEV = 1, HDR_NBINS = 2, HDR_CS = 3, HDR_NREG = 4, HDR_LEVCNT = 8 /* .. +IVX_MAXL */, HDR_WORDS = 8 + IVX_MAXL };
+enum { HDR_SH0 = 0, HDR_NLEV = 1, HDR_NBINS = 2, HDR_CS = 3 /* log2(cells per region) or ~0u */, HDR_NREG = 4,
+       HDR_RCELLS = 5 /* cells per region */, HDR_RMUL_LO = 6, HDR_RMUL_HI = 7 /* ceil(2^40 / cells per region) */, HDR_LEVCNT = 8 /* .. +IVX_MAXL */, HDR_WORDS = 8 + IVX_MAXL };
 #define IVX_MAXREG 255   // probe regions routed with ONE partition pass (one radix digit; 255 = rows that cannot match)
+#define IVX_MAXREG_WIDE 1023   // ... still one pass, with 1024 digits (overlap join count / fill only)
 #define IVX_MAXREG2 65025u   // most regions at all: beyond 255 the probe rows are routed by a two-digit stable sort
 #define IVX_REG_CS_MAX 13   // a region spans at most 2^13 level-0 cells, what a workgroup can stage in LDS
 

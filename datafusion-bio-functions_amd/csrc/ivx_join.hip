@@ -35,7 +35,7 @@ __device__ __forceinline__ u32 cells_of(u32 cnt, u32 span, u32 sh) { return cnt 
 // lay out the (level,key) cell ranges.  hdr: sh0, #levels, #cells.
 __global__ __launch_bounds__(1024) void k_join_layout(const i32 *kmin, const i32 *kmax, const u32 *kcnt, u32 nkeys, u64 n,
                                                       i32 *origin, u32 *span, u32 *lbase, u32 *hdr, u64 maxcells,
-                                                      u32 *kreg, u32 *rkey, const u32 *lenhist)
+                                                      u32 *kreg, u32 *rkey, const u32 *lenhist, u32 regmax)
 {
     __shared__ u64 red[1024 / IVX_WAVE + 1];
     __shared__ u32 s_sh0;
@@ -106,6 +106,9 @@ __global__ __launch_bounds__(1024) void k_join_layout(const i32 *kmin, const i32
     if (t == 0) {
         u32 bi = 0;
         for (u32 c = 1; c < 32; c++) if (s_cost[c] < s_cost[bi]) bi = c;
+#ifdef IVX_SH_BIAS                                              // experiments: shift the choice by a fixed amount
+        { const int b2 = (int)bi + (IVX_SH_BIAS); bi = b2 < 0 ? 0u : (s_shb + (u32)b2 > 31 ? 31 - s_shb : (u32)b2); }
+#endif
         s_sh0 = s_shb + bi; s_occ0 = s_cocc[bi];
     }
     __syncthreads();
@@ -155,23 +158,51 @@ __global__ __launch_bounds__(1024) void k_join_layout(const i32 *kmin, const i32
     // regions wider than 2^IVX_REG_CS_MAX cells cannot be staged in LDS: take more, narrower regions instead
     // (the probe rows are then routed by a two-digit sort), as long as their number stays within IVX_MAXREG2
     if (clo > IVX_REG_CS_MAX && clo <= 32 && s_tot[IVX_REG_CS_MAX] <= IVX_MAXREG2) clo = IVX_REG_CS_MAX;
-    // ... and so can regions that hold more level-0 rows than the slice has room for (IVX_RP_ECAP): when an
-    // average region would overflow, shrink the regions until ~0.7 of the capacity is used on average
-    if (clo < 32 && s_occ0 * (float)(1u << clo) > (float)IVX_RP_ECAP) {
-        u32 c = clo;
-        while (c > 0 && s_occ0 * (float)(1u << c) > 0.7f * (float)IVX_RP_ECAP) c--;
-        while (c < clo && s_tot[c] > IVX_MAXREG2) c++;
-        clo = c;
+    // Cells per region R: 2^clo, unless an average region of that size holds more level-0 rows than the LDS slice
+    // has room for (IVX_RP_ECAP).  Then R is whatever fills ~0.85 of the slice -- any integer, not a power of two
+    // (a power of two would waste up to half of the capacity and double the number of regions, and 1023 regions
+    // is where the one-pass routing of the probe rows ends): region = cell / R by multiplication with
+    // M = ceil(2^40 / R), exact while cell * R < 2^40.
+    u64 R = clo < 32 ? (1ull << clo) : 0;
+    bool pow2 = true;
+    if (clo < 32 && s_occ0 * (float)R > 0.9f * (float)IVX_RP_ECAP) {
+        const float want = 0.85f * (float)IVX_RP_ECAP / s_occ0;
+        R = want < 1.f ? 1ull : (u64)want;
+        pow2 = false;
     }
-    const u32 cs = clo;                                             // 32 = not even one region per key fits
+    auto regions_for = [&](u64 r) -> u64 {                          // sum over keys of ceil(cells / r); workgroup-uniform
+        u64 a = 0;
+        for (u32 k = t; k < nkeys; k += 1024) { const u64 c = cells_of(kcnt[k], span[k], sh0); a += (c + r - 1) / r; }
+        return block_sum<u64, 1024>(a, red);
+    };
+    if (R) {
+        while (regions_for(R) > regmax) { R *= 2; }                     // the caller's tables hold regmax regions
+        if (!pow2) {
+            u64 mc = 0;
+            for (u32 k = t; k < nkeys; k += 1024) { const u64 c = cells_of(kcnt[k], span[k], sh0); mc = c > mc ? c : mc; }
+            __shared__ u64 s_mc;
+            if (t == 0) s_mc = 0;
+            __syncthreads();
+            atomicMax((unsigned long long *)&s_mc, (unsigned long long)mc);
+            __syncthreads();
+            const u64 M = ((1ull << 40) + R - 1) / R;
+            if (s_mc * R >= (1ull << 40) || s_mc > (1ull << 63) / M || (R & (R - 1)) == 0) {   // not exact / overflow (or R is a power of two after all)
+                u64 p = 1; while (p * 2 <= R) p *= 2;
+                R = p; pow2 = true;
+                while (regions_for(R) > regmax) R *= 2;
+            }
+        }
+    }
+    u32 cs = 32;
+    if (R && pow2) { cs = 0; while ((1ull << cs) < R) cs++; }
     u64 rrun = 0;
     for (u32 k0 = 0; k0 < nkeys; k0 += 1024) {
         const u32 k = k0 + t;
         u64 c = k < nkeys ? cells_of(kcnt[k], span[k], sh0) : 0u;
-        c = cs >= 32 ? 0 : ((c + (1ull << cs) - 1) >> cs);
+        c = R ? (c + R - 1) / R : 0;
         u64 tot;
         const u64 ex = block_excl_scan<u64, 1024>(c, red, &tot);
-        if (k < nkeys && cs < 32) {
+        if (k < nkeys && R) {
             kreg[k] = (u32)(rrun + ex);
             for (u64 r = 0; r < c; r++) rkey[rrun + ex + r] = k;
         }
@@ -179,8 +210,11 @@ __global__ __launch_bounds__(1024) void k_join_layout(const i32 *kmin, const i32
     }
     if (t == 0) {
         kreg[nkeys] = (u32)rrun;
-        hdr[HDR_CS] = cs;
-        hdr[HDR_NREG] = cs < 32 ? (u32)rrun : 0u;
+        hdr[HDR_CS] = pow2 ? cs : 0xFFFFFFFFu;
+        hdr[HDR_NREG] = R ? (u32)rrun : 0u;
+        hdr[HDR_RCELLS] = (u32)(R > 0xFFFFFFFFull ? 0xFFFFFFFFull : R);
+        const u64 M = R ? ((1ull << 40) + R - 1) / R : 0;
+        hdr[HDR_RMUL_LO] = (u32)M; hdr[HDR_RMUL_HI] = (u32)(M >> 32);
     }
 }
 
@@ -190,12 +224,14 @@ __global__ __launch_bounds__(256) void k_join_regdesc(const i32 *origin, const u
 {
     const u32 r = threadIdx.x + blockIdx.x * 256;
     if (r >= hdr[HDR_NREG]) return;
-    const u32 sh0 = hdr[HDR_SH0], cs = hdr[HDR_CS];
+    const u32 sh0 = hdr[HDR_SH0];
+    const u64 R = hdr[HDR_RCELLS];
     ivx_regdesc d;
     d.k = rkey[r]; d.origin = origin[d.k]; d.span = span[d.k]; d.lb = lbase[d.k];
     const u32 cells0 = (d.span >> sh0) + 1u;
-    const u32 rc0 = (r - kreg[d.k]) << cs;
-    const u64 rc1w = (u64)rc0 + (1ull << cs);
+    const u64 rc0w = (u64)(r - kreg[d.k]) * R;                  // < cells0: the region exists
+    const u32 rc0 = (u32)rc0w;
+    const u64 rc1w = rc0w + R;
     const u32 rc1 = rc1w < cells0 ? (u32)rc1w : cells0;
     d.slo = rc0 ? rc0 - 1u : 0u;                      // a build row starts at most one cell before the cell it reaches into
     d.shi = rc1 + IVX_RP_HALO < cells0 ? rc1 + IVX_RP_HALO : cells0;
@@ -331,7 +367,9 @@ ivx_status ivx_join_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32
     IVX_TRY(ivx_index_alloc(ctx, ix, HDR_WORDS * sizeof(u32), (void **)&hdr));
     IVX_TRY(ivx_index_alloc(ctx, ix, ((size_t)nkeys + 1) * sizeof(u32), (void **)&kreg));
     // region tables: 256 entries cover the one-digit scheme; big build sides may need up to IVX_MAXREG2
-    const size_t regcap = (maxcells >> IVX_REG_CS_MAX) + nkeys + 2 > IVX_MAXREG + 1 ? (size_t)IVX_MAXREG2 + 1 : (size_t)IVX_MAXREG + 1;
+    // region tables: regions hold ~0.85 * IVX_RP_ECAP level-0 rows or 2^IVX_REG_CS_MAX cells, and at least one per key
+    size_t regcap = (size_t)(n / (IVX_RP_ECAP / 2)) + (size_t)(maxcells >> IVX_REG_CS_MAX) + 2 * (size_t)nkeys + 64;
+    regcap = regcap <= IVX_MAXREG + 1 ? (size_t)IVX_MAXREG + 1 : (regcap > (size_t)IVX_MAXREG2 + 1 ? (size_t)IVX_MAXREG2 + 1 : regcap);
     IVX_TRY(ivx_index_alloc(ctx, ix, regcap * sizeof(u32), (void **)&rkey));
     IVX_TRY(ivx_index_alloc(ctx, ix, regcap * sizeof(ivx_regdesc), (void **)&rdesc));
     IVX_TRY(ivx_index_alloc(ctx, ix, (n ? n : 1) * sizeof(ivx_ent), (void **)&ent));
@@ -350,7 +388,7 @@ ivx_status ivx_join_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32
     IVX_HIP(ctx, hipMemsetAsync(hdr, 0, HDR_WORDS * sizeof(u32), st));
     IVX_TRY(ivx_keystats_len(ctx, key, s, n, nkeys, kmin, kmax, kcnt, errflag, 1u, e, lenhist));   // + the length classes for the layout
     const u32 grid = ivx_stream_grid(n, BT * 8, 1024);
-    hipLaunchKernelGGL(k_join_layout, dim3(1), dim3(1024), 0, st, kmin, kmax, kcnt, nkeys, n, origin, span, lbase, hdr, maxcells, kreg, rkey, (const u32 *)lenhist);
+    hipLaunchKernelGGL(k_join_layout, dim3(1), dim3(1024), 0, st, kmin, kmax, kcnt, nkeys, n, origin, span, lbase, hdr, maxcells, kreg, rkey, (const u32 *)lenhist, (u32)(regcap - 1));
     hipLaunchKernelGGL(k_join_count, dim3(grid), dim3(BT), 0, st, key, s, e, n, nkeys, origin, lbase, hdr, binstart, cellid, rank);
     IVX_TRY(ivx_scan_exclusive_u32(ctx, binstart, maxcells + 1));
     hipLaunchKernelGGL(k_join_scatter, dim3(grid), dim3(BT), 0, st, s, e, n, (const u32 *)binstart, (const u32 *)cellid, (const u32 *)rank, ent);

@@ -20,6 +20,7 @@
 //
 // HBM traffic per probe row: 8 B (hist) + 12 B + 12 B (scatter) + 12 B (probe) +
 // 8 B per pair, all streaming (measured: profiles/r1_d_regions_pipeline_pmc.txt).
+#include <type_traits>
 #include "ivx_join.hpp"
 #include "ivx_sort.hpp"
 #include <cstdlib>
@@ -50,12 +51,14 @@ constexpr u32 KT_MAX = 256;                       // per-key tables cached in LD
 // per-key lookup for "which region does a probe row start in", cached in LDS
 struct KeyTab {
     const i32 *origin; const u32 *lastcell; const u32 *kreg;   // lastcell = 0xFFFFFFFF: key has no build rows
-    u32 nkeys, sh0, cs;
+    u32 nkeys, sh0, cs;          // cs = log2(cells per region), or ~0u: divide by multiplying with rmul
+    u64 rmul;
 };
 
 __device__ __forceinline__ void keytab_load(const JoinIndexView &ix, i32 *s_origin, u32 *s_last, u32 *s_kreg, KeyTab &kt)
 {
     kt.nkeys = ix.nkeys; kt.sh0 = ix.hdr[HDR_SH0]; kt.cs = ix.hdr[HDR_CS];
+    kt.rmul = (u64)ix.hdr[HDR_RMUL_LO] | ((u64)ix.hdr[HDR_RMUL_HI] << 32);
     if (ix.nkeys <= KT_MAX) {
         for (u32 k = threadIdx.x; k < ix.nkeys; k += blockDim.x) {
             s_origin[k] = ix.origin[k];
@@ -79,7 +82,7 @@ __device__ __forceinline__ u32 region_of(const JoinIndexView &ix, const KeyTab &
     const i64 d = (i64)qs - (i64)origin;
     const i64 c64 = d <= 0 ? 0 : (d >> kt.sh0);
     const u32 c = c64 > (i64)last ? last : (u32)c64;
-    return kreg + (c >> kt.cs);
+    return kreg + (kt.cs != 0xFFFFFFFFu ? c >> kt.cs : (u32)(((u64)c * kt.rmul) >> 40));   // k_join_layout guarantees exactness
 }
 
 // LDS counter bump that returns the old value.  Sorted / clustered probe input sends a whole wavefront to
@@ -129,17 +132,19 @@ __device__ __forceinline__ void load4(const u32 *__restrict__ pkey, const i32 *_
 // a row of a smaller region after a larger one, or a row that cannot be routed.  If it stays 0 (probe input
 // sorted by contig id and start: the usual state of genomic files) the partitioned order IS the input order
 // and the scatter pass is skipped altogether.
-template <bool VEC>
+// ND = digits of the pass: 256 for up to IVX_MAXREG regions, 1024 for up to IVX_MAXREG_WIDE (build sides of a few
+// million rows: four times the table, shorter runs in the scatter, still one pass)
+template <bool VEC, int ND>
 __global__ __launch_bounds__(PA_T) void k_part_hist(JoinIndexView ix, const u32 *__restrict__ pkey, const i32 *__restrict__ ps,
                                                     u64 n, u32 nblk, u32 chunk, u32 *__restrict__ hist, u32 adj, u32 *unsorted)
 {
-    __shared__ u32 cnt[256];
+    __shared__ u32 cnt[ND];
     __shared__ i32 s_origin[KT_MAX];
     __shared__ u32 s_last[KT_MAX], s_kreg[KT_MAX];
     __shared__ u32 s_unsorted;
     KeyTab kt;
     keytab_load(ix, s_origin, s_last, s_kreg, kt);
-    if (threadIdx.x < PA_ND) cnt[threadIdx.x] = 0;
+    if (threadIdx.x < ND) cnt[threadIdx.x] = 0;
     if (threadIdx.x == 0) s_unsorted = 0;
     __syncthreads();
     const u64 lo = (u64)blockIdx.x * chunk;
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(PA_T) void k_part_hist(JoinIndexView ix, const u32 
         }
     }
     __syncthreads();
-    if (threadIdx.x < PA_ND) hist[(u64)threadIdx.x * nblk + blockIdx.x] = cnt[threadIdx.x];
+    if (threadIdx.x < ND) hist[(u64)threadIdx.x * nblk + blockIdx.x] = cnt[threadIdx.x];
     if (threadIdx.x == 0 && s_unsorted) *unsorted = 1;
 }
 
@@ -179,15 +184,16 @@ __global__ __launch_bounds__(PA_T) void k_part_hist(JoinIndexView ix, const u32 
 // RowT = u32: the row's index in the probe batch (join: it goes into the pair list);
 // RowT = u16: its index inside this workgroup's chunk of at most two tiles (per-row-output operators: k_unpermute
 // puts the chunk back in input order through LDS, so the chunk-local index is all that is needed)
-template <bool VEC, typename RowT>
+template <bool VEC, typename RowT, int ND>
 __global__ __launch_bounds__(PA_T) void k_part_scatter(JoinIndexView ix, const u32 *__restrict__ pkey, const i32 *__restrict__ ps,
                                                        const i32 *__restrict__ pe, u64 n, u32 nblk, const u32 *__restrict__ offs,
                                                        u64 *__restrict__ out_se, RowT *__restrict__ out_row, u32 chunk, u32 adj, const u32 *unsorted, int dbg)
 {
     __shared__ u64 r_se[PA_TILE];
     __shared__ unsigned short r_slot[PA_TILE];          // the row's slot in the tile (its row id follows from it)
-    __shared__ unsigned char r_dig[PA_TILE];
-    __shared__ u32 tcnt[256], dstart[256], gbase[256];
+    using DigT = typename std::conditional<(ND > 256), unsigned short, unsigned char>::type;
+    __shared__ DigT r_dig[PA_TILE];
+    __shared__ u32 dstart[ND], gbase[ND];              // dstart: the tile's counters first, then (in place) their exclusive scan
     __shared__ u32 scan_lds[PA_T / IVX_WAVE + 1];
     __shared__ i32 s_origin[KT_MAX];
     __shared__ u32 s_last[KT_MAX], s_kreg[KT_MAX];
@@ -197,11 +203,11 @@ __global__ __launch_bounds__(PA_T) void k_part_scatter(JoinIndexView ix, const u
     if (*unsorted == 0) return;                             // input already in region order: nothing to move
     KeyTab kt;
     keytab_load(ix, s_origin, s_last, s_kreg, kt);
-    if (tid < PA_ND) gbase[tid] = offs[(u64)tid * nblk + blockIdx.x];
+    if (tid < ND) gbase[tid] = offs[(u64)tid * nblk + blockIdx.x];
     const u64 lo = (u64)blockIdx.x * chunk;
     const u64 hi = lo + chunk < n ? lo + chunk : n;
     for (u64 t0 = lo; t0 < hi; t0 += PA_TILE) {
-        if (tid < PA_ND) tcnt[tid] = 0;
+        if (tid < ND) dstart[tid] = 0;
         __syncthreads();
         u64 se[PA_I]; u32 dig[PA_I], lrank[PA_I];
         u32 kk[PA_I]; i32 qs[PA_I], qe[PA_I];
@@ -219,13 +225,13 @@ __global__ __launch_bounds__(PA_T) void k_part_scatter(JoinIndexView ix, const u
             se[k] = (u64)(u32)qs[k] | ((u64)(u32)qe[k] << 32);
             const u32 d = region_of(ix, kt, kk[k], qs[k]);
             dig[k] = d;
-            lrank[k] = lds_count_up(tcnt, d, d != NO_REGION);
+            lrank[k] = lds_count_up(dstart, d, d != NO_REGION);
         }
         __syncthreads();
         u32 tot;
-        const u32 mine = tid < PA_ND ? tcnt[tid] : 0u;
-        const u32 ds = block_excl_scan<u32, PA_T>(mine, scan_lds, &tot);
-        if (tid < PA_ND) dstart[tid] = ds;
+        const u32 mine = tid < ND ? dstart[tid] : 0u;
+        const u32 ds = block_excl_scan<u32, PA_T>(mine, scan_lds, &tot);     // (barriers inside: every counter is read before any is overwritten)
+        if (tid < ND) dstart[tid] = ds;
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < PA_I; k++) {
@@ -233,7 +239,7 @@ __global__ __launch_bounds__(PA_T) void k_part_scatter(JoinIndexView ix, const u
                 const u32 pos = dstart[dig[k]] + lrank[k];
                 r_se[pos] = se[k];
                 r_slot[pos] = (unsigned short)(((k / 4) * PA_T + tid) * 4 + (k % 4));
-                r_dig[pos] = (unsigned char)dig[k];
+                r_dig[pos] = (DigT)dig[k];
             }
         }
         __syncthreads();
@@ -251,7 +257,7 @@ __global__ __launch_bounds__(PA_T) void k_part_scatter(JoinIndexView ix, const u
             }
         }
         __syncthreads();
-        if (tid < PA_ND) gbase[tid] += mine;
+        if (tid < ND) gbase[tid] += mine;
     }
 }
 
@@ -591,8 +597,8 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
     const u32 wv = threadIdx.x / IVX_WAVE, ln = lane_id();
     const u32 nreg = ix.hdr[HDR_NREG];
     // first partitioned row of every region, once, in LDS (the share boundaries below search it)
-    __shared__ u32 s_rfirst[IVX_MAXREG + 2];
-    const bool rf_lds = nreg <= IVX_MAXREG;                           // (the two-digit scheme has up to 65025 regions: global table)
+    __shared__ u32 s_rfirst[IVX_MAXREG_WIDE + 2];
+    const bool rf_lds = nreg <= IVX_MAXREG_WIDE;                           // (the two-digit scheme has up to 65025 regions: global table)
     if (rf_lds) for (u32 t = threadIdx.x; t <= nreg; t += RP_T) s_rfirst[t] = offs[(u64)t * nblk];
     __syncthreads();
     auto rfirst = [&](u32 r) -> u32 { return rf_lds ? s_rfirst[r] : offs[(u64)r * nblk]; };
@@ -782,11 +788,11 @@ ivx_status ivx_rowval_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, int k
     const bool vec = (((uintptr_t)key | (uintptr_t)s | (uintptr_t)e) & 15) == 0;
     u32 *unsorted = (u32 *)(ctx->d_scalars + 10);                       // stays 0 if the rows already come in region order
     IVX_HIP(ctx, hipMemsetAsync(unsorted, 0, sizeof(u32), st));
-    if (vec) hipLaunchKernelGGL(k_part_hist<true>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, n, nblk, chunk, hist, adj, unsorted);
-    else hipLaunchKernelGGL(k_part_hist<false>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, n, nblk, chunk, hist, adj, unsorted);
+    if (vec) hipLaunchKernelGGL((k_part_hist<true, PA_ND>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, n, nblk, chunk, hist, adj, unsorted);
+    else hipLaunchKernelGGL((k_part_hist<false, PA_ND>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, n, nblk, chunk, hist, adj, unsorted);
     IVX_TRY(ivx_scan_exclusive_u32(ctx, hist, nh));
-    if (vec) hipLaunchKernelGGL((k_part_scatter<true, unsigned short>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, cidx, chunk, adj, (const u32 *)unsorted, 0);
-    else hipLaunchKernelGGL((k_part_scatter<false, unsigned short>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, cidx, chunk, adj, (const u32 *)unsorted, 0);
+    if (vec) hipLaunchKernelGGL((k_part_scatter<true, unsigned short, PA_ND>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, cidx, chunk, adj, (const u32 *)unsorted, 0);
+    else hipLaunchKernelGGL((k_part_scatter<false, unsigned short, PA_ND>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, cidx, chunk, adj, (const u32 *)unsorted, 0);
 #define IVX_RV(M_, ID_) hipLaunchKernelGGL((k_probe_regions<M_, RP_B, ID_>), dim3(RP_VGRID), dim3(RP_T), 0, st, jv, ID_ ? (const void *)s : (const void *)pse, ID_ ? (const void *)e : (const void *)nullptr, (const u32 *)hist, nblk, 1u, val, (u32 *)nullptr, (u64)0, (unsigned long long *)nullptr, 1u, adj, (const u32 *)unsorted, 0)
     if (kind == IVX_RV_COVERAGE) { IVX_RV(RV_COVERAGE, false); IVX_RV(RV_COVERAGE, true); }
     else if (kind == IVX_RV_COUNT) { IVX_RV(RV_COUNT, false); IVX_RV(RV_COUNT, true); }
@@ -877,7 +883,7 @@ ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nre
 {
     if (n == 0) return IVX_OK;
     ivx_join_plan &pl = ctx->join_plan;
-    if (nreg > IVX_MAXREG) {
+    if (nreg > IVX_MAXREG_WIDE) {
         if (planned) return ctx->fail(IVX_ERR_INVALID, "join plan for a two-digit region table");   // never recorded
         return probe_wide(ctx, jv, mode, nreg, key, s, e, n, ob, op, cap, d_cursor);
     }
@@ -897,18 +903,21 @@ ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nre
     } else {
         chunk = part_chunk(n);
         nblk = (u32)((n + chunk - 1) / chunk);
-        const u64 nh = (u64)256 * nblk + 1;
+        const bool wide = nreg > IVX_MAXREG;                // 1024 digits instead of 256
+        const u64 nh = (u64)(wide ? 1024 : 256) * nblk + 1;
         IVX_TRY(ctx->get_scratch(WS_SORTHIST, nh * sizeof(u32), (void **)&hist));
         IVX_TRY(ctx->get_scratch(WS_T0, n * sizeof(u64), (void **)&pse));
         IVX_TRY(ctx->get_scratch(WS_T1, n * sizeof(u32), (void **)&prow));
         IVX_HIP(ctx, hipMemsetAsync(hist + (nh - 1), 0, sizeof(u32), st));
         const bool vec = (((uintptr_t)key | (uintptr_t)s | (uintptr_t)e) & 15) == 0;
         IVX_HIP(ctx, hipMemsetAsync(unsorted, 0, sizeof(u32), st));
-        if (vec) hipLaunchKernelGGL(k_part_hist<true>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, n, nblk, chunk, hist, 0u, unsorted);
-        else hipLaunchKernelGGL(k_part_hist<false>, dim3(nblk), dim3(PA_T), 0, st, jv, key, s, n, nblk, chunk, hist, 0u, unsorted);
-        IVX_TRY(ivx_scan_exclusive_u32(ctx, hist, nh));
-        if (vec) hipLaunchKernelGGL((k_part_scatter<true, u32>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, prow, chunk, 0u, (const u32 *)unsorted, dbg);
-        else hipLaunchKernelGGL((k_part_scatter<false, u32>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, prow, chunk, 0u, (const u32 *)unsorted, dbg);
+#define IVX_PART(V_, ND_) do { \
+        hipLaunchKernelGGL((k_part_hist<V_, ND_>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, n, nblk, chunk, hist, 0u, unsorted); \
+        IVX_TRY(ivx_scan_exclusive_u32(ctx, hist, nh)); \
+        hipLaunchKernelGGL((k_part_scatter<V_, u32, ND_>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, prow, chunk, 0u, (const u32 *)unsorted, dbg); } while (0)
+        if (wide) { if (vec) IVX_PART(true, 1024); else IVX_PART(false, 1024); }
+        else { if (vec) IVX_PART(true, 256); else IVX_PART(false, 256); }
+#undef IVX_PART
         if (mode == JP_COUNT) {
             // leave the routed rows for the fill call (ivx_capi.hip fills in whose columns they are)
             pl.hist = hist; pl.pse = pse; pl.prow = prow; pl.ds = s; pl.de = e; pl.chunk = chunk; pl.nblk = nblk;
