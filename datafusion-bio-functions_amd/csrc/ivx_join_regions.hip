@@ -690,6 +690,136 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
     if (FILL && round && !(dbg & 32)) round_copy_out(L, pend_mine, pend_start, round - 1, wv, ob, op, cap, dbg);
 }
 
+// ------------------------------------------------------------------ match-dense fill: count, scan, write
+// With several pairs per probe row the staging ring holds only one 64-row batch per wavefront and the 16
+// wavefronts of a workgroup end up in lock step, round after round.  For such joins the pairs are written in two
+// passes over the same decomposition instead, with no ring, no atomics and no synchronisation between wavefronts:
+//   piece   = the rows of one 64-row granule [64g, 64g+64) of the partitioned order that belong to region r
+//             (row shares start at multiples of 64, so a piece has ONE owner); slot(piece) = g + r, which grows
+//             strictly along the row order
+//   PASS 0  every piece's pair count goes to pcount[slot]; an exclusive scan turns it into output offsets
+//   PASS 1  the piece is walked again in lock step (every lane steps through its candidates together); the lanes
+//           that match in a step take consecutive positions after the piece's running offset by ballot rank, so
+//           the stores of a step are contiguous.  Order inside a piece is arbitrary, like everywhere else.
+template <int PASS, bool IDENT>
+__global__ __launch_bounds__(RP_T) void k_probe_dense(JoinIndexView ix, const void *__restrict__ rows_a, const void *__restrict__ rows_b,
+                                                      const u32 *__restrict__ offs, u32 nblk, u32 prow_stride, const u32 *unsorted,
+                                                      u64 *__restrict__ pcount, u32 *__restrict__ ob, u32 *__restrict__ op, u64 cap)
+{
+    if ((unsorted != nullptr && *unsorted == 0) != IDENT) return;
+    auto row_se = [&](u64 i) -> u64 {
+        if (IDENT) return (u64)(u32)((const i32 *)rows_a)[i] | ((u64)(u32)((const i32 *)rows_b)[i] << 32);
+        return ((const u64 *)rows_a)[i];
+    };
+    auto row_id = [&](u64 i) -> u32 { return IDENT ? (u32)i : ((const u32 *)rows_b)[i * prow_stride]; };
+    __shared__ unsigned short s_off[RP_CCAP];
+    __shared__ u64 s_ent[RP_ECAP];
+    __shared__ u32 s_row[RP_ECAP];
+    __shared__ u32 s_rfirst[IVX_MAXREG_WIDE + 2];
+    ProbeLds L{s_off, s_ent, s_row, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const u32 wv = threadIdx.x / IVX_WAVE, ln = lane_id();
+    const u32 nreg = ix.hdr[HDR_NREG];
+    const bool rf_lds = nreg <= IVX_MAXREG_WIDE;
+    if (rf_lds) for (u32 t = threadIdx.x; t <= nreg; t += RP_T) s_rfirst[t] = offs[(u64)t * nblk];
+    __syncthreads();
+    auto rfirst = [&](u32 r) -> u32 { return rf_lds ? s_rfirst[r] : offs[(u64)r * nblk]; };
+    const u64 total_rows = rfirst(nreg);
+    const u32 nvb = gridDim.x, vb = blockIdx.x;
+    u64 lo = (total_rows * vb / nvb) & ~63ull;
+    const u64 hi = vb + 1 == nvb ? total_rows : ((total_rows * (vb + 1) / nvb) & ~63ull);
+    if (lo >= hi) return;
+    Slice S;
+    slice_init(ix, S, L);
+    u32 r;
+    { u32 a = 0, b = nreg; while (a < b) { const u32 m = (a + b + 1) >> 1; if (rfirst(m) <= lo) a = m; else b = m - 1; } r = a; }
+    for (; lo < hi; r++) {
+        const u64 rend = rfirst(r + 1);
+        const u64 c_hi = hi < rend ? hi : rend;
+        if (c_hi <= lo) continue;
+        const u64 g1 = (c_hi + 63) >> 6;
+        u64 g = (lo >> 6) + wv;
+        // the first granule's rows are in flight while the slice loads
+        u64 nx = 0; u32 nxr = 0;
+        { const u64 i = g * 64 + ln; const bool ok = g < g1 && i >= lo && i < c_hi; nx = ok ? row_se(i) : 0; nxr = (PASS == 1 && ok) ? row_id(i) : 0u; }
+        slice_load(ix, S, L, r, true);
+        for (; g < g1; g += RP_W) {
+            const u64 i = g * 64 + ln;
+            const bool ok = i >= lo && i < c_hi;
+            const i32 qs = (i32)(u32)nx, qe = (i32)(u32)(nx >> 32);
+            const u32 rowv = nxr;
+            { const u64 g2 = g + RP_W; const u64 i2 = g2 * 64 + ln; const bool ok2 = g2 < g1 && i2 >= lo && i2 < c_hi; nx = ok2 ? row_se(i2) : 0; nxr = (PASS == 1 && ok2) ? row_id(i2) : 0u; }
+            const u64 slot = g + r;
+            if (PASS == 0) {
+                u32 c = 0;
+                if (ok) probe_row(S, qs, qe, [&](u32, bool, i32, i32) { c++; });
+                const u64 tot = wave_sum((u64)c);
+                if (ln == 0) pcount[slot] = tot;
+                continue;
+            }
+            u64 base = pcount[slot];                                   // (scanned) the same for every lane
+            // lock-step walk of one candidate list per lane: [ja, jb) of the staged slice or of the index in HBM
+            auto walk = [&](u32 ja, u32 jb, bool lds) {
+                while (__any(ja < jb)) {
+                    bool hit = false; u32 brow = 0;
+                    if (ja < jb) {
+                        if (lds) { const u64 x = S.s_ent[ja]; hit = (i32)(u32)x <= qe && (i32)(u32)(x >> 32) >= qs; if (hit) brow = S.s_row[ja]; }
+                        else { const ivx_ent x = ix.ent[ja]; hit = x.s <= qe && x.e >= qs; brow = x.row; }
+                        ja++;
+                    }
+                    const u64 m = __ballot(hit);
+                    if (hit) { const u64 pos = base + mask_rank(m); if (pos < cap) { ob[pos] = brow; op[pos] = rowv; } }
+                    base += (u64)__popcll(m);
+                }
+            };
+            const i64 hi64 = (i64)qe - (i64)S.origin;
+            const bool live = ok && hi64 >= 0;
+            {   // level 0
+                u32 ja = 0, jb = 0; bool lds = false;
+                if (live && S.lev0) {
+                    const u32 ncell = S.ncell0;
+                    const i64 lo64 = (i64)qs - ((i64)1 << S.sh0) + 1 - (i64)S.origin;
+                    const i64 bl = lo64 <= 0 ? 0 : (lo64 >> S.sh0);
+                    if (bl < (i64)ncell) {
+                        const u32 blo = (u32)bl;
+                        const i64 bh = hi64 >> S.sh0;
+                        const u32 bhi = bh >= (i64)ncell ? ncell - 1u : (u32)bh;
+                        if (blo <= bhi) {
+                            lds = S.inlds && blo >= S.slo && bhi < S.shi;
+                            if (lds) { ja = S.s_off[blo - S.slo]; jb = S.s_off[bhi + 1 - S.slo]; }
+                            else { ja = ix.binstart[S.lb + blo]; jb = ix.binstart[S.lb + bhi + 1]; }
+                        }
+                    }
+                }
+                // lanes of one wavefront may differ in where their list lives (a row reaching past the slice): two rounds
+                const u32 la = lds ? ja : 0u, lb = lds ? jb : 0u, ga = lds ? 0u : ja, gb = lds ? 0u : jb;
+                walk(la, lb, true);
+                if (__any(ga < gb)) walk(ga, gb, false);
+            }
+            if (S.upper) {
+                for (u32 l = 1; l < S.nlev; l++) {
+                    if (ix.hdr[HDR_LEVCNT + l] == 0) continue;
+                    const u32 sh = S.sh0 + IVX_LSTEP * l;
+                    u32 ja = 0, jb = 0;
+                    if (live) {
+                        u32 blo = 0, bhi = 0; bool any = true;
+                        if (sh < 32) {
+                            const u32 ncell = (S.span >> sh) + 1u;
+                            const i64 lo64 = (i64)qs - ((i64)1 << sh) + 1 - (i64)S.origin;
+                            const i64 bl = lo64 <= 0 ? 0 : (lo64 >> sh);
+                            const i64 bh = hi64 >> sh;
+                            if (bl >= (i64)ncell) any = false;
+                            else { blo = (u32)bl; bhi = bh >= (i64)ncell ? ncell - 1u : (u32)bh; if (blo > bhi) any = false; }
+                        }
+                        if (any) { const u32 lbase = ix.lbase[(u64)l * ix.nkeys + S.k]; ja = ix.binstart[lbase + blo]; jb = ix.binstart[lbase + bhi + 1]; }
+                    }
+                    if (__any(ja < jb)) walk(ja, jb, false);
+                }
+            }
+        }
+        lo = c_hi;
+    }
+}
+
 // fill pass: rows per lane and batch from the expected matches per row (cap / n)
 static inline int fill_rows_per_lane(u64 cap, u64 n)
 {
@@ -845,6 +975,35 @@ __global__ __launch_bounds__(WR_T) void k_region_bounds(const u64 *__restrict__ 
     rfirst[r] = (u32)lo;
 }
 
+// match-dense fill (k_probe_dense): count the pieces, scan, write.  rows/ident: the partitioned rows and row ids, and --
+// when the partition may have found the input already in region order (`unsorted` given) -- the input start / end columns
+static bool dense_fill_wanted(u64 cap, u64 n)
+{
+    if (const char *f = getenv("IVX_DENSE")) return atoi(f) != 0;          // tests / experiments
+    return (double)cap / (double)n > 3.5;                                  // measured crossover (tools/probe_only.py IVX_DENSE=0/1): the ring wins below
+}
+
+ivx_status dense_fill(ivx_ctx *ctx, const JoinIndexView &jv, u32 nreg, const void *rows_se, const void *rows_id, u32 prow_stride,
+                      const i32 *s, const i32 *e, const u32 *offs, u32 nblk, const u32 *unsorted, u64 n,
+                      u32 *ob, u32 *op, u64 cap, u64 *d_cursor)
+{
+    hipStream_t st = ctx->stream;
+    const u64 slots = (n >> 6) + nreg + 3;
+    u64 *pcount;
+    IVX_TRY(ctx->get_scratch(WS_T3, slots * sizeof(u64), (void **)&pcount));
+    IVX_HIP(ctx, hipMemsetAsync(pcount, 0, slots * sizeof(u64), st));
+#define IVX_DENSE_PASS(P_) do { \
+        hipLaunchKernelGGL((k_probe_dense<P_, false>), dim3(RP_VGRID), dim3(RP_T), 0, st, jv, rows_se, rows_id, offs, nblk, prow_stride, unsorted, pcount, ob, op, cap); \
+        if (unsorted) hipLaunchKernelGGL((k_probe_dense<P_, true>), dim3(RP_VGRID), dim3(RP_T), 0, st, jv, (const void *)s, (const void *)e, offs, nblk, 1u, unsorted, pcount, ob, op, cap); } while (0)
+    IVX_DENSE_PASS(0);
+    IVX_TRY(ivx_scan_exclusive_u64(ctx, pcount, slots));
+    IVX_HIP(ctx, hipMemcpyAsync(d_cursor, pcount + (slots - 1), sizeof(u64), hipMemcpyDeviceToDevice, st));   // the pair total
+    IVX_DENSE_PASS(1);
+#undef IVX_DENSE_PASS
+    IVX_HIP(ctx, hipGetLastError());
+    return IVX_OK;
+}
+
 ivx_status probe_wide(ivx_ctx *ctx, const JoinIndexView &jv, int mode, u32 nreg, const u32 *key, const i32 *s, const i32 *e, u64 n,
                       u32 *ob, u32 *op, u64 cap, u64 *d_cursor)
 {
@@ -863,7 +1022,9 @@ ivx_status probe_wide(ivx_ctx *ctx, const JoinIndexView &jv, int mode, u32 nreg,
     hipLaunchKernelGGL(k_region_bounds, dim3((nreg + 1 + WR_T - 1) / WR_T), dim3(WR_T), 0, st, (const u64 *)o[1], n, nreg, rfirst);
     unsigned long long *cur = (unsigned long long *)d_cursor;
     const u32 *prow = (const u32 *)o[1];                                // low word of (region << 32 | row): stride 2
-    if (mode == JP_FILL) {
+    if (mode == JP_FILL && dense_fill_wanted(cap, n)) {
+        return dense_fill(ctx, jv, nreg, (const void *)o[0], (const void *)prow, 2u, nullptr, nullptr, (const u32 *)rfirst, 1u, nullptr, n, ob, op, cap, d_cursor);
+    } else if (mode == JP_FILL) {
         const int bsel = fill_rows_per_lane(cap, n);
 #define IVX_FILLW(B_) hipLaunchKernelGGL((k_probe_regions<1, B_, false>), dim3(RP_GRID), dim3(RP_T), 0, st, jv, (const void *)o[0], (const void *)prow, (const u32 *)rfirst, 1u, RP_VGRID / RP_GRID, ob, op, cap, cur, 2u, 0u, (const u32 *)nullptr, 0)
         switch (bsel) { case 1: IVX_FILLW(1); break; case 2: IVX_FILLW(2); break; case 4: IVX_FILLW(4); break; default: IVX_FILLW(8); }
@@ -926,7 +1087,9 @@ ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nre
         }
     }
     unsigned long long *cur = (unsigned long long *)d_cursor;
-    if (mode == JP_FILL) {   // single walk: pairs staged per wavefront, one output reservation per workgroup and round
+    if (mode == JP_FILL && dense_fill_wanted(cap, n)) {
+        return dense_fill(ctx, jv, nreg, (const void *)pse, (const void *)prow, 1u, s, e, (const u32 *)hist, nblk, (const u32 *)unsorted, n, ob, op, cap, d_cursor);
+    } else if (mode == JP_FILL) {   // single walk: pairs staged per wavefront, one output reservation per workgroup and round
         // rows per lane and batch by the expected matches per row (cap / n: callers size the output from the
         // count pass): two consecutive rounds of a wavefront must fit its 512-pair staging ring, else the
         // batch takes the slow direct path

@@ -28,8 +28,11 @@ def _check_join(ctx, bk, bs, be, pk, ps, pe, nkeys):
     assert total == len(want_b)
     assert (per_row.astype(np.uint64) == want_cnt).all()
     # both probe paths: gathers straight from the index, and region-partitioned through LDS
-    for path in ("direct", "regions"):
-        os.environ["IVX_JOIN_PATH"] = path
+    # ... and for the latter both ways of writing the pairs: staging ring (IVX_DENSE=0) and count-scan-write (1)
+    for path in ("direct", "regions", "regions-dense"):
+        os.environ["IVX_JOIN_PATH"] = path.split("-")[0]
+        if path != "direct":
+            os.environ["IVX_DENSE"] = "1" if path.endswith("dense") else "0"
         try:
             assert ctx.overlap_count(ix, pk, ps, pe) == total, path
             ob, op = ctx.overlap_fill(ix, pk, ps, pe, cap=total)
@@ -37,6 +40,7 @@ def _check_join(ctx, bk, bs, be, pk, ps, pe, nkeys):
             ex2 = ctx.exists(ix, pk, ps, pe)
         finally:
             del os.environ["IVX_JOIN_PATH"]
+            os.environ.pop("IVX_DENSE", None)
         assert len(ob) == total, path
         assert (pair_set(ob, op) == pair_set(want_b, want_p)).all(), path
         assert t2 == total and (pr2.astype(np.uint64) == want_cnt).all(), path
@@ -141,9 +145,19 @@ def test_join_regions_staging_ring_overflow(ctx):
     _check_join(ctx, z(nb, np.uint32), bs, be, z(len(ps), np.uint32), ps, pe, 1)
 
 
+def test_join_more_than_1023_regions(ctx):
+    # a build side too big for the one-pass routing: > 1023 regions, probe rows routed by the two-digit stable sort
+    bk, bs, be = synth(7_000_000, 63, nkeys=3, mean_len=200, span=240_000_000)
+    pk, ps, pe = synth(400_000, 64, nkeys=4, mean_len=150, span=240_000_000)
+    pe[::97] = ps[::97] + 30_000
+    _check_join(ctx, bk, bs, be, pk, ps, pe, 4)
+    pk, ps, pe = _sorted_by_key_start(pk, ps, pe)
+    _check_join(ctx, bk, bs, be, pk, ps, pe, 4)
+
+
 def test_join_more_than_255_regions(ctx):
-    # a build side too big for 255 LDS-sized regions: ~600 narrower regions, probe rows routed by the
-    # two-digit stable sort; three keys, rows of unknown keys, long rows, a few chromosome-long build rows
+    # a build side too big for 255 LDS-sized regions: a few hundred of them, probe rows routed in one pass with
+    # 1024 digits; three keys, rows of unknown keys, long rows, a few chromosome-long build rows
     bk, bs, be = synth(2_400_000, 61, nkeys=3, mean_len=300, span=240_000_000)
     pk, ps, pe = synth(700_000, 62, nkeys=4, mean_len=150, span=240_000_000)
     pe[::89] = ps[::89] + 50_000

@@ -43,7 +43,10 @@ for it in range(iters):
     strict = bool(rng.integers(0, 2))
     path = str(rng.choice(["direct", "regions"]))
     os.environ["IVX_JOIN_PATH"] = path; os.environ["IVX_ROWVAL_PATH"] = path
-    tag = f"it={it} nk={nk} span={span} nb={nb} np={npr} bmean={bmean} sorted={srt} strict={strict} path={path}"
+    dense = str(rng.choice(["0", "1", ""]))                       # pair writer of the region path: ring, count-scan-write, by density
+    if dense: os.environ["IVX_DENSE"] = dense
+    else: os.environ.pop("IVX_DENSE", None)
+    tag = f"it={it} nk={nk} span={span} nb={nb} np={npr} bmean={bmean} sorted={srt} strict={strict} path={path} dense={dense!r}"
     try:
         # ---- join: count, per-row, exists, fill
         ix = ctx.build(pyivx.KIND_OVERLAP, bk, bs, be, n_keys=nk)
