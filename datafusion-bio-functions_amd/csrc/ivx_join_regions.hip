@@ -756,7 +756,12 @@ __global__ __launch_bounds__(RP_T) void k_probe_dense(JoinIndexView ix, const vo
                 if (ln == 0) pcount[slot] = tot;
                 continue;
             }
-            u64 base = pcount[slot];                                   // (scanned) the same for every lane
+            // (scanned) the piece's pairs go to [base, base + its count); everything below is relative to it, in 32 bits
+            const u64 base = __builtin_amdgcn_readfirstlane((u32)pcount[slot]) | ((u64)__builtin_amdgcn_readfirstlane((u32)(pcount[slot] >> 32)) << 32);
+            u32 *const obp = ob + base, *const opp = op + base;
+            const u64 room = cap > base ? cap - base : 0;
+            const u32 lim = room > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)room;   // pairs of this piece the caller's buffers still hold
+            u32 cnt = 0;                                                // pairs of the piece written so far (wavefront-uniform)
             // lock-step walk of one candidate list per lane: [ja, jb) of the staged slice or of the index in HBM
             auto walk = [&](u32 ja, u32 jb, bool lds) {
                 while (__any(ja < jb)) {
@@ -767,8 +772,9 @@ __global__ __launch_bounds__(RP_T) void k_probe_dense(JoinIndexView ix, const vo
                         ja++;
                     }
                     const u64 m = __ballot(hit);
-                    if (hit) { const u64 pos = base + mask_rank(m); if (pos < cap) { ob[pos] = brow; op[pos] = rowv; } }
-                    base += (u64)__popcll(m);
+                    const u32 pos = cnt + mask_rank(m);
+                    if (hit && pos < lim) { obp[pos] = brow; opp[pos] = rowv; }
+                    cnt += (u32)__popcll(m);
                 }
             };
             const i64 hi64 = (i64)qe - (i64)S.origin;
