@@ -22,7 +22,6 @@
 // 8 B per pair, all streaming (measured: profiles/r1_d_regions_pipeline_pmc.txt).
 #include <type_traits>
 #include "ivx_join.hpp"
-#include "ivx_sort.hpp"
 #include <cstdlib>
 #include <cstdlib>
 
@@ -134,9 +133,13 @@ __device__ __forceinline__ void load4(const u32 *__restrict__ pkey, const i32 *_
 // and the scatter pass is skipped altogether.
 // ND = digits of the pass: 256 for up to IVX_MAXREG regions, 1024 for up to IVX_MAXREG_WIDE (build sides of a few
 // million rows: four times the table, shorter runs in the scatter, still one pass)
-template <bool VEC, int ND>
+// SPLIT (more than IVX_MAXREG_WIDE regions): the digit is the SUPER-region = region / G (G = split.x, as a
+// multiplication by split.y = ceil(2^32 / G), exact for region * G < 2^32); a second pass orders each super-region's
+// rows by region % G (k_p2_*).  Sortedness is still judged on the regions themselves.
+template <bool VEC, int ND, bool SPLIT = false>
 __global__ __launch_bounds__(PA_T) void k_part_hist(JoinIndexView ix, const u32 *__restrict__ pkey, const i32 *__restrict__ ps,
-                                                    u64 n, u32 nblk, u32 chunk, u32 *__restrict__ hist, u32 adj, u32 *unsorted)
+                                                    u64 n, u32 nblk, u32 chunk, u32 *__restrict__ hist, u32 adj, u32 *unsorted,
+                                                    uint2 split = make_uint2(1u, 0u))
 {
     __shared__ u32 cnt[ND];
     __shared__ i32 s_origin[KT_MAX];
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(PA_T) void k_part_hist(JoinIndexView ix, const u32 
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             d[u] = region_of(ix, kt, k[u], (i32)((u32)q[u] + adj));
-            lds_count_up(cnt, d[u], d[u] != NO_REGION);
+            lds_count_up(cnt, SPLIT ? (u32)(((u64)d[u] * split.y) >> 32) : d[u], d[u] != NO_REGION);
         }
         if (!s_unsorted) {                                  // (once raised nobody needs to look any further)
             bool bad = false;
@@ -184,10 +187,11 @@ __global__ __launch_bounds__(PA_T) void k_part_hist(JoinIndexView ix, const u32 
 // RowT = u32: the row's index in the probe batch (join: it goes into the pair list);
 // RowT = u16: its index inside this workgroup's chunk of at most two tiles (per-row-output operators: k_unpermute
 // puts the chunk back in input order through LDS, so the chunk-local index is all that is needed)
-template <bool VEC, typename RowT, int ND>
+template <bool VEC, typename RowT, int ND, bool SPLIT = false>
 __global__ __launch_bounds__(PA_T) void k_part_scatter(JoinIndexView ix, const u32 *__restrict__ pkey, const i32 *__restrict__ ps,
                                                        const i32 *__restrict__ pe, u64 n, u32 nblk, const u32 *__restrict__ offs,
-                                                       u64 *__restrict__ out_se, RowT *__restrict__ out_row, u32 chunk, u32 adj, const u32 *unsorted, int dbg)
+                                                       u64 *__restrict__ out_se, RowT *__restrict__ out_row, u32 chunk, u32 adj, const u32 *unsorted, int dbg,
+                                                       uint2 split = make_uint2(1u, 0u), unsigned char *__restrict__ out_sub = nullptr)
 {
     __shared__ u64 r_se[PA_TILE];
     __shared__ unsigned short r_slot[PA_TILE];          // the row's slot in the tile (its row id follows from it)
@@ -223,9 +227,13 @@ __global__ __launch_bounds__(PA_T) void k_part_scatter(JoinIndexView ix, const u
         for (int k = 0; k < PA_I; k++) {
             qs[k] = (i32)((u32)qs[k] + adj); qe[k] = (i32)((u32)qe[k] - adj);
             se[k] = (u64)(u32)qs[k] | ((u64)(u32)qe[k] << 32);
-            const u32 d = region_of(ix, kt, kk[k], qs[k]);
+            u32 d = region_of(ix, kt, kk[k], qs[k]);
+            if (SPLIT && d != NO_REGION) {                       // digit = super-region; region % G rides along in the bits above it
+                const u32 sup = (u32)(((u64)d * split.y) >> 32);
+                d = sup | ((d - sup * split.x) << 10);
+            }
             dig[k] = d;
-            lrank[k] = lds_count_up(dstart, d, d != NO_REGION);
+            lrank[k] = lds_count_up(dstart, SPLIT ? (d & 1023u) : d, d != NO_REGION);
         }
         __syncthreads();
         u32 tot;
@@ -236,7 +244,7 @@ __global__ __launch_bounds__(PA_T) void k_part_scatter(JoinIndexView ix, const u
 #pragma unroll
         for (int k = 0; k < PA_I; k++) {
             if (dig[k] != NO_REGION) {
-                const u32 pos = dstart[dig[k]] + lrank[k];
+                const u32 pos = dstart[SPLIT ? (dig[k] & 1023u) : dig[k]] + lrank[k];
                 r_se[pos] = se[k];
                 r_slot[pos] = (unsigned short)(((k / 4) * PA_T + tid) * 4 + (k % 4));
                 r_dig[pos] = (DigT)dig[k];
@@ -247,8 +255,10 @@ __global__ __launch_bounds__(PA_T) void k_part_scatter(JoinIndexView ix, const u
         for (int k = 0; k < PA_I; k++) {
             const u32 j = k * PA_T + tid;
             if (j < tot) {
-                const u32 d = r_dig[j];
+                const u32 dd = r_dig[j];
+                const u32 d = SPLIT ? (dd & 1023u) : dd;
                 const u64 g = (u64)gbase[d] + (j - dstart[d]);
+                if (SPLIT) out_sub[g] = (unsigned char)(dd >> 10);
                 if (!(dbg & 1)) {
                     const RowT row = (RowT)(t0 - (sizeof(RowT) == 2 ? lo : 0) + r_slot[j]);
                     if (dbg & 8) { __builtin_nontemporal_store(r_se[j], &out_se[g]); __builtin_nontemporal_store(row, &out_row[g]); }
@@ -954,30 +964,109 @@ namespace {
 
 constexpr int WR_T = 256;
 
-__global__ __launch_bounds__(WR_T) void k_region_ids(JoinIndexView ix, const u32 *__restrict__ pkey, const i32 *__restrict__ ps,
-                                                     const i32 *__restrict__ pe, u64 n, u32 nreg, u64 *__restrict__ w_se, u64 *__restrict__ w_rr)
+// ------------------------------------------------------------------ second routing pass (more than IVX_MAXREG_WIDE regions)
+// Pass A (k_part_* with SPLIT) grouped the probe rows by super-region = region / G and kept region % G ("sub") per
+// row.  Pass B orders the rows of every super-region by sub.  Super-region s is cut into tiles of PA_TILE rows;
+// the histogram is laid out as [s][sub][tile of s] -- exactly the output order, so ONE plain exclusive scan over it
+// gives every (tile, sub) run its place, and (s, sub, tile 0) is where region s*G + sub starts.
+constexpr u32 P2_SUBMAX = 64;                           // G <= 64: up to 1023 * 64 = 65 472 >= IVX_MAXREG2 regions
+
+// tprefix[s] = tiles of the super-regions before s (one workgroup; nsuper <= 1023)
+__global__ __launch_bounds__(1024) void k_p2_layout(const u32 *__restrict__ offs1, u32 nblk1, u32 nsuper, u32 *tprefix, const u32 *unsorted)
 {
-    __shared__ i32 s_origin[KT_MAX];
-    __shared__ u32 s_last[KT_MAX], s_kreg[KT_MAX];
-    KeyTab kt;
-    keytab_load(ix, s_origin, s_last, s_kreg, kt);
+    __shared__ u32 red[1024 / IVX_WAVE + 1];
+    if (*unsorted == 0) return;
+    const u32 t = threadIdx.x;
+    const u32 rows = t < nsuper ? offs1[(u64)(t + 1) * nblk1] - offs1[(u64)t * nblk1] : 0u;
+    const u32 tiles = (rows + PA_TILE - 1) / PA_TILE;
+    u32 tot;
+    const u32 ex = block_excl_scan<u32, 1024>(tiles, red, &tot);
+    if (t < nsuper) tprefix[t] = ex;
+    if (t == 0) tprefix[nsuper] = tot;
+}
+
+struct P2Tile { u32 s, t, nt; u64 lo, hi; bool ok; };
+__device__ __forceinline__ P2Tile p2_tile(const u32 *__restrict__ offs1, u32 nblk1, u32 nsuper, const u32 *__restrict__ tprefix, u32 *s_tp)
+{
+    for (u32 i = threadIdx.x; i <= nsuper; i += blockDim.x) s_tp[i] = tprefix[i];
     __syncthreads();
-    for (u64 i = (u64)blockIdx.x * WR_T + threadIdx.x; i < n; i += (u64)gridDim.x * WR_T) {
-        const i32 qs = ps[i], qe = pe[i];
-        u32 r = region_of(ix, kt, pkey ? pkey[i] : 0u, qs);
-        if (r == NO_REGION) r = nreg;                                   // sorts behind every real region, never probed
-        w_se[i] = (u64)(u32)qs | ((u64)(u32)qe << 32);
-        w_rr[i] = ((u64)r << 32) | (u32)i;
+    P2Tile T; T.ok = blockIdx.x < s_tp[nsuper];
+    if (!T.ok) return T;
+    u32 a = 0, b = nsuper - 1;                                      // last s with tprefix[s] <= block
+    while (a < b) { const u32 m = (a + b + 1) >> 1; if (s_tp[m] <= blockIdx.x) a = m; else b = m - 1; }
+    T.s = a; T.t = blockIdx.x - s_tp[a]; T.nt = s_tp[a + 1] - s_tp[a];
+    const u64 seg_lo = offs1[(u64)a * nblk1], seg_hi = offs1[(u64)(a + 1) * nblk1];
+    T.lo = seg_lo + (u64)T.t * PA_TILE;
+    T.hi = T.lo + PA_TILE < seg_hi ? T.lo + PA_TILE : seg_hi;
+    return T;
+}
+
+__global__ __launch_bounds__(PA_T) void k_p2_hist(const unsigned char *__restrict__ sub1, const u32 *__restrict__ offs1, u32 nblk1, u32 nsuper,
+                                                  const u32 *__restrict__ tprefix, u32 G, u32 *__restrict__ hist2, const u32 *unsorted)
+{
+    __shared__ u32 s_tp[IVX_MAXREG_WIDE + 2];
+    __shared__ u32 cnt[P2_SUBMAX];
+    if (*unsorted == 0) return;
+    if (threadIdx.x < P2_SUBMAX) cnt[threadIdx.x] = 0;
+    const P2Tile T = p2_tile(offs1, nblk1, nsuper, tprefix, s_tp);  // (barrier inside)
+    if (!T.ok) return;
+    for (u64 i0 = T.lo; i0 < T.hi; i0 += PA_T) {
+        const u64 i = i0 + threadIdx.x;
+        const bool ok = i < T.hi;
+        lds_count_up(cnt, ok ? (u32)sub1[i] : 0u, ok);
+    }
+    __syncthreads();
+    if (threadIdx.x < G) hist2[(u64)G * s_tp[T.s] + (u64)threadIdx.x * T.nt + T.t] = cnt[threadIdx.x];
+}
+
+__global__ __launch_bounds__(PA_T) void k_p2_scatter(const unsigned char *__restrict__ sub1, const u64 *__restrict__ se1, const u32 *__restrict__ row1,
+                                                     const u32 *__restrict__ offs1, u32 nblk1, u32 nsuper, const u32 *__restrict__ tprefix, u32 G,
+                                                     const u32 *__restrict__ hist2, u64 *__restrict__ se2, u32 *__restrict__ row2, const u32 *unsorted)
+{
+    __shared__ u32 s_tp[IVX_MAXREG_WIDE + 2];
+    __shared__ u32 cur[P2_SUBMAX];
+    if (*unsorted == 0) return;
+    const P2Tile T = p2_tile(offs1, nblk1, nsuper, tprefix, s_tp);
+    if (!T.ok) return;
+    if (threadIdx.x < G) cur[threadIdx.x] = hist2[(u64)G * s_tp[T.s] + (u64)threadIdx.x * T.nt + T.t];   // this tile's run of every sub
+    __syncthreads();
+    for (u64 i0 = T.lo; i0 < T.hi; i0 += PA_T) {
+        const u64 i = i0 + threadIdx.x;
+        const bool ok = i < T.hi;
+        const u32 d = ok ? (u32)sub1[i] : 0u;
+        const u32 pos = lds_count_up(cur, d, ok);                   // order inside a run is arbitrary
+        if (ok) { se2[pos] = se1[i]; row2[pos] = row1[i]; }
     }
 }
 
-// rfirst[r] = first sorted position whose region id is >= r, for r = 0 .. nreg
-__global__ __launch_bounds__(WR_T) void k_region_bounds(const u64 *__restrict__ w_rr, u64 n, u32 nreg, u32 *__restrict__ rfirst)
+// rfirst[r] = first routed position of region r (r = 0 .. nreg), from the scanned second-pass histogram
+__global__ __launch_bounds__(WR_T) void k_p2_bounds(u32 nreg, u32 G, u32 nsuper, const u32 *__restrict__ offs1, u32 nblk1, u64 nh1,
+                                                    const u32 *__restrict__ tprefix, const u32 *__restrict__ hist2, u32 *__restrict__ rfirst,
+                                                    const u32 *unsorted)
 {
+    if (*unsorted == 0) return;
     const u32 r = blockIdx.x * WR_T + threadIdx.x;
     if (r > nreg) return;
-    u64 lo = 0, hi = n;
-    while (lo < hi) { const u64 mid = lo + ((hi - lo) >> 1); if ((u32)(w_rr[mid] >> 32) < r) lo = mid + 1; else hi = mid; }
+    if (r == nreg) { rfirst[r] = offs1[nh1 - 1]; return; }          // all routed rows
+    const u32 sp = r / G, sub = r - sp * G;
+    const u32 nt = tprefix[sp + 1] - tprefix[sp];
+    rfirst[r] = nt ? hist2[(u64)G * tprefix[sp] + (u64)sub * nt] : offs1[(u64)sp * nblk1];
+}
+
+// the same table when the probe rows came in region order already (nothing was moved): binary searches in the input
+__global__ __launch_bounds__(WR_T) void k_sorted_bounds(JoinIndexView ix, const u32 *__restrict__ pkey, const i32 *__restrict__ ps, u64 n,
+                                                        u32 nreg, u32 *__restrict__ rfirst, const u32 *unsorted)
+{
+    __shared__ i32 s_origin[KT_MAX];
+    __shared__ u32 s_last[KT_MAX], s_kreg[KT_MAX];
+    if (*unsorted != 0) return;
+    KeyTab kt;
+    keytab_load(ix, s_origin, s_last, s_kreg, kt);
+    __syncthreads();
+    const u32 r = blockIdx.x * WR_T + threadIdx.x;
+    if (r > nreg) return;
+    u64 lo = 0, hi = n;                                             // first row whose region is >= r (every row is routable here)
+    while (lo < hi) { const u64 mid = lo + ((hi - lo) >> 1); if (region_of(ix, kt, pkey ? pkey[mid] : 0u, ps[mid]) < r) lo = mid + 1; else hi = mid; }
     rfirst[r] = (u32)lo;
 }
 
@@ -1010,33 +1099,64 @@ ivx_status dense_fill(ivx_ctx *ctx, const JoinIndexView &jv, u32 nreg, const voi
     return IVX_OK;
 }
 
-ivx_status probe_wide(ivx_ctx *ctx, const JoinIndexView &jv, int mode, u32 nreg, const u32 *key, const i32 *s, const i32 *e, u64 n,
-                      u32 *ob, u32 *op, u64 cap, u64 *d_cursor)
+// more than IVX_MAXREG_WIDE regions: route the probe rows in two partition passes (super-region, then region inside
+// it), or not at all if they already come in region order; then the same probe kernels with a global region table
+ivx_status probe_two_level(ivx_ctx *ctx, const JoinIndexView &jv, int mode, u32 nreg, const u32 *key, const i32 *s, const i32 *e, u64 n,
+                           u32 *ob, u32 *op, u64 cap, u64 *d_cursor)
 {
     hipStream_t st = ctx->stream;
-    u64 *a[2], *b[2]; u32 *rfirst;
-    IVX_TRY(ctx->get_scratch(WS_T0, n * sizeof(u64), (void **)&a[0]));
-    IVX_TRY(ctx->get_scratch(WS_T1, n * sizeof(u64), (void **)&a[1]));
-    IVX_TRY(ctx->get_scratch(WS_SA0, n * sizeof(u64), (void **)&b[0]));
-    IVX_TRY(ctx->get_scratch(WS_SA1, n * sizeof(u64), (void **)&b[1]));
-    IVX_TRY(ctx->get_scratch(WS_T2, ((size_t)nreg + 1) * sizeof(u32), (void **)&rfirst));
-    hipLaunchKernelGGL(k_region_ids, dim3(ivx_stream_grid(n, WR_T * 8, 4096)), dim3(WR_T), 0, st, jv, key, s, e, n, nreg, a[0], a[1]);
-    const ivx_sort_field f[1] = {{1, 32, 48}};
-    int in_b = 0;
-    IVX_TRY(ivx_radix_sort(ctx, 2, a, b, n, f, 1, &in_b));
-    u64 *const *o = in_b ? b : a;
-    hipLaunchKernelGGL(k_region_bounds, dim3((nreg + 1 + WR_T - 1) / WR_T), dim3(WR_T), 0, st, (const u64 *)o[1], n, nreg, rfirst);
+    const u32 G = (nreg + IVX_MAXREG_WIDE - 1) / IVX_MAXREG_WIDE;       // regions per super-region
+    if (G > P2_SUBMAX) return ctx->fail(IVX_ERR_INVALID, "overlap index with too many probe regions");
+    const u32 nsuper = (nreg + G - 1) / G;
+    const uint2 split = make_uint2(G, (u32)(((1ull << 32) + G - 1) / G));
+    const u32 chunk = part_chunk(n);
+    const u32 nblk1 = (u32)((n + chunk - 1) / chunk);
+    const u64 nh1 = (u64)1024 * nblk1 + 1;
+    const u32 grid2 = (u32)(n / PA_TILE) + nsuper + 1;                   // tiles of the second pass, at most
+    const u64 nh2 = (u64)G * grid2 + 1;
+    u32 *hist1, *hist2, *tprefix, *rfirst, *prow1, *prow2; u64 *pse1, *pse2; unsigned char *sub1;
+    IVX_TRY(ctx->get_scratch(WS_SORTHIST, nh1 * sizeof(u32), (void **)&hist1));
+    IVX_TRY(ctx->get_scratch(WS_T0, n * sizeof(u64), (void **)&pse1));
+    IVX_TRY(ctx->get_scratch(WS_T1, n * sizeof(u32), (void **)&prow1));
+    IVX_TRY(ctx->get_scratch(WS_T2, n, (void **)&sub1));
+    IVX_TRY(ctx->get_scratch(WS_SA0, n * sizeof(u64), (void **)&pse2));
+    IVX_TRY(ctx->get_scratch(WS_SA1, n * sizeof(u32), (void **)&prow2));
+    IVX_TRY(ctx->get_scratch(WS_T4, ((size_t)nsuper + 1) * sizeof(u32), (void **)&tprefix));
+    IVX_TRY(ctx->get_scratch(WS_T5, nh2 * sizeof(u32), (void **)&hist2));
+    IVX_TRY(ctx->get_scratch(WS_T6, ((size_t)nreg + 1) * sizeof(u32), (void **)&rfirst));
+    u32 *unsorted = (u32 *)(ctx->d_scalars + 10);
+    IVX_HIP(ctx, hipMemsetAsync(hist1 + (nh1 - 1), 0, sizeof(u32), st));
+    IVX_HIP(ctx, hipMemsetAsync(hist2, 0, nh2 * sizeof(u32), st));
+    IVX_HIP(ctx, hipMemsetAsync(unsorted, 0, sizeof(u32), st));
+    const bool vec = (((uintptr_t)key | (uintptr_t)s | (uintptr_t)e) & 15) == 0;
+    // pass A: by super-region (and the sortedness check on the regions themselves)
+    if (vec) hipLaunchKernelGGL((k_part_hist<true, 1024, true>), dim3(nblk1), dim3(PA_T), 0, st, jv, key, s, n, nblk1, chunk, hist1, 0u, unsorted, split);
+    else hipLaunchKernelGGL((k_part_hist<false, 1024, true>), dim3(nblk1), dim3(PA_T), 0, st, jv, key, s, n, nblk1, chunk, hist1, 0u, unsorted, split);
+    IVX_TRY(ivx_scan_exclusive_u32(ctx, hist1, nh1));
+    if (vec) hipLaunchKernelGGL((k_part_scatter<true, u32, 1024, true>), dim3(nblk1), dim3(PA_T), 0, st, jv, key, s, e, n, nblk1, (const u32 *)hist1, pse1, prow1, chunk, 0u, (const u32 *)unsorted, 0, split, sub1);
+    else hipLaunchKernelGGL((k_part_scatter<false, u32, 1024, true>), dim3(nblk1), dim3(PA_T), 0, st, jv, key, s, e, n, nblk1, (const u32 *)hist1, pse1, prow1, chunk, 0u, (const u32 *)unsorted, 0, split, sub1);
+    // pass B: inside every super-region by region
+    hipLaunchKernelGGL(k_p2_layout, dim3(1), dim3(1024), 0, st, (const u32 *)hist1, nblk1, nsuper, tprefix, (const u32 *)unsorted);
+    hipLaunchKernelGGL(k_p2_hist, dim3(grid2), dim3(PA_T), 0, st, (const unsigned char *)sub1, (const u32 *)hist1, nblk1, nsuper, (const u32 *)tprefix, G, hist2, (const u32 *)unsorted);
+    IVX_TRY(ivx_scan_exclusive_u32(ctx, hist2, nh2));
+    hipLaunchKernelGGL(k_p2_scatter, dim3(grid2), dim3(PA_T), 0, st, (const unsigned char *)sub1, (const u64 *)pse1, (const u32 *)prow1, (const u32 *)hist1, nblk1, nsuper,
+                       (const u32 *)tprefix, G, (const u32 *)hist2, pse2, prow2, (const u32 *)unsorted);
+    const u32 bgrid = (nreg + 1 + WR_T - 1) / WR_T;
+    hipLaunchKernelGGL(k_p2_bounds, dim3(bgrid), dim3(WR_T), 0, st, nreg, G, nsuper, (const u32 *)hist1, nblk1, nh1, (const u32 *)tprefix, (const u32 *)hist2, rfirst, (const u32 *)unsorted);
+    hipLaunchKernelGGL(k_sorted_bounds, dim3(bgrid), dim3(WR_T), 0, st, jv, key, s, n, nreg, rfirst, (const u32 *)unsorted);
     unsigned long long *cur = (unsigned long long *)d_cursor;
-    const u32 *prow = (const u32 *)o[1];                                // low word of (region << 32 | row): stride 2
-    if (mode == JP_FILL && dense_fill_wanted(cap, n)) {
-        return dense_fill(ctx, jv, nreg, (const void *)o[0], (const void *)prow, 2u, nullptr, nullptr, (const u32 *)rfirst, 1u, nullptr, n, ob, op, cap, d_cursor);
-    } else if (mode == JP_FILL) {
+    if (mode == JP_FILL && dense_fill_wanted(cap, n))
+        return dense_fill(ctx, jv, nreg, (const void *)pse2, (const void *)prow2, 1u, s, e, (const u32 *)rfirst, 1u, (const u32 *)unsorted, n, ob, op, cap, d_cursor);
+    if (mode == JP_FILL) {
         const int bsel = fill_rows_per_lane(cap, n);
-#define IVX_FILLW(B_) hipLaunchKernelGGL((k_probe_regions<1, B_, false>), dim3(RP_GRID), dim3(RP_T), 0, st, jv, (const void *)o[0], (const void *)prow, (const u32 *)rfirst, 1u, RP_VGRID / RP_GRID, ob, op, cap, cur, 2u, 0u, (const u32 *)nullptr, 0)
+#define IVX_FILL2(B_, ID_) hipLaunchKernelGGL((k_probe_regions<1, B_, ID_>), dim3(RP_GRID), dim3(RP_T), 0, st, jv, ID_ ? (const void *)s : (const void *)pse2, ID_ ? (const void *)e : (const void *)prow2, (const u32 *)rfirst, 1u, RP_VGRID / RP_GRID, ob, op, cap, cur, 1u, 0u, (const u32 *)unsorted, 0)
+#define IVX_FILLW(B_) do { IVX_FILL2(B_, false); IVX_FILL2(B_, true); } while (0)
         switch (bsel) { case 1: IVX_FILLW(1); break; case 2: IVX_FILLW(2); break; case 4: IVX_FILLW(4); break; default: IVX_FILLW(8); }
 #undef IVX_FILLW
+#undef IVX_FILL2
     } else {
-        hipLaunchKernelGGL((k_probe_regions<0, RP_B, false>), dim3(RP_VGRID), dim3(RP_T), 0, st, jv, (const void *)o[0], (const void *)prow, (const u32 *)rfirst, 1u, 1u, ob, op, cap, cur, 2u, 0u, (const u32 *)nullptr, 0);
+        hipLaunchKernelGGL((k_probe_regions<0, RP_B, false>), dim3(RP_VGRID), dim3(RP_T), 0, st, jv, (const void *)pse2, (const void *)prow2, (const u32 *)rfirst, 1u, 1u, ob, op, cap, cur, 1u, 0u, (const u32 *)unsorted, 0);
+        hipLaunchKernelGGL((k_probe_regions<0, RP_B, true>), dim3(RP_VGRID), dim3(RP_T), 0, st, jv, (const void *)s, (const void *)e, (const u32 *)rfirst, 1u, 1u, ob, op, cap, cur, 1u, 0u, (const u32 *)unsorted, 0);
     }
     IVX_HIP(ctx, hipGetLastError());
     return IVX_OK;
@@ -1052,7 +1172,7 @@ ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nre
     ivx_join_plan &pl = ctx->join_plan;
     if (nreg > IVX_MAXREG_WIDE) {
         if (planned) return ctx->fail(IVX_ERR_INVALID, "join plan for a two-digit region table");   // never recorded
-        return probe_wide(ctx, jv, mode, nreg, key, s, e, n, ob, op, cap, d_cursor);
+        return probe_two_level(ctx, jv, mode, nreg, key, s, e, n, ob, op, cap, d_cursor);
     }
     hipStream_t st = ctx->stream;
 #ifdef IVX_ABLATE          // profiling builds only (tools/variant.sh <name> -DIVX_ABLATE; tools/ablate.sh): IVX_DBG bit switches
