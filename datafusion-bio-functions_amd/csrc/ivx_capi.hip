@@ -303,12 +303,12 @@ static ivx_status overlap_common(ivx_ctx *ctx, const ivx_index *ix, int mem, int
     // small batches and the per-row modes gather straight from the index
     bool regions = ix->jv_nreg > 0 && (mode == JP_COUNT || mode == JP_FILL) && n >= (1u << 21);   // measured crossover (tools/crossover.py)
     // the per-row modes (rle_right, semi / anti) of big batches: same partition, one value per row, un-permuted
-    bool rowval = ix->jv_nreg > 0 && ix->jv_nreg <= IVX_MAXREG && (mode == JP_PER_ROW || mode == JP_EXISTS) && n >= (1u << 21);
+    bool rowval = ix->jv_nreg > 0 && ix->jv_nreg <= IVX_MAXREG_WIDE && (mode == JP_PER_ROW || mode == JP_EXISTS) && n >= (1u << 21);
     if (const char *f = getenv("IVX_JOIN_PATH")) {
         if (!strcmp(f, "direct")) regions = rowval = false;
         else if (!strcmp(f, "regions")) {
             regions = ix->jv_nreg > 0 && (mode == JP_COUNT || mode == JP_FILL);
-            rowval = ix->jv_nreg > 0 && ix->jv_nreg <= IVX_MAXREG && (mode == JP_PER_ROW || mode == JP_EXISTS);
+            rowval = ix->jv_nreg > 0 && ix->jv_nreg <= IVX_MAXREG_WIDE && (mode == JP_PER_ROW || mode == JP_EXISTS);
         }
     }
     // a fill call right after the count call that sized it: the routed probe rows are still in the context
@@ -335,7 +335,7 @@ static ivx_status overlap_common(ivx_ctx *ctx, const ivx_index *ix, int mem, int
             if (st != IVX_OK) { pl.valid = false; return st; }
             if (mode == JP_COUNT && pl.valid) { memcpy(pl.in, in, sizeof(in)); pl.mem = mem; pl.n = n; pl.ix = ix; pl.ix_serial = ix->serial; pl.stream = ctx->stream; }
         }
-        else if (rowval) IVX_TRY(ivx_rowval_probe_regions(ctx, ix->jv, mode == JP_PER_ROW ? IVX_RV_PER_ROW : IVX_RV_EXISTS, dk, ds, de, n, 0,
+        else if (rowval) IVX_TRY(ivx_rowval_probe_regions(ctx, ix->jv, ix->jv_nreg, mode == JP_PER_ROW ? IVX_RV_PER_ROW : IVX_RV_EXISTS, dk, ds, de, n, 0,
                                                           mode == JP_PER_ROW ? (void *)d_row : (void *)d_ex, ctx->d_scalars));
         else IVX_TRY(ivx_join_probe(ctx, ix->jv, mode, dk, ds, de, n, d_row, d_ex, d_b, d_p, cap, ctx->d_scalars));
     }

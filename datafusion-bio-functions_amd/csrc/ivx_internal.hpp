@@ -209,7 +209,7 @@ ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nre
 // per-row-output operators through the same partition (count_overlaps: jv over the build rows, no row with
 // end < start; coverage: jv over the merged nodes)
 enum { IVX_RV_COUNT = 0, IVX_RV_COVERAGE = 1, IVX_RV_PER_ROW = 2, IVX_RV_EXISTS = 3 };
-ivx_status ivx_rowval_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, int kind,
+ivx_status ivx_rowval_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nreg, int kind,
                                     const u32 *key, const i32 *s, const i32 *e, u64 n, int strict, void *out, u64 *d_total);
 
 ivx_status ivx_index_alloc(ivx_ctx *ctx, ivx_index *ix, size_t bytes, void **out);

@@ -43,7 +43,6 @@ constexpr int PA_T = 1024;
 #endif
 constexpr int PA_I = IVX_PA_I;                    // rows per thread and tile (multiple of 4)
 constexpr int PA_TILE = PA_T * PA_I;              // 12288 rows: ~63 rows per region and tile = the length of the runs written to HBM
-constexpr int PA_ND = 256;                        // radix digits = regions (+ unused)
 constexpr u32 NO_REGION = 0xFFFFFFFFu;
 constexpr u32 KT_MAX = 256;                       // per-key tables cached in LDS up to this many keys
 
@@ -867,7 +866,7 @@ __device__ __forceinline__ void up_store(void *out, u64 i, u32 v)
     else ((u8 *)out)[i] = v != 0;
 }
 
-template <int OUT>
+template <int OUT, int ND>
 __global__ __launch_bounds__(PA_T) void k_unpermute(const u32 *__restrict__ val, const unsigned short *__restrict__ cidx,
                                                     const u32 *__restrict__ offs, u32 nblk, u32 chunk, u32 nreg, u64 n, void *__restrict__ out,
                                                     const u32 *unsorted, unsigned long long *total)
@@ -882,7 +881,7 @@ __global__ __launch_bounds__(PA_T) void k_unpermute(const u32 *__restrict__ val,
         return;
     }
     __shared__ u32 s_val[UP_CHUNK];
-    __shared__ u32 s_pre[PA_ND + 1], s_g[PA_ND];
+    __shared__ u32 s_pre[ND + 1], s_g[ND];
     __shared__ u32 scan_lds[PA_T / IVX_WAVE + 1];
     const u32 tid = threadIdx.x, blk = blockIdx.x;
     const u64 lo = (u64)blk * chunk;
@@ -891,8 +890,8 @@ __global__ __launch_bounds__(PA_T) void k_unpermute(const u32 *__restrict__ val,
     if (tid < nreg) { g = offs[(u64)tid * nblk + blk]; c = offs[(u64)tid * nblk + blk + 1] - g; }
     u32 tot;
     const u32 ex = block_excl_scan<u32, PA_T>(c, scan_lds, &tot);
-    if (tid < PA_ND) { s_pre[tid] = ex; s_g[tid] = g; }
-    if (tid == 0) s_pre[PA_ND] = tot;
+    if (tid < ND) { s_pre[tid] = ex; s_g[tid] = g; }
+    if (tid == 0) s_pre[ND] = tot;
     for (u32 t = tid; t < chunk; t += PA_T) s_val[t] = 0;
     __syncthreads();
     // wavefront w owns elements [w*per, (w+1)*per) of the chunk's region-major value list
@@ -900,9 +899,9 @@ __global__ __launch_bounds__(PA_T) void k_unpermute(const u32 *__restrict__ val,
     const u32 per = (tot + PA_T / IVX_WAVE - 1) / (PA_T / IVX_WAVE);
     const u32 t_lo = wv * per, t_hi = t_lo + per < tot ? t_lo + per : tot;
     u32 r = 0;
-    if (t_lo < t_hi) { u32 a = 0, b = PA_ND; while (a < b) { const u32 m = (a + b + 1) >> 1; if (s_pre[m] <= t_lo + ln && m < PA_ND) a = m; else b = m - 1; } r = a; }
+    if (t_lo < t_hi) { u32 a = 0, b = ND; while (a < b) { const u32 m = (a + b + 1) >> 1; if (s_pre[m] <= t_lo + ln && m < ND) a = m; else b = m - 1; } r = a; }
     for (u32 t = t_lo + ln; t < t_hi; t += IVX_WAVE) {
-        while (r + 1 < PA_ND && s_pre[r + 1] <= t) r++;
+        while (r + 1 < ND && s_pre[r + 1] <= t) r++;
         const u64 at = (u64)s_g[r] + (t - s_pre[r]);
         s_val[cidx[at]] = val[at];
     }
@@ -916,15 +915,17 @@ __global__ __launch_bounds__(PA_T) void k_unpermute(const u32 *__restrict__ val,
 // One value per probe row, in input order, through the region partition.  kind: IVX_RV_COUNT (count_overlaps,
 // jv over the build rows, i64 out), IVX_RV_COVERAGE (jv over the merged nodes, i64 out), IVX_RV_PER_ROW (the
 // join's rle_right: u32 out, *d_total += all matches), IVX_RV_EXISTS (semi / anti join: u8 out).
-ivx_status ivx_rowval_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, int kind,
+ivx_status ivx_rowval_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nreg, int kind,
                                     const u32 *key, const i32 *s, const i32 *e, u64 n, int strict, void *out, u64 *d_total)
 {
     if (n == 0) return IVX_OK;
+    if (nreg == 0 || nreg > IVX_MAXREG_WIDE) return ctx->fail(IVX_ERR_INVALID, "per-row region probe: one partition pass only");
     hipStream_t st = ctx->stream;
+    const bool wide = nreg > IVX_MAXREG;                                // 1024 digits instead of 256
     const u32 chunk = part_chunk(n, 2);
     const u32 nblk = (u32)((n + chunk - 1) / chunk);
     u32 *hist, *val; u64 *pse; unsigned short *cidx;
-    const u64 nh = (u64)256 * nblk + 1;
+    const u64 nh = (u64)(wide ? 1024 : 256) * nblk + 1;
     IVX_TRY(ctx->get_scratch(WS_SORTHIST, nh * sizeof(u32), (void **)&hist));
     IVX_TRY(ctx->get_scratch(WS_T0, n * sizeof(u64), (void **)&pse));
     IVX_TRY(ctx->get_scratch(WS_T1, n * sizeof(unsigned short), (void **)&cidx));
@@ -934,17 +935,20 @@ ivx_status ivx_rowval_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, int k
     const bool vec = (((uintptr_t)key | (uintptr_t)s | (uintptr_t)e) & 15) == 0;
     u32 *unsorted = (u32 *)(ctx->d_scalars + 10);                       // stays 0 if the rows already come in region order
     IVX_HIP(ctx, hipMemsetAsync(unsorted, 0, sizeof(u32), st));
-    if (vec) hipLaunchKernelGGL((k_part_hist<true, PA_ND>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, n, nblk, chunk, hist, adj, unsorted);
-    else hipLaunchKernelGGL((k_part_hist<false, PA_ND>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, n, nblk, chunk, hist, adj, unsorted);
-    IVX_TRY(ivx_scan_exclusive_u32(ctx, hist, nh));
-    if (vec) hipLaunchKernelGGL((k_part_scatter<true, unsigned short, PA_ND>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, cidx, chunk, adj, (const u32 *)unsorted, 0);
-    else hipLaunchKernelGGL((k_part_scatter<false, unsigned short, PA_ND>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, cidx, chunk, adj, (const u32 *)unsorted, 0);
+#define IVX_PART(V_, ND_) do { \
+    hipLaunchKernelGGL((k_part_hist<V_, ND_>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, n, nblk, chunk, hist, adj, unsorted); \
+    IVX_TRY(ivx_scan_exclusive_u32(ctx, hist, nh)); \
+    hipLaunchKernelGGL((k_part_scatter<V_, unsigned short, ND_>), dim3(nblk), dim3(PA_T), 0, st, jv, key, s, e, n, nblk, (const u32 *)hist, pse, cidx, chunk, adj, (const u32 *)unsorted, 0); } while (0)
+    if (wide) { if (vec) IVX_PART(true, 1024); else IVX_PART(false, 1024); }
+    else { if (vec) IVX_PART(true, 256); else IVX_PART(false, 256); }
+#undef IVX_PART
 #define IVX_RV(M_, ID_) hipLaunchKernelGGL((k_probe_regions<M_, RP_B, ID_>), dim3(RP_VGRID), dim3(RP_T), 0, st, jv, ID_ ? (const void *)s : (const void *)pse, ID_ ? (const void *)e : (const void *)nullptr, (const u32 *)hist, nblk, 1u, val, (u32 *)nullptr, (u64)0, (unsigned long long *)nullptr, 1u, adj, (const u32 *)unsorted, 0)
     if (kind == IVX_RV_COVERAGE) { IVX_RV(RV_COVERAGE, false); IVX_RV(RV_COVERAGE, true); }
     else if (kind == IVX_RV_COUNT) { IVX_RV(RV_COUNT, false); IVX_RV(RV_COUNT, true); }
     else { IVX_RV(RV_MATCHES, false); IVX_RV(RV_MATCHES, true); }
 #undef IVX_RV
-#define IVX_UP(O_) hipLaunchKernelGGL(k_unpermute<O_>, dim3(nblk), dim3(PA_T), 0, st, (const u32 *)val, (const unsigned short *)cidx, (const u32 *)hist, nblk, chunk, (u32)PA_ND, n, out, (const u32 *)unsorted, (unsigned long long *)d_total)
+#define IVX_UP1(O_, ND_) hipLaunchKernelGGL((k_unpermute<O_, ND_>), dim3(nblk), dim3(PA_T), 0, st, (const u32 *)val, (const unsigned short *)cidx, (const u32 *)hist, nblk, chunk, (u32)ND_, n, out, (const u32 *)unsorted, (unsigned long long *)d_total)
+#define IVX_UP(O_) do { if (wide) IVX_UP1(O_, 1024); else IVX_UP1(O_, 256); } while (0)
     switch (kind) {
     case IVX_RV_COVERAGE: IVX_UP(UP_I64S); break;
     case IVX_RV_COUNT: IVX_UP(UP_I64); break;
@@ -952,14 +956,11 @@ ivx_status ivx_rowval_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, int k
     default: IVX_UP(UP_U8); break;
     }
 #undef IVX_UP
+#undef IVX_UP1
     IVX_HIP(ctx, hipGetLastError());
     return IVX_OK;
 }
 
-// ------------------------------------------------------------------ more than 255 regions
-// Build sides beyond ~1.5 M rows need more than 255 LDS-sized regions.  The probe rows are then routed by
-// region id with the stable radix sort (two 8-bit digits; records = (qs,qe) + (region << 32 | row)), the
-// region starts come from binary searches in the sorted ids, and the same probe kernel runs on top.
 namespace {
 
 constexpr int WR_T = 256;

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(OT) void k_any_inverted(const i32 *__restrict__ s, 
 // large unsorted batches go through the region partition (ivx_join_regions.hip) unless told otherwise
 bool rowval_regions_wanted(const ivx_index *ix, u64 n)
 {
-    if (!(ix->flags & IVX_IXF_REGION_ROWVAL) || ix->jv_nreg == 0 || ix->jv_nreg > IVX_MAXREG) return false;   // one-digit regions only
+    if (!(ix->flags & IVX_IXF_REGION_ROWVAL) || ix->jv_nreg == 0 || ix->jv_nreg > IVX_MAXREG_WIDE) return false;   // one partition pass only
     const char *f = getenv("IVX_ROWVAL_PATH");                          // tests: "direct" | "regions"
     if (f && !strcmp(f, "direct")) return false;
     if (f && !strcmp(f, "regions")) return true;
@@ -501,7 +501,7 @@ ivx_status ivx_nearest_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const 
 ivx_status ivx_count_probe(ivx_ctx *ctx, const ivx_index *ix, const u32 *key, const i32 *s, const i32 *e, u64 n, int strict, i64 *out)
 {
     if (n == 0) return IVX_OK;
-    if (rowval_regions_wanted(ix, n)) return ivx_rowval_probe_regions(ctx, ix->jv, IVX_RV_COUNT, key, s, e, n, strict, out, nullptr);
+    if (rowval_regions_wanted(ix, n)) return ivx_rowval_probe_regions(ctx, ix->jv, ix->jv_nreg, IVX_RV_COUNT, key, s, e, n, strict, out, nullptr);
     hipLaunchKernelGGL(k_probe_count, dim3(ivx_stream_grid(n, OT * 4)), dim3(OT), 0, ctx->stream, ix->gs, ix->ge, key, s, e, n, strict, out);
     IVX_HIP(ctx, hipGetLastError());
     return IVX_OK;
@@ -510,7 +510,7 @@ ivx_status ivx_count_probe(ivx_ctx *ctx, const ivx_index *ix, const u32 *key, co
 ivx_status ivx_coverage_probe(ivx_ctx *ctx, const ivx_index *ix, const u32 *key, const i32 *s, const i32 *e, u64 n, int strict, i64 *out)
 {
     if (n == 0) return IVX_OK;
-    if (rowval_regions_wanted(ix, n)) return ivx_rowval_probe_regions(ctx, ix->jv, IVX_RV_COVERAGE, key, s, e, n, strict, out, nullptr);
+    if (rowval_regions_wanted(ix, n)) return ivx_rowval_probe_regions(ctx, ix->jv, ix->jv_nreg, IVX_RV_COVERAGE, key, s, e, n, strict, out, nullptr);
     hipLaunchKernelGGL(k_probe_coverage, dim3(ivx_stream_grid(n, OT * 4)), dim3(OT), 0, ctx->stream, ix->cv, key, s, e, n, strict, out);
     IVX_HIP(ctx, hipGetLastError());
     return IVX_OK;

@@ -613,3 +613,31 @@ def test_count_coverage_sorted_probe_input(ctx):
             for path in _paths():
                 assert (fn(ix, pk, ps, pe, strict=strict) == want).all(), (kind, strict, path)
         ix.free()
+
+
+def test_count_coverage_and_per_row_with_several_hundred_regions(ctx):
+    # a build side that needs more than 255 LDS-sized regions: count_overlaps / coverage / the join's per-row counts and
+    # exists go through the 1024-digit partition and the un-permute; unsorted and sorted probe rows, strict and weak
+    bk, bs, be = synth(2_600_000, 91, nkeys=3, mean_len=300, span=240_000_000)
+    pk, ps, pe = synth(500_000, 92, nkeys=4, mean_len=150, span=240_000_000)
+    pe[::83] = ps[::83] + 40_000
+    for srt in (False, True):
+        if srt:
+            o = np.lexsort((ps, pk)); pk, ps, pe = pk[o].copy(), ps[o].copy(), pe[o].copy()
+        for kind, fn, ofn in ((pyivx.KIND_COUNT, ctx.count_overlaps, orc.count_overlaps), (pyivx.KIND_COVERAGE, ctx.coverage, orc.coverage)):
+            ix = ctx.build(kind, bk, bs, be, n_keys=4)
+            for strict in (False, True):
+                want = ofn(bk, bs, be, pk, ps, pe, strict=strict)
+                for path in _paths():
+                    assert (fn(ix, pk, ps, pe, strict=strict) == want).all(), (kind, strict, path, srt)
+            ix.free()
+        ix = ctx.build(pyivx.KIND_OVERLAP, bk, bs, be, n_keys=4)
+        _, _, want_cnt = orc.join(bk, bs, be, pk, ps, pe, per_row=True, threads=4)
+        os.environ["IVX_JOIN_PATH"] = "regions"
+        try:
+            tot, pr = ctx.overlap_count(ix, pk, ps, pe, per_row=True)
+            ex = ctx.exists(ix, pk, ps, pe)
+        finally:
+            del os.environ["IVX_JOIN_PATH"]
+        assert tot == int(want_cnt.sum()) and (pr.astype(np.uint64) == want_cnt).all() and (ex == (want_cnt > 0)).all(), srt
+        ix.free()
