@@ -27,7 +27,7 @@ sys.path.insert(0, os.path.join(ROOT, "datafusion-bio-functions_amd"))
 
 HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # HBM bytes per probe call from rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE, the gfx950 correction of
-# MI355X_MICROARCH.md "HBM"), summed over the pipeline's kernels: profiles/r1_m_regions_pipeline_pmc.txt
+# MI355X_MICROARCH.md "HBM"), summed over the pipeline's kernels: profiles/r1_n_regions_pipeline_pmc.txt (same as r1_m)
 PMC_TRAFFIC_BYTES = {"join_100Mx1M_24contigs": 4.898e9}
 
 WORKLOADS = {
