@@ -140,6 +140,29 @@ __global__ __launch_bounds__(ST) void k_copy_sorted(const u32 *__restrict__ key,
     if (rows) rows[i] = (u32)i;
 }
 
+// After a (stable) sort on the packed word's (key,start) bits only: rows with equal (key,start) sit together in
+// input order and still have to be ordered by end, then row.  Such runs are short for genomic data (two or three
+// rows), so the thread at the head of a run insertion-sorts it in place; a run longer than FIX_MAXRUN raises
+// *toolong and the host falls back to the full-width sort.
+constexpr u32 FIX_MAXRUN = 64;
+__global__ __launch_bounds__(ST) void k_fix_runs(u64 *__restrict__ w0, u64 *__restrict__ w1, u64 n, u32 lo_bits, u32 *toolong)
+{
+    const u64 i = (u64)blockIdx.x * ST + threadIdx.x;
+    if (i >= n) return;
+    const u64 h = w0[i] >> lo_bits;
+    if (i && (w0[i - 1] >> lo_bits) == h) return;                       // not the head of its run
+    if (i + 1 >= n || (w0[i + 1] >> lo_bits) != h) return;              // a run of one
+    u32 len = 2;
+    while (i + len < n && len <= FIX_MAXRUN && (w0[i + len] >> lo_bits) == h) len++;
+    if (len > FIX_MAXRUN) { *toolong = 1; return; }
+    for (u32 a = 1; a < len; a++) {                                     // stable: equal words keep their (row) order
+        const u64 x0 = w0[i + a], x1 = w1[i + a];
+        u32 b = a;
+        while (b > 0 && w0[i + b - 1] > x0) { w0[i + b] = w0[i + b - 1]; w1[i + b] = w1[i + b - 1]; b--; }
+        w0[i + b] = x0; w1[i + b] = x1;
+    }
+}
+
 u32 bits_of(u64 x) { u32 b = 0; while (x) { b++; x >>= 1; } return b; }
 
 // sort (key,start,end,row) ascending; rows of equal (key,start,end) keep input order = ascending row
@@ -178,9 +201,32 @@ ivx_status sort64(ivx_ctx *ctx, int slot_a, int slot_b, const u32 *key, const i6
     int in_b = 0;
     if (nw == 2) {
         hipLaunchKernelGGL(k_pack1, dim3(grid1(n)), dim3(ST), 0, st, key, s, e, n, p, a[0], a[1]);
-        const ivx_sort_field f[1] = {{0, 0, (int)((total + 7) / 8 * 8)}};
-        IVX_TRY(ivx_radix_sort(ctx, 2, a, b, n, f, 1, &in_b));
-        u64 *const *o = in_b ? b : a;
+        // Few rows share a (key,start) when the rows are sparse in the coordinate space: then sort on those bits
+        // only -- the end bits would be three or four more digit passes -- and order the short runs of equal
+        // (key,start) afterwards (k_fix_runs).
+        const double per_pos = (double)n / ((double)(nkeys ? nkeys : 1) * (p.bits_s >= 62 ? 4.6e18 : (double)(1ull << p.bits_s)));
+        bool two_step = p.bits_e >= 8 && n >= (1u << 16) && per_pos <= 0.25 && !getenv("IVX_FORCE_SORT");
+        u64 *const *o = a;
+        if (two_step) {
+            const int lo = (int)p.bits_e;
+            const ivx_sort_field f[1] = {{0, lo, lo + (int)((total - p.bits_e + 7) / 8 * 8)}};
+            IVX_TRY(ivx_radix_sort(ctx, 2, a, b, n, f, 1, &in_b));
+            o = in_b ? b : a;
+            u32 *toolong = flags + 1;                                   // (upper half of the key-flag word; zeroed by the caller)
+            hipLaunchKernelGGL(k_fix_runs, dim3(grid1(n)), dim3(ST), 0, st, o[0], o[1], n, p.bits_e, toolong);
+            IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 8, flags, sizeof(u64), hipMemcpyDeviceToHost, st));
+            IVX_HIP(ctx, hipStreamSynchronize(st));
+            if (((const u32 *)(ctx->h_scalars + 8))[1]) {                // a long run of equal (key,start): the plain way after all
+                IVX_HIP(ctx, hipMemsetAsync(toolong, 0, sizeof(u32), st));
+                hipLaunchKernelGGL(k_pack1, dim3(grid1(n)), dim3(ST), 0, st, key, s, e, n, p, a[0], a[1]);
+                two_step = false;
+            }
+        }
+        if (!two_step) {
+            const ivx_sort_field f[1] = {{0, 0, (int)((total + 7) / 8 * 8)}};
+            IVX_TRY(ivx_radix_sort(ctx, 2, a, b, n, f, 1, &in_b));
+            o = in_b ? b : a;
+        }
         hipLaunchKernelGGL(k_unpack1, dim3(grid1(n)), dim3(ST), 0, st, (const u64 *)o[0], (const u64 *)o[1], n, p, ks, ss, es, rows);
     } else {
         hipLaunchKernelGGL(k_pack64, dim3(grid1(n)), dim3(ST), 0, st, key, s, e, n, nkeys, a[0], a[1], a[2], flags);

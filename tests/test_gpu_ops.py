@@ -308,6 +308,30 @@ def test_sweeps_on_coordinate_sorted_input(ctx, variant):
             os.environ.pop("IVX_FORCE_SORT", None)
 
 
+@pytest.mark.parametrize("dups", ["few", "long_runs"])
+def test_sweeps_sort_on_key_start_then_fix_runs(ctx, dups):
+    """Unsorted sparse input is radix-sorted on (key,start) only and runs of equal (key,start) are ordered by
+    (end,row) afterwards; runs longer than 64 rows send the call back to the full-width sort."""
+    rng = np.random.default_rng(77)
+    n = 150_000
+    k = rng.integers(0, 5, n).astype(np.uint32)
+    if dups == "few":
+        s = rng.integers(0, 3_000_000, n).astype(np.int64)              # a few percent of the rows share a start
+        s[::7] = s[1::7][: len(s[::7])]; k[::7] = k[1::7][: len(k[::7])]
+    else:
+        s = rng.choice(rng.integers(0, 2_000_000_000, 40), n).astype(np.int64)   # 40 distinct starts: runs of thousands
+    e = s + rng.integers(1, 5000, n)
+    e[::11] = e[1::11][: len(e[::11])]                                  # equal (start,end) too: the row index decides
+    rk, rs, re = synth(30_000, 413, nkeys=6, mean_len=150, span=3_000_000, dtype=np.int64)
+    re += 1
+    for strict in (False, True):
+        for g, w in zip(ctx.merge(k, s, e, n_keys=6, min_dist=2, strict=strict), orc.merge(k, s, e, min_dist=2, strict=strict)):
+            assert len(g) == len(w) and (g == w).all()
+        _same_cluster(ctx.cluster(k, s, e, n_keys=6, min_dist=0, strict=strict), orc.cluster(k, s, e, min_dist=0, strict=strict, n_keys=6))
+        for g, w in zip(ctx.subtract(k, s, e, rk, rs, re, n_keys=6, strict=strict), orc.subtract(k, s, e, rk, rs, re, strict=strict)):
+            assert len(g) == len(w) and (g == w).all()
+
+
 def test_merge_i64_extremes(ctx):
     big = np.iinfo(np.int64).max
     k = np.zeros(6, np.uint32)
