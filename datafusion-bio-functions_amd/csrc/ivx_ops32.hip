@@ -361,6 +361,27 @@ __global__ __launch_bounds__(OT) void k_nearest_emit(NearestView nv, const i32 *
 
 u32 grid1(u64 n) { return (u32)((n + OT - 1) / OT); }
 
+// after a stable sort on (key,start) alone: order the runs of equal (key,start) by end (rows of equal end keep their
+// row order); a run longer than NFIX_MAXRUN raises *toolong and the caller sorts on all three fields instead
+constexpr u32 NFIX_MAXRUN = 64;
+__global__ __launch_bounds__(OT) void k_fix_runs_se(u64 *__restrict__ w0, u64 *__restrict__ w1, u64 n, u32 *toolong)
+{
+    const u64 i = (u64)blockIdx.x * OT + threadIdx.x;
+    if (i >= n) return;
+    auto same = [&](u64 a, u64 b) { return (w0[a] >> 32) == (w0[b] >> 32) && (w1[a] >> 32) == (w1[b] >> 32); };
+    if (i && same(i - 1, i)) return;
+    if (i + 1 >= n || !same(i, i + 1)) return;
+    u32 len = 2;
+    while (i + len < n && len <= NFIX_MAXRUN && same(i, i + len)) len++;
+    if (len > NFIX_MAXRUN) { *toolong = 1; return; }
+    for (u32 a = 1; a < len; a++) {
+        const u64 x0 = w0[i + a], x1 = w1[i + a];
+        u32 b = a;
+        while (b > 0 && w0[i + b - 1] > x0) { w0[i + b] = w0[i + b - 1]; w1[i + b] = w1[i + b - 1]; b--; }
+        w0[i + b] = x0; w1[i + b] = x1;
+    }
+}
+
 // The two orders of the nearest index as records: rs by (key,start,end,row) (nearest_index.rs:50-55), re by
 // (key,end,start,row) (:77-82), ks = the key column (the same in both orders).  The second order is a STABLE
 // sort of the first by (key,end) alone -- ties keep their (start,row) order -- which is 5 digit passes
@@ -383,8 +404,28 @@ ivx_status nearest_sorted_records(ivx_ctx *ctx, const u32 *key, const i32 *s, co
     const bool presorted = ((const u32 *)(ctx->h_scalars + 8))[1] == 0 && !getenv("IVX_FORCE_SORT");
     int in_b = 0;
     if (!presorted) {
-        const ivx_sort_field f[3] = {{0, 0, 32}, {0, 32, 64}, {1, 32, 64}};
-        IVX_TRY(ivx_radix_sort(ctx, 2, a, b, n, f, 3, &in_b));
+        // (key,start) first -- equal (key,start) rows are rare -- then the short runs by end in place; all three
+        // fields only if a run turns out long
+        bool done = false;
+        if (n >= 4096 && !getenv("IVX_FORCE_SORT")) {
+            const ivx_sort_field f2[2] = {{0, 32, 64}, {1, 32, 64}};
+            IVX_TRY(ivx_radix_sort(ctx, 2, a, b, n, f2, 2, &in_b));
+            u64 *const *o = in_b ? b : a;
+            IVX_HIP(ctx, hipMemsetAsync(flags + 1, 0, sizeof(u32), ctx->stream));
+            hipLaunchKernelGGL(k_fix_runs_se, dim3(grid1(n)), dim3(OT), 0, ctx->stream, o[0], o[1], n, flags + 1);
+            IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 8, flags, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+            IVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            done = ((const u32 *)(ctx->h_scalars + 8))[1] == 0;
+            if (!done) {
+                IVX_HIP(ctx, hipMemsetAsync(flags + 1, 0, sizeof(u32), ctx->stream));
+                hipLaunchKernelGGL(k_pack_se, dim3(grid1(n)), dim3(OT), 0, ctx->stream, key, s, e, n, nkeys, a[0], a[1], flags);
+                in_b = 0;
+            }
+        }
+        if (!done) {
+            const ivx_sort_field f[3] = {{0, 0, 32}, {0, 32, 64}, {1, 32, 64}};
+            IVX_TRY(ivx_radix_sort(ctx, 2, a, b, n, f, 3, &in_b));
+        }
     }
     u64 *const *r = in_b ? b : a, *const *y = in_b ? a : b;
     hipLaunchKernelGGL(k_unpack_rec, dim3(grid1(n)), dim3(OT), 0, ctx->stream, (const u64 *)r[0], (const u64 *)r[1], n, ks, rs, y[0], y[1]);

@@ -248,6 +248,23 @@ def test_nearest_build_rows_already_sorted(ctx, variant):
     ix.free()
 
 
+def test_nearest_build_long_runs_of_equal_starts(ctx):
+    # thousands of build rows share a (key,start): the (key,start)-only sort of the index build hands over to the
+    # full sort; tie-breaks on end and row decide most answers
+    rng = np.random.default_rng(31)
+    nb = 30_000
+    bk = rng.integers(0, 3, nb).astype(np.uint32)
+    bs = rng.choice(rng.integers(0, 1_000_000, 25), nb).astype(np.int32)
+    be = (bs + rng.integers(0, 300, nb)).astype(np.int32)
+    pk, ps, pe = synth(20_000, 513, nkeys=4, mean_len=100, span=1_000_000)
+    ix = ctx.build(pyivx.KIND_NEAREST, bk, bs, be, n_keys=4)
+    for k, ovl in [(1, True), (1, False), (4, True)]:
+        gb, gp, gd = ctx.nearest(ix, pk, ps, pe, k=k, overlap=ovl)
+        wb, wp, wd = orc.nearest(bk, bs, be, pk, ps, pe, k=k, overlap=ovl)
+        assert len(gb) == len(wb) and (gb == wb).all() and (gp == wp).all() and (gd == wd).all(), (k, ovl)
+    ix.free()
+
+
 def test_nearest_empty_build_and_k0(ctx):
     e = np.empty(0, np.int32)
     ix = ctx.build(pyivx.KIND_NEAREST, np.empty(0, np.uint32), e, e, n_keys=3)
