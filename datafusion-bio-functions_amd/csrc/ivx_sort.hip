@@ -84,12 +84,23 @@ __global__ __launch_bounds__(RS_HT) void k_hist(const u64 *__restrict__ w, u64 n
     const u64 lo = (u64)blockIdx.x * RS_CHUNK;
     const u64 hi = lo + RS_CHUNK < n ? lo + RS_CHUNK : n;
     const u32 wv = threadIdx.x / IVX_WAVE;
-    for (u64 i0 = lo; i0 < hi; i0 += RS_HT) {
-        const u64 i = i0 + threadIdx.x;
-        const bool valid = i < hi;
-        const u32 d = valid ? (u32)((w[i] >> shift) & 0xFF) : 0u;
-        const u64 peers = match_digit(d, valid);
-        if (valid && mask_rank(peers) == 0) cnt[wv][d] += (u32)__popcll(peers);   // one lane per distinct digit
+    // four independent loads per thread in flight; per-wavefront LDS counters.  A digit shared by the whole
+    // wavefront (sorted or clustered keys) is counted once by one lane, anything else by LDS atomics, which
+    // random digits rarely make collide.
+    for (u64 i0 = lo; i0 < hi; i0 += RS_HT * 4) {
+        u64 x[4]; bool valid[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const u64 i = i0 + (u64)u * RS_HT + threadIdx.x; valid[u] = i < hi; x[u] = valid[u] ? w[i] : 0; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const u32 d = (u32)((x[u] >> shift) & 0xFF);
+            const u64 act = __ballot(valid[u]);
+            if (act == 0) continue;
+            const u32 first = (u32)__builtin_ctzll(act);
+            const u32 d0 = __shfl(d, first, IVX_WAVE);
+            if (__ballot(valid[u] && d == d0) == act) { if (lane_id() == first) cnt[wv][d0] += (u32)__popcll(act); }
+            else if (valid[u]) atomicAdd(&cnt[wv][d], 1u);
+        }
     }
     __syncthreads();
     {
