@@ -341,6 +341,7 @@ static ivx_status overlap_common(ivx_ctx *ctx, const ivx_index *ix, int mem, int
     }
     u64 tot = 0;
     if (mode != JP_EXISTS) IVX_TRY(read_scalar(ctx, 0, &tot));
+    if (mode == JP_COUNT && regions && pl.valid) pl.total = tot;
     if (total) *total = tot;
     if (mode == JP_FILL && tot > cap) return ctx->fail(IVX_ERR_CAPACITY, "pair buffers too small");
     IVX_TRY(copy_out(ctx, mem, per_row, d_row, n));

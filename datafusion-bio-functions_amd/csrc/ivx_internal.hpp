@@ -46,6 +46,7 @@ struct ivx_join_plan {
     int mem = 0;
     const void *in[3] = {};
     u64 n = 0;
+    u64 total = 0;                      // the pairs the count call found: the fill call's density hint, whatever its cap
     const void *ix = nullptr; u64 ix_serial = 0;
     hipStream_t stream = nullptr;
     const u32 *hist = nullptr; const u64 *pse = nullptr; const u32 *prow = nullptr;

@@ -1214,13 +1214,15 @@ ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nre
         }
     }
     unsigned long long *cur = (unsigned long long *)d_cursor;
-    if (mode == JP_FILL && dense_fill_wanted(cap, n)) {
+    // how dense the matches are: from the caller's capacity, or -- planned -- from what the count call found
+    const u64 hint = planned && pl.total < cap ? pl.total : cap;
+    if (mode == JP_FILL && dense_fill_wanted(hint, n)) {
         return dense_fill(ctx, jv, nreg, (const void *)pse, (const void *)prow, 1u, s, e, (const u32 *)hist, nblk, (const u32 *)unsorted, n, ob, op, cap, d_cursor);
     } else if (mode == JP_FILL) {   // single walk: pairs staged per wavefront, one output reservation per workgroup and round
         // rows per lane and batch by the expected matches per row (cap / n: callers size the output from the
         // count pass): two consecutive rounds of a wavefront must fit its 512-pair staging ring, else the
         // batch takes the slow direct path
-        const int b = fill_rows_per_lane(cap, n);
+        const int b = fill_rows_per_lane(hint, n);
 #define IVX_FILL1(B_, ID_) hipLaunchKernelGGL((k_probe_regions<1, B_, ID_>), dim3(RP_GRID), dim3(RP_T), 0, st, jv, ID_ ? (const void *)s : (const void *)pse, ID_ ? (const void *)e : (const void *)prow, (const u32 *)hist, nblk, RP_VGRID / RP_GRID, ob, op, cap, cur, 1u, 0u, (const u32 *)unsorted, dbg)
 #define IVX_FILL(B_) do { IVX_FILL1(B_, false); IVX_FILL1(B_, true); } while (0)
         switch (b) { case 1: IVX_FILL(1); break; case 2: IVX_FILL(2); break; case 4: IVX_FILL(4); break; default: IVX_FILL(8); }

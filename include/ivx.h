@@ -126,7 +126,8 @@ ivx_status ivx_probe_overlap_count(ivx_ctx *ctx, const ivx_index *ix, int mem,
  *       probe rows routed to the index regions (and, for IVX_MEM_HOST, copied to
  *       the device) in the context: the fill call for the same index, column
  *       pointers, n and stream that is the next call on that context skips that
- *       work -- the three columns must not change between the two calls.  Any
+ *       work (and takes the counted total, not cap, as the density hint) --
+ *       the three columns must not change between the two calls.  Any
  *       other call drops that state and the fill call does everything itself. */
 ivx_status ivx_probe_overlap_fill(ivx_ctx *ctx, const ivx_index *ix, int mem,
                                   const uint32_t *key, const int32_t *start, const int32_t *end, uint64_t n,

@@ -294,6 +294,7 @@ def test_join_count_then_fill_reuses_the_routed_rows(ctx, device):
             assert ctx.overlap_count(ix, *cols) == len(want[key])
             assert (pairs(*ctx.overlap_fill(ix, *cols, cap=len(want[key]))) == want[key]).all(), key
             assert (pairs(*ctx.overlap_fill(ix, *cols, cap=len(want[key]))) == want[key]).all(), key   # a second fill
+            assert (pairs(*ctx.overlap_fill(ix, *cols, cap=40 * len(want[key]))) == want[key]).all(), key   # blanket capacity: the counted total is the density hint
         # the plan belongs to the LAST count call
         assert ctx.overlap_count(ix, *P) == n_ap
         assert ctx.overlap_count(ix, *Q) == n_aq
