@@ -199,8 +199,8 @@ def test_device_pointers_match_host(ctx):
 
 
 def test_many_keys_all_operators(ctx):
-    # thousands of small contigs (scaffold-level assemblies): per-key tables no longer fit the LDS caches,
-    # the probe-region partition is unavailable (more keys than regions) and everything takes the general paths
+    # thousands of small contigs (scaffold-level assemblies): per-key tables no longer fit the LDS caches and the
+    # probe regions (at least one per key) need the two-pass routing
     nk = 5000
     bk, bs, be = synth(120_000, 31, nkeys=nk, mean_len=400, span=200_000)
     pk, ps, pe = synth(400_000, 32, nkeys=nk + 50, mean_len=150, span=200_000)
@@ -216,6 +216,16 @@ def test_many_keys_all_operators(ctx):
     k64, s64, e64 = bk, bs.astype(np.int64), be.astype(np.int64)
     for g, w in zip(ctx.merge(k64, s64, e64, n_keys=nk), orc.merge(k64, s64, e64)):
         assert len(g) == len(w) and (g == w).all()
+
+
+def test_more_keys_than_region_slots(ctx):
+    # 70 000 keys with rows: more than the 65 025 probe regions an index can have -- no region probe for it,
+    # every operator gathers from the index directly
+    nk = 70_000
+    bk, bs, be = synth(210_000, 33, nkeys=nk, mean_len=300, span=100_000)
+    bk[:nk] = np.arange(nk, dtype=np.uint32)                     # every key has a row
+    pk, ps, pe = synth(300_000, 34, nkeys=nk, mean_len=150, span=100_000)
+    _check_join(ctx, bk, bs, be, pk, ps, pe, nk)
 
 
 def test_unaligned_device_views(ctx):
