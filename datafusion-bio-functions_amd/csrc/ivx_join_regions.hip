@@ -772,18 +772,30 @@ __global__ __launch_bounds__(RP_T) void k_probe_dense(JoinIndexView ix, const vo
             const u32 lim = room > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)room;   // pairs of this piece the caller's buffers still hold
             u32 cnt = 0;                                                // pairs of the piece written so far (wavefront-uniform)
             // lock-step walk of one candidate list per lane: [ja, jb) of the staged slice or of the index in HBM
+            // (four candidates per lane are fetched before any of them is tested: the steps are otherwise one LDS round
+            // trip each, with nothing else in flight)
             auto walk = [&](u32 ja, u32 jb, bool lds) {
+                constexpr int U = 4;
                 while (__any(ja < jb)) {
-                    bool hit = false; u32 brow = 0;
-                    if (ja < jb) {
-                        if (lds) { const u64 x = S.s_ent[ja]; hit = (i32)(u32)x <= qe && (i32)(u32)(x >> 32) >= qs; if (hit) brow = S.s_row[ja]; }
-                        else { const ivx_ent x = ix.ent[ja]; hit = x.s <= qe && x.e >= qs; brow = x.row; }
-                        ja++;
+                    i32 cs_[U], ce_[U]; u32 cr_[U]; bool v[U];
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        v[u] = ja + u < jb;
+                        cs_[u] = 0; ce_[u] = 0; cr_[u] = 0;
+                        if (v[u]) {
+                            if (lds) { const u64 x = S.s_ent[ja + u]; cs_[u] = (i32)(u32)x; ce_[u] = (i32)(u32)(x >> 32); cr_[u] = S.s_row[ja + u]; }
+                            else { const ivx_ent x = ix.ent[ja + u]; cs_[u] = x.s; ce_[u] = x.e; cr_[u] = x.row; }
+                        }
                     }
-                    const u64 m = __ballot(hit);
-                    const u32 pos = cnt + mask_rank(m);
-                    if (hit && pos < lim) { obp[pos] = brow; opp[pos] = rowv; }
-                    cnt += (u32)__popcll(m);
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        const bool hit = v[u] && cs_[u] <= qe && ce_[u] >= qs;
+                        const u64 m = __ballot(hit);
+                        const u32 pos = cnt + mask_rank(m);
+                        if (hit && pos < lim) { obp[pos] = cr_[u]; opp[pos] = rowv; }
+                        cnt += (u32)__popcll(m);
+                    }
+                    ja = jb - ja > U ? ja + U : jb;
                 }
             };
             const i64 hi64 = (i64)qe - (i64)S.origin;
