@@ -1115,9 +1115,16 @@ ivx_status dense_fill(ivx_ctx *ctx, const JoinIndexView &jv, u32 nreg, const voi
 // more than IVX_MAXREG_WIDE regions: route the probe rows in two partition passes (super-region, then region inside
 // it), or not at all if they already come in region order; then the same probe kernels with a global region table
 ivx_status probe_two_level(ivx_ctx *ctx, const JoinIndexView &jv, int mode, u32 nreg, const u32 *key, const i32 *s, const i32 *e, u64 n,
-                           u32 *ob, u32 *op, u64 cap, u64 *d_cursor)
+                           u32 *ob, u32 *op, u64 cap, u64 *d_cursor, bool planned)
 {
     hipStream_t st = ctx->stream;
+    ivx_join_plan &pl = ctx->join_plan;
+    u32 *unsorted = (u32 *)(ctx->d_scalars + 10);
+    u32 *rfirst, *prow2; u64 *pse2;
+    if (planned) {                                                      // routed by the count call that sized this fill call
+        rfirst = const_cast<u32 *>(pl.hist); pse2 = const_cast<u64 *>(pl.pse); prow2 = const_cast<u32 *>(pl.prow);
+        s = pl.ds; e = pl.de;
+    } else {
     const u32 G = (nreg + IVX_MAXREG_WIDE - 1) / IVX_MAXREG_WIDE;       // regions per super-region
     if (G > P2_SUBMAX) return ctx->fail(IVX_ERR_INVALID, "overlap index with too many probe regions");
     const u32 nsuper = (nreg + G - 1) / G;
@@ -1127,7 +1134,7 @@ ivx_status probe_two_level(ivx_ctx *ctx, const JoinIndexView &jv, int mode, u32 
     const u64 nh1 = (u64)1024 * nblk1 + 1;
     const u32 grid2 = (u32)(n / PA_TILE) + nsuper + 1;                   // tiles of the second pass, at most
     const u64 nh2 = (u64)G * grid2 + 1;
-    u32 *hist1, *hist2, *tprefix, *rfirst, *prow1, *prow2; u64 *pse1, *pse2; unsigned char *sub1;
+    u32 *hist1, *hist2, *tprefix, *prow1; u64 *pse1; unsigned char *sub1;
     IVX_TRY(ctx->get_scratch(WS_SORTHIST, nh1 * sizeof(u32), (void **)&hist1));
     IVX_TRY(ctx->get_scratch(WS_T0, n * sizeof(u64), (void **)&pse1));
     IVX_TRY(ctx->get_scratch(WS_T1, n * sizeof(u32), (void **)&prow1));
@@ -1137,7 +1144,6 @@ ivx_status probe_two_level(ivx_ctx *ctx, const JoinIndexView &jv, int mode, u32 
     IVX_TRY(ctx->get_scratch(WS_T4, ((size_t)nsuper + 1) * sizeof(u32), (void **)&tprefix));
     IVX_TRY(ctx->get_scratch(WS_T5, nh2 * sizeof(u32), (void **)&hist2));
     IVX_TRY(ctx->get_scratch(WS_T6, ((size_t)nreg + 1) * sizeof(u32), (void **)&rfirst));
-    u32 *unsorted = (u32 *)(ctx->d_scalars + 10);
     IVX_HIP(ctx, hipMemsetAsync(hist1 + (nh1 - 1), 0, sizeof(u32), st));
     IVX_HIP(ctx, hipMemsetAsync(hist2, 0, nh2 * sizeof(u32), st));
     IVX_HIP(ctx, hipMemsetAsync(unsorted, 0, sizeof(u32), st));
@@ -1157,11 +1163,19 @@ ivx_status probe_two_level(ivx_ctx *ctx, const JoinIndexView &jv, int mode, u32 
     const u32 bgrid = (nreg + 1 + WR_T - 1) / WR_T;
     hipLaunchKernelGGL(k_p2_bounds, dim3(bgrid), dim3(WR_T), 0, st, nreg, G, nsuper, (const u32 *)hist1, nblk1, nh1, (const u32 *)tprefix, (const u32 *)hist2, rfirst, (const u32 *)unsorted);
     hipLaunchKernelGGL(k_sorted_bounds, dim3(bgrid), dim3(WR_T), 0, st, jv, key, s, n, nreg, rfirst, (const u32 *)unsorted);
+    if (mode == JP_COUNT) {                                             // leave the routed rows for the fill call (ivx_capi.hip fills in whose they are)
+        pl.hist = rfirst; pl.pse = pse2; pl.prow = prow2; pl.ds = s; pl.de = e; pl.chunk = 0; pl.nblk = 1;
+        pl.slots = 0;
+        for (int slot : {WS_SORTHIST, WS_T0, WS_T1, WS_T2, WS_SA0, WS_SA1, WS_T4, WS_T5, WS_T6, WS_IN_START, WS_IN_END}) pl.slots |= 1ull << slot;
+        pl.valid = true;
+    }
+    }
     unsigned long long *cur = (unsigned long long *)d_cursor;
-    if (mode == JP_FILL && dense_fill_wanted(cap, n))
+    const u64 hint = planned && pl.total < cap ? pl.total : cap;
+    if (mode == JP_FILL && dense_fill_wanted(hint, n))
         return dense_fill(ctx, jv, nreg, (const void *)pse2, (const void *)prow2, 1u, s, e, (const u32 *)rfirst, 1u, (const u32 *)unsorted, n, ob, op, cap, d_cursor);
     if (mode == JP_FILL) {
-        const int bsel = fill_rows_per_lane(cap, n);
+        const int bsel = fill_rows_per_lane(hint, n);
 #define IVX_FILL2(B_, ID_) hipLaunchKernelGGL((k_probe_regions<1, B_, ID_>), dim3(RP_GRID), dim3(RP_T), 0, st, jv, ID_ ? (const void *)s : (const void *)pse2, ID_ ? (const void *)e : (const void *)prow2, (const u32 *)rfirst, 1u, RP_VGRID / RP_GRID, ob, op, cap, cur, 1u, 0u, (const u32 *)unsorted, 0)
 #define IVX_FILLW(B_) do { IVX_FILL2(B_, false); IVX_FILL2(B_, true); } while (0)
         switch (bsel) { case 1: IVX_FILLW(1); break; case 2: IVX_FILLW(2); break; case 4: IVX_FILLW(4); break; default: IVX_FILLW(8); }
@@ -1183,10 +1197,7 @@ ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nre
 {
     if (n == 0) return IVX_OK;
     ivx_join_plan &pl = ctx->join_plan;
-    if (nreg > IVX_MAXREG_WIDE) {
-        if (planned) return ctx->fail(IVX_ERR_INVALID, "join plan for a two-digit region table");   // never recorded
-        return probe_two_level(ctx, jv, mode, nreg, key, s, e, n, ob, op, cap, d_cursor);
-    }
+    if (nreg > IVX_MAXREG_WIDE) return probe_two_level(ctx, jv, mode, nreg, key, s, e, n, ob, op, cap, d_cursor, planned);
     hipStream_t st = ctx->stream;
 #ifdef IVX_ABLATE          // profiling builds only (tools/variant.sh <name> -DIVX_ABLATE; tools/ablate.sh): IVX_DBG bit switches
     const int dbg = getenv("IVX_DBG") ? atoi(getenv("IVX_DBG")) : 0;

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "datafusion-bio-functions_amd"))
 import pyivx, synth
 dev = torch.device("cuda:0")
-bk, bs, be = synth.gen_torch(1_000_000, 1000, 24, 0x5EED0004, dev)
+bk, bs, be = synth.gen_torch(int(os.environ.get("NB", 1_000_000)), 1000, 24, 0x5EED0004, dev)
 pk, ps, pe = synth.gen_torch(int(os.environ.get("NP", 100_000_000)), 150, 24, 0x5EED0005, dev)
 ctx = pyivx.Ctx(0); ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 ix = ctx.build(pyivx.KIND_OVERLAP, bk, bs, be, n_keys=24)
