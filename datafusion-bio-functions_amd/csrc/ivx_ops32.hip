@@ -285,26 +285,29 @@ __global__ __launch_bounds__(OT) void k_probe_nearest1(NearestView nv, const u32
 // k > 1: up to k candidates per probe row into tmp[i*k ..], rows-per-probe into cnt[i]
 __global__ __launch_bounds__(OT) void k_probe_nearestk(NearestView nv, const u32 *__restrict__ pkey, const i32 *__restrict__ ps,
                                                        const i32 *__restrict__ pe, u64 n, int strict, int include_overlaps, u32 kk,
-                                                       u32 *__restrict__ tmp, u32 *__restrict__ cnt)
+                                                       u32 *__restrict__ tmp, i64 *__restrict__ tmpd, u32 *__restrict__ cnt)
 {
     NearestCtx x; x.nv = nv; x.sh_s = nv.by_start.hdr[0]; x.sh_e = nv.by_end.hdr[0]; x.sh_p = nv.pmax.hdr[0];
     for (u64 i = (u64)blockIdx.x * OT + threadIdx.x; i < n; i += (u64)gridDim.x * OT) {
         const u32 k = pkey ? pkey[i] : 0u;
-        i32 qs = ps[i], qe = pe[i];
+        const i32 rs = ps[i], re = pe[i];
+        i32 qs = rs, qe = re;
         if (strict) { qs = wadd(qs, 1); qe = wsub(qe, 1); }
-        u32 *mine = tmp + i * (u64)kk;                                   // holds indices into by_start/by_end: bit31 = by_end
+        u32 *mine = tmp + i * (u64)kk;                                   // the build rows taken so far (the emit pass only copies)
+        i64 *mined = tmpd ? tmpd + i * (u64)kk : nullptr;                // and their distances on the raw coordinates (nearest.rs:367-374)
+        auto take = [&](u32 at, const Cand &c) { mine[at] = c.row; if (mined) mined[at] = cand_dist(rs, re, c.s, c.e); };
         u32 found = 0;
         if (k < nv.by_start.nkeys && nv.by_start.kcnt[k] != 0) {
             const u32 off = nv.by_start.koff[k], cnt_k = nv.by_start.kcnt[k];
             const u32 pend = grid_rank_le<4>(nv.by_start, x.sh_s, k, qe);
             // seen-set of nearest_k (:122, :134, :186): rows already taken
-            auto seen = [&](u32 row) { for (u32 q = 0; q < found; q++) { const u32 t = mine[q]; const u32 r = (t >> 31) ? nv.re[t & 0x7FFFFFFFu].row : nv.rs[t].row; if (r == row) return true; } return false; };
+            auto seen = [&](u32 row) { for (u32 q = 0; q < found; q++) if (mine[q] == row) return true; return false; };
             if (include_overlaps && pend > off && nv.rs[pend - 1].pmax >= qs) {
                 // all overlaps in (start,end,row) order = by_start order filtered by end >= qs (:125-137)
                 u32 j = grid_rank_lt<4>(nv.pmax, x.sh_p, k, qs);
                 for (; j < pend && found < kk; j++) {
                     const ivx_nrec r = nv.rs[j];
-                    if (r.b >= qs && !seen(r.row)) mine[found++] = j;
+                    if (r.b >= qs && !seen(r.row)) { Cand c; c.s = r.a; c.e = r.b; c.row = r.row; take(found++, c); }
                 }
             }
             if (found < kk) {                                            // alternate the two cursors (:144-189)
@@ -315,11 +318,11 @@ __global__ __launch_bounds__(OT) void k_probe_nearestk(NearestView nv, const u32
                     bool take_left;
                     if (hl && hr) take_left = cmp_cand(qs, qe, x.by_end(li - 1), x.by_start(ri)) <= 0;
                     else take_left = hl;
-                    u32 tag; Cand c;
-                    if (take_left) { li--; c = x.by_end(li); tag = li | 0x80000000u; }
-                    else { c = x.by_start(ri); tag = ri; ri++; }
+                    Cand c;
+                    if (take_left) { li--; c = x.by_end(li); }
+                    else { c = x.by_start(ri); ri++; }
                     if (!include_overlaps && cand_dist(qs, qe, c.s, c.e) == 0) continue;
-                    if (!seen(c.row)) mine[found++] = tag;
+                    if (!seen(c.row)) take(found++, c);
                 }
             }
         }
@@ -334,8 +337,8 @@ __global__ __launch_bounds__(OT) void k_rows_of(const u32 *__restrict__ cnt, u64
     if (i == n) rows[i] = 0;
 }
 
-__global__ __launch_bounds__(OT) void k_nearest_emit(NearestView nv, const i32 *__restrict__ ps, const i32 *__restrict__ pe, u64 n, u32 kk,
-                                                     const u32 *__restrict__ tmp, const u32 *__restrict__ cnt, const u64 *__restrict__ offs,
+__global__ __launch_bounds__(OT) void k_nearest_emit(u64 n, u32 kk, const u32 *__restrict__ tmp, const i64 *__restrict__ tmpd,
+                                                     const u32 *__restrict__ cnt, const u64 *__restrict__ offs,
                                                      u64 cap, u32 *ob, u32 *op, i64 *od)
 {
     for (u64 i = (u64)blockIdx.x * OT + threadIdx.x; i < n; i += (u64)gridDim.x * OT) {
@@ -347,14 +350,9 @@ __global__ __launch_bounds__(OT) void k_nearest_emit(NearestView nv, const i32 *
         }
         for (u32 q = 0; q < c; q++, at++) {
             if (at >= cap) break;
-            const u32 t = tmp[i * (u64)kk + q];
-            const u32 j = t & 0x7FFFFFFFu;
-            const bool e = t >> 31;
-            const ivx_nrec r = e ? nv.re[j] : nv.rs[j];
-            const i32 s_ = e ? r.b : r.a, e_ = e ? r.a : r.b;
-            ob[at] = r.row;
+            ob[at] = tmp[i * (u64)kk + q];
             op[at] = (u32)i;
-            if (od) od[at] = cand_dist(ps[i], pe[i], s_, e_);
+            if (od) od[at] = tmpd[i * (u64)kk + q];
         }
     }
 }
@@ -575,17 +573,18 @@ ivx_status ivx_nearest_probe(ivx_ctx *ctx, const ivx_index *ix, const u32 *key, 
             IVX_HIP(ctx, hipMemsetAsync(cnt, 0, n * sizeof(u32), st));
             hipLaunchKernelGGL(k_rows_of, dim3(grid1(n + 1)), dim3(OT), 0, st, (const u32 *)cnt, n, offs);
             IVX_TRY(ivx_scan_exclusive_u64(ctx, offs, n + 1));
-            hipLaunchKernelGGL(k_nearest_emit, dim3(ivx_stream_grid(n, OT * 4)), dim3(OT), 0, st, ix->nv, s, e, n, 1u, (const u32 *)cnt, (const u32 *)cnt, (const u64 *)offs, cap, ob, op, od);
+            hipLaunchKernelGGL(k_nearest_emit, dim3(ivx_stream_grid(n, OT * 4)), dim3(OT), 0, st, n, 1u, (const u32 *)cnt, (const i64 *)nullptr, (const u32 *)cnt, (const u64 *)offs, cap, ob, op, od);
         }
         IVX_HIP(ctx, hipGetLastError());
         *rows = n;
         return IVX_OK;
     }
-    u32 *tmp, *cnt; u64 *offs;
+    u32 *tmp, *cnt; u64 *offs; i64 *tmpd = nullptr;
     IVX_TRY(ctx->get_scratch(WS_T2, n * (u64)k * sizeof(u32), (void **)&tmp));
+    if (od) IVX_TRY(ctx->get_scratch(WS_T5, n * (u64)k * sizeof(i64), (void **)&tmpd));
     IVX_TRY(ctx->get_scratch(WS_T3, n * sizeof(u32), (void **)&cnt));
     IVX_TRY(ctx->get_scratch(WS_T4, (n + 1) * sizeof(u64), (void **)&offs));
-    hipLaunchKernelGGL(k_probe_nearestk, dim3(ivx_stream_grid(n, OT * 2)), dim3(OT), 0, st, ix->nv, key, s, e, n, strict, include_overlaps, k, tmp, cnt);
+    hipLaunchKernelGGL(k_probe_nearestk, dim3(ivx_stream_grid(n, OT * 2)), dim3(OT), 0, st, ix->nv, key, s, e, n, strict, include_overlaps, k, tmp, tmpd, cnt);
     hipLaunchKernelGGL(k_rows_of, dim3(grid1(n + 1)), dim3(OT), 0, st, (const u32 *)cnt, n, offs);
     IVX_TRY(ivx_scan_exclusive_u64(ctx, offs, n + 1));
     IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 3, offs + n, sizeof(u64), hipMemcpyDeviceToHost, st));
@@ -593,7 +592,7 @@ ivx_status ivx_nearest_probe(ivx_ctx *ctx, const ivx_index *ix, const u32 *key, 
     const u64 total = ctx->h_scalars[3];
     *rows = total;
     if (total > cap) return ctx->fail(IVX_ERR_CAPACITY, "nearest: output buffers too small");
-    hipLaunchKernelGGL(k_nearest_emit, dim3(ivx_stream_grid(n, OT * 2)), dim3(OT), 0, st, ix->nv, s, e, n, k, (const u32 *)tmp, (const u32 *)cnt, (const u64 *)offs, cap, ob, op, od);
+    hipLaunchKernelGGL(k_nearest_emit, dim3(ivx_stream_grid(n, OT * 2)), dim3(OT), 0, st, n, k, (const u32 *)tmp, (const i64 *)tmpd, (const u32 *)cnt, (const u64 *)offs, cap, ob, op, od);
     IVX_HIP(ctx, hipGetLastError());
     return IVX_OK;
 }
