@@ -62,3 +62,30 @@ def test_rust_ffi_declarations_match_the_header():
     rust = sigs(open(os.path.join(ROOT, "integration", "rust", "hip_ffi.rs")).read(), r"pub fn (ivx_\w+)\(([^;]*?)\)\s*(?:->\s*[\w\* ]+)?;")
     assert len(rust) >= 19
     assert {k: hdr.get(k) for k in rust} == rust
+
+
+def test_rust_join_stream_declarations_match_the_header():
+    # integration/rust/join_stream_ffi.rs: the brh_* functions it declares exist in include/bio_ranges_host.h with the
+    # same number of parameters, and the host library exports them
+    import ctypes
+    import re
+
+    def sigs(text, pat):
+        out = {}
+        for m in re.finditer(pat, text, re.S):
+            args = re.sub(r"/\*.*?\*/", "", m.group(2), flags=re.S)
+            out[m.group(1)] = 0 if args.strip() in ("", "void") else args.count(",") + 1
+        return out
+
+    hdr = sigs(open(os.path.join(ROOT, "include", "bio_ranges_host.h")).read(), r"\b(brh_\w+)\s*\(([^;{]*?)\)\s*;")
+    rust = sigs(open(os.path.join(ROOT, "integration", "rust", "join_stream_ffi.rs")).read(), r"pub fn (brh_\w+)\(([^;]*?)\)\s*(?:->\s*[\w\* ]+)?;")
+    assert len(rust) >= 8
+    assert {k: hdr.get(k) for k in rust} == rust
+    lib = os.path.join(ROOT, "datafusion-bio-functions_amd", "lib", "libbio_ranges_hip.so")
+    if os.path.exists(lib):
+        try:
+            h = ctypes.CDLL(lib)
+        except OSError:
+            pytest.skip("host library not loadable here (needs the HIP runtime)")
+        for name in rust:
+            assert hasattr(h, name), name
