@@ -187,9 +187,16 @@ struct ivx_index {
     RankGridView gs{}, ge{};
     CoverageView cv{};
     NearestView nv{};
+    JoinIndexView nroute{};     // nearest index: regions that only ROUTE big probe batches (origin/span/kcnt/kreg/rkey/hdr; no cells)
+    u32 nroute_nreg = 0;
     int flags = 0;              // IVX_IXF_*
 };
 enum { IVX_IXF_REGION_ROWVAL = 1 };   // count/coverage index: jv is usable for the region-partitioned per-row probe
+
+// probe rows routed to the regions of a routing view (ivx_route_rows): scanned [1024][nblk] histogram (region r starts at
+// hist[r * nblk]), the rows' (start,end) in routed order, each row's index inside its one-tile chunk; *unsorted == 0:
+// the rows came in region order already and nothing was moved
+struct ivx_routed { const u32 *hist; const u64 *pse; const unsigned short *cidx; const u32 *unsorted; u32 nblk, chunk; };
 
 // ---------------------------------------------------------------- internal API
 // scan.hip
@@ -210,6 +217,8 @@ ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nre
 // per-row-output operators through the same partition (count_overlaps: jv over the build rows, no row with
 // end < start; coverage: jv over the merged nodes)
 enum { IVX_RV_COUNT = 0, IVX_RV_COVERAGE = 1, IVX_RV_PER_ROW = 2, IVX_RV_EXISTS = 3 };
+ivx_status ivx_route_rows(ivx_ctx *ctx, const JoinIndexView &rv, const u32 *key, const i32 *s, const i32 *e, u64 n, u32 adj, ivx_routed *out);
+ivx_status ivx_unroute_pair(ivx_ctx *ctx, const ivx_routed &r, u64 n, const u32 *vb, const i64 *vd, u32 *ob, u32 *op, i64 *od);
 ivx_status ivx_rowval_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nreg, int kind,
                                     const u32 *key, const i32 *s, const i32 *e, u64 n, int strict, void *out, u64 *d_total);
 

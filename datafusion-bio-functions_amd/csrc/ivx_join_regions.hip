@@ -973,6 +973,81 @@ ivx_status ivx_rowval_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 n
     return IVX_OK;
 }
 
+// ------------------------------------------------------------------ routing for operators with their own probe (nearest)
+namespace {
+
+// two values per row back into input order: the un-permute above for (u32, i64) pairs with one-tile chunks; rows that
+// were never routed get (IVX_NULL_IDX, -1); op = the row's own index
+__global__ __launch_bounds__(PA_T) void k_unpermute_pair(const u32 *__restrict__ vb, const i64 *__restrict__ vd, const unsigned short *__restrict__ cidx,
+                                                         const u32 *__restrict__ offs, u32 nblk, u64 n, u32 *__restrict__ ob, u32 *__restrict__ op,
+                                                         i64 *__restrict__ od, const u32 *unsorted)
+{
+    constexpr int ND = 1024;
+    __shared__ u32 s_b[PA_TILE];
+    __shared__ i64 s_d[PA_TILE];
+    __shared__ u32 s_pre[ND + 1], s_g[ND];
+    __shared__ u32 scan_lds[PA_T / IVX_WAVE + 1];
+    if (*unsorted == 0) return;                             // the probe wrote the outputs in place
+    const u32 tid = threadIdx.x, blk = blockIdx.x;
+    const u64 lo = (u64)blk * PA_TILE;
+    const u32 len = (u32)(lo + PA_TILE < n ? PA_TILE : n - lo);
+    const u32 g = offs[(u64)tid * nblk + blk];
+    const u32 c = offs[(u64)tid * nblk + blk + 1] - g;
+    u32 tot;
+    const u32 ex = block_excl_scan<u32, PA_T>(c, scan_lds, &tot);
+    s_pre[tid] = ex; s_g[tid] = g;
+    if (tid == 0) s_pre[ND] = tot;
+    for (u32 t = tid; t < PA_TILE; t += PA_T) { s_b[t] = IVX_NULL_IDX; s_d[t] = -1; }
+    __syncthreads();
+    const u32 wv = tid / IVX_WAVE, ln = lane_id();
+    const u32 per = (tot + PA_T / IVX_WAVE - 1) / (PA_T / IVX_WAVE);
+    const u32 t_lo = wv * per, t_hi = t_lo + per < tot ? t_lo + per : tot;
+    u32 r = 0;
+    if (t_lo < t_hi) { u32 a = 0, b = ND; while (a < b) { const u32 m = (a + b + 1) >> 1; if (s_pre[m] <= t_lo + ln && m < ND) a = m; else b = m - 1; } r = a; }
+    for (u32 t = t_lo + ln; t < t_hi; t += IVX_WAVE) {
+        while (r + 1 < ND && s_pre[r + 1] <= t) r++;
+        const u64 at = (u64)s_g[r] + (t - s_pre[r]);
+        const u32 ci = cidx[at];
+        s_b[ci] = vb[at];
+        if (vd) s_d[ci] = vd[at];
+    }
+    __syncthreads();
+    for (u32 t = tid; t < len; t += PA_T) { ob[lo + t] = s_b[t]; op[lo + t] = (u32)(lo + t); if (od) od[lo + t] = s_d[t]; }
+}
+
+}  // namespace
+
+ivx_status ivx_route_rows(ivx_ctx *ctx, const JoinIndexView &rv, const u32 *key, const i32 *s, const i32 *e, u64 n, u32 adj, ivx_routed *out)
+{
+    hipStream_t st = ctx->stream;
+    const u32 chunk = PA_TILE;
+    const u32 nblk = (u32)((n + chunk - 1) / chunk);
+    const u64 nh = (u64)1024 * nblk + 1;
+    u32 *hist; u64 *pse; unsigned short *cidx;
+    IVX_TRY(ctx->get_scratch(WS_SORTHIST, nh * sizeof(u32), (void **)&hist));
+    IVX_TRY(ctx->get_scratch(WS_T0, n * sizeof(u64), (void **)&pse));
+    IVX_TRY(ctx->get_scratch(WS_T1, n * sizeof(unsigned short), (void **)&cidx));
+    u32 *unsorted = (u32 *)(ctx->d_scalars + 10);
+    IVX_HIP(ctx, hipMemsetAsync(hist + (nh - 1), 0, sizeof(u32), st));
+    IVX_HIP(ctx, hipMemsetAsync(unsorted, 0, sizeof(u32), st));
+    const bool vec = (((uintptr_t)key | (uintptr_t)s | (uintptr_t)e) & 15) == 0;
+    if (vec) hipLaunchKernelGGL((k_part_hist<true, 1024>), dim3(nblk), dim3(PA_T), 0, st, rv, key, s, n, nblk, chunk, hist, adj, unsorted);
+    else hipLaunchKernelGGL((k_part_hist<false, 1024>), dim3(nblk), dim3(PA_T), 0, st, rv, key, s, n, nblk, chunk, hist, adj, unsorted);
+    IVX_TRY(ivx_scan_exclusive_u32(ctx, hist, nh));
+    if (vec) hipLaunchKernelGGL((k_part_scatter<true, unsigned short, 1024>), dim3(nblk), dim3(PA_T), 0, st, rv, key, s, e, n, nblk, (const u32 *)hist, pse, cidx, chunk, adj, (const u32 *)unsorted, 0);
+    else hipLaunchKernelGGL((k_part_scatter<false, unsigned short, 1024>), dim3(nblk), dim3(PA_T), 0, st, rv, key, s, e, n, nblk, (const u32 *)hist, pse, cidx, chunk, adj, (const u32 *)unsorted, 0);
+    IVX_HIP(ctx, hipGetLastError());
+    out->hist = hist; out->pse = pse; out->cidx = cidx; out->unsorted = unsorted; out->nblk = nblk; out->chunk = chunk;
+    return IVX_OK;
+}
+
+ivx_status ivx_unroute_pair(ivx_ctx *ctx, const ivx_routed &r, u64 n, const u32 *vb, const i64 *vd, u32 *ob, u32 *op, i64 *od)
+{
+    hipLaunchKernelGGL(k_unpermute_pair, dim3(r.nblk), dim3(PA_T), 0, ctx->stream, vb, vd, r.cidx, r.hist, r.nblk, n, ob, op, od, r.unsorted);
+    IVX_HIP(ctx, hipGetLastError());
+    return IVX_OK;
+}
+
 namespace {
 
 constexpr int WR_T = 256;

@@ -249,36 +249,108 @@ __device__ __forceinline__ bool first_overlap(const NearestCtx &x, u32 k, u32 of
     return true;
 }
 
+// the one nearest build row of key k for the (already strict-adjusted) query [qs,qe]
+__device__ __forceinline__ bool nearest_one(const NearestCtx &x, u32 k, i32 qs, i32 qe, int include_overlaps, Cand *best)
+{
+    const NearestView &nv = x.nv;
+    bool found = false;
+    if (k < nv.by_start.nkeys && nv.by_start.kcnt[k] != 0) {
+        const u32 off = nv.by_start.koff[k], cnt = nv.by_start.kcnt[k];
+        u32 pend;
+        if (include_overlaps) found = first_overlap(x, k, off, qs, qe, &pend, best);
+        else pend = grid_rank_le<4>(nv.by_start, x.sh_s, k, qe);
+        if (!found) {                                                    // nearest_non_overlap_one :192-220
+            const u32 li = grid_rank_lt<4>(nv.by_end, x.sh_e, k, qs);    // by_end.partition_point(last < start)
+            const bool hl = li > off, hr = pend < off + cnt;
+            if (hl && hr) {
+                const Cand l = x.by_end(li - 1), r = x.by_start(pend);
+                *best = cmp_cand(qs, qe, l, r) <= 0 ? l : r; found = true;
+            } else if (hl) { *best = x.by_end(li - 1); found = true; }
+            else if (hr) { *best = x.by_start(pend); found = true; }
+        }
+    }
+    return found;
+}
+
+// gate (nullable): run only if *gate == 0 (the routed path found the probe rows in region order and moved nothing)
 __global__ __launch_bounds__(OT) void k_probe_nearest1(NearestView nv, const u32 *__restrict__ pkey, const i32 *__restrict__ ps,
                                                        const i32 *__restrict__ pe, u64 n, int strict, int include_overlaps,
-                                                       u32 *__restrict__ ob, u32 *__restrict__ op, i64 *__restrict__ od)
+                                                       u32 *__restrict__ ob, u32 *__restrict__ op, i64 *__restrict__ od, const u32 *gate)
 {
+    if (gate && *gate != 0) return;
     NearestCtx x; x.nv = nv; x.sh_s = nv.by_start.hdr[0]; x.sh_e = nv.by_end.hdr[0]; x.sh_p = nv.pmax.hdr[0];
     for (u64 i = (u64)blockIdx.x * OT + threadIdx.x; i < n; i += (u64)gridDim.x * OT) {
         const u32 k = pkey ? pkey[i] : 0u;
         const i32 rs = ps[i], re = pe[i];
         i32 qs = rs, qe = re;
         if (strict) { qs = wadd(qs, 1); qe = wsub(qe, 1); }              // nearest.rs:341-344
-        bool found = false;
         Cand best{};
-        if (k < nv.by_start.nkeys && nv.by_start.kcnt[k] != 0) {
-            const u32 off = nv.by_start.koff[k], cnt = nv.by_start.kcnt[k];
-            u32 pend;
-            if (include_overlaps) found = first_overlap(x, k, off, qs, qe, &pend, &best);
-            else pend = grid_rank_le<4>(nv.by_start, x.sh_s, k, qe);
-            if (!found) {                                                // nearest_non_overlap_one :192-220
-                const u32 li = grid_rank_lt<4>(nv.by_end, x.sh_e, k, qs);   // by_end.partition_point(last < start)
-                const bool hl = li > off, hr = pend < off + cnt;
-                if (hl && hr) {
-                    const Cand l = x.by_end(li - 1), r = x.by_start(pend);
-                    best = cmp_cand(qs, qe, l, r) <= 0 ? l : r; found = true;
-                } else if (hl) { best = x.by_end(li - 1); found = true; }
-                else if (hr) { best = x.by_start(pend); found = true; }
-            }
-        }
+        const bool found = nearest_one(x, k, qs, qe, include_overlaps, &best);
         ob[i] = found ? best.row : IVX_NULL_IDX;
         op[i] = (u32)i;
         if (od) od[i] = found ? cand_dist(rs, re, best.s, best.e) : -1;  // raw coordinates, nearest.rs:367-374
+    }
+}
+
+// The same over probe rows ROUTED by coordinate region (ivx_route_rows): rows of one region sit together, so the
+// gathers of a wavefront fall into a few MB of the index instead of all of it.  pse = (qs,qe) already strict-adjusted;
+// the key of a row follows from its region (rkey); results at the routed position.
+constexpr int NR_T = 256;
+__global__ __launch_bounds__(NR_T) void k_nearest_routed(NearestView nv, const u32 *__restrict__ rkey, u32 nreg, const u64 *__restrict__ pse,
+                                                         const u32 *__restrict__ offs, u32 nblk, u32 adj, int include_overlaps,
+                                                         u32 *__restrict__ vb, i64 *__restrict__ vd, const u32 *unsorted)
+{
+    __shared__ u32 s_rfirst[IVX_MAXREG_WIDE + 2];
+    if (*unsorted == 0) return;
+    for (u32 t = threadIdx.x; t <= nreg; t += NR_T) s_rfirst[t] = offs[(u64)t * nblk];
+    __syncthreads();
+    const u64 total = s_rfirst[nreg];
+    NearestCtx x; x.nv = nv; x.sh_s = nv.by_start.hdr[0]; x.sh_e = nv.by_end.hdr[0]; x.sh_p = nv.pmax.hdr[0];
+    // workgroups are dealt to the 8 XCDs round robin: XCD x sweeps the x-th eighth of the routed rows, so that every
+    // L2 sees one stretch of the index and the index is read from HBM once, not once per XCD (gridDim.x is a multiple of 8)
+    const u32 xcd = blockIdx.x & 7u, nb = gridDim.x >> 3, bi = blockIdx.x >> 3;
+    const u64 seg_lo = total * xcd / 8, seg_hi = total * (xcd + 1) / 8;
+    for (u64 i = seg_lo + (u64)bi * NR_T + threadIdx.x; i < seg_hi; i += (u64)nb * NR_T) {
+        u32 a = 0, b = nreg;                                            // last region whose first row is <= i (empty regions share a start: take the last)
+        while (a < b) { const u32 m = (a + b + 1) >> 1; if (s_rfirst[m] <= i) a = m; else b = m - 1; }
+        const u32 k = rkey[a];
+        const u64 w = pse[i];
+        const i32 qs = (i32)(u32)w, qe = (i32)(u32)(w >> 32);
+        Cand best{};
+        const bool found = nearest_one(x, k, qs, qe, include_overlaps, &best);
+        vb[i] = found ? best.row : IVX_NULL_IDX;
+        if (vd) vd[i] = found ? cand_dist(wsub(qs, (i32)adj), wadd(qe, (i32)adj), best.s, best.e) : -1;
+    }
+}
+
+// routing regions of a nearest index: 2^sh0-wide cells over every key's span of starts, R (a power of two) cells per
+// region, at most IVX_MAXREG_WIDE regions that never straddle a key; nreg = 0 if more keys than that have rows
+__global__ __launch_bounds__(1024) void k_nroute_layout(const i32 *origin, const u32 *span, const u32 *kcnt, u32 nkeys, u32 *kreg, u32 *rkey, u32 *hdr)
+{
+    __shared__ u64 red[1024 / IVX_WAVE + 1];
+    const u32 t = threadIdx.x;
+    const u32 sh0 = 10;
+    auto regions_for = [&](u32 cs) -> u64 {
+        u64 a = 0;
+        for (u32 k = t; k < nkeys; k += 1024) if (kcnt[k]) a += (((u64)(span[k] >> sh0) + 1) + ((1ull << cs) - 1)) >> cs;
+        return block_sum<u64, 1024>(a, red);
+    };
+    u32 cs = 0;
+    while (cs < 32 && regions_for(cs) > IVX_MAXREG_WIDE) cs++;
+    const bool ok = regions_for(cs) <= IVX_MAXREG_WIDE;
+    u64 rrun = 0;
+    for (u32 k0 = 0; k0 < nkeys; k0 += 1024) {
+        const u32 k = k0 + t;
+        u64 c = (ok && k < nkeys && kcnt[k]) ? ((((u64)(span[k] >> sh0) + 1) + ((1ull << cs) - 1)) >> cs) : 0;
+        u64 tot;
+        const u64 ex = block_excl_scan<u64, 1024>(c, red, &tot);
+        if (k < nkeys) { kreg[k] = (u32)(rrun + ex); for (u64 r = 0; r < c; r++) rkey[rrun + ex + r] = k; }
+        rrun += tot;
+    }
+    if (t == 0) {
+        kreg[nkeys] = (u32)rrun;
+        hdr[HDR_SH0] = sh0; hdr[HDR_CS] = cs < 31 ? cs : 31; hdr[HDR_NREG] = ok ? (u32)rrun : 0u; hdr[HDR_RCELLS] = 1u << (cs < 31 ? cs : 31);
+        hdr[HDR_RMUL_LO] = 0; hdr[HDR_RMUL_HI] = 0;
     }
 }
 
@@ -531,8 +603,23 @@ ivx_status ivx_nearest_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const 
     IVX_TRY(ivx_grid_build(ctx, ix, ks, &re->a, n, nkeys, &ix->nv.by_end, true, 4));
     IVX_TRY(ivx_grid_build(ctx, ix, ks, &rs->pmax, n, nkeys, &ix->nv.pmax, true, 4));
     ix->nv.rs = rs; ix->nv.re = re;
+    {   // regions that route big unsorted probe batches (no cells of their own: the by_start grid's per-key spans)
+        u32 *kreg, *rkey, *rhdr;
+        IVX_TRY(ivx_index_alloc(ctx, ix, ((size_t)nkeys + 1) * sizeof(u32), (void **)&kreg));
+        IVX_TRY(ivx_index_alloc(ctx, ix, ((size_t)IVX_MAXREG_WIDE + 1) * sizeof(u32), (void **)&rkey));
+        IVX_TRY(ivx_index_alloc(ctx, ix, HDR_WORDS * sizeof(u32), (void **)&rhdr));
+        IVX_HIP(ctx, hipMemsetAsync(rhdr, 0, HDR_WORDS * sizeof(u32), st));
+        const RankGridView &g = ix->nv.by_start;
+        hipLaunchKernelGGL(k_nroute_layout, dim3(1), dim3(1024), 0, st, g.origin, g.span, g.kcnt, nkeys, kreg, rkey, rhdr);
+        IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 32, rhdr, HDR_WORDS * sizeof(u32), hipMemcpyDeviceToHost, st));
+        ix->nroute = JoinIndexView{};
+        ix->nroute.origin = g.origin; ix->nroute.span = g.span; ix->nroute.kcnt = g.kcnt; ix->nroute.kreg = kreg; ix->nroute.rkey = rkey;
+        ix->nroute.hdr = rhdr; ix->nroute.nkeys = nkeys;
+    }
     IVX_HIP(ctx, hipGetLastError());
-    return check_keyflag(ctx);
+    IVX_TRY(check_keyflag(ctx));                                          // synchronises
+    ix->nroute_nreg = ((const u32 *)(ctx->h_scalars + 32))[HDR_NREG];
+    return IVX_OK;
 }
 
 // ---------------------------------------------------------------------------- probes (called from ivx_capi.hip)
@@ -564,8 +651,22 @@ ivx_status ivx_nearest_probe(ivx_ctx *ctx, const ivx_index *ix, const u32 *key, 
     if (k <= 1) {
         // k == 0 yields no candidate, i.e. one NULL row per probe row, like k == 1 on an empty index (nearest_index.rs:111)
         if (cap < n) { *rows = n; return ctx->fail(IVX_ERR_CAPACITY, "nearest: output buffers too small"); }
-        if (k == 1) {
-            hipLaunchKernelGGL(k_probe_nearest1, dim3(ivx_stream_grid(n, OT * 4)), dim3(OT), 0, st, ix->nv, key, s, e, n, strict, include_overlaps, ob, op, od);
+        bool routed = ix->nroute_nreg > 0 && n >= (1u << 21);
+        if (const char *f = getenv("IVX_NEAREST_PATH")) routed = !strcmp(f, "routed") ? ix->nroute_nreg > 0 : (!strcmp(f, "direct") ? false : routed);
+        if (k == 1 && routed) {
+            // big batches: route the probe rows by coordinate region first, probe in that order, put the answers back
+            ivx_routed R;
+            IVX_TRY(ivx_route_rows(ctx, ix->nroute, key, s, e, n, strict ? 1u : 0u, &R));
+            u32 *vb; i64 *vd = nullptr;
+            IVX_TRY(ctx->get_scratch(WS_T2, n * sizeof(u32), (void **)&vb));
+            if (od) IVX_TRY(ctx->get_scratch(WS_T3, n * sizeof(i64), (void **)&vd));
+            hipLaunchKernelGGL(k_nearest_routed, dim3((ivx_stream_grid(n, NR_T * 4) + 7u) & ~7u), dim3(NR_T), 0, st, ix->nv, ix->nroute.rkey, ix->nroute_nreg, R.pse,
+                               R.hist, R.nblk, strict ? 1u : 0u, include_overlaps, vb, vd, R.unsorted);
+            IVX_TRY(ivx_unroute_pair(ctx, R, n, vb, vd, ob, op, od));
+            // rows that came in region order were not moved: the plain kernel answers them in place
+            hipLaunchKernelGGL(k_probe_nearest1, dim3(ivx_stream_grid(n, OT * 4)), dim3(OT), 0, st, ix->nv, key, s, e, n, strict, include_overlaps, ob, op, od, R.unsorted);
+        } else if (k == 1) {
+            hipLaunchKernelGGL(k_probe_nearest1, dim3(ivx_stream_grid(n, OT * 4)), dim3(OT), 0, st, ix->nv, key, s, e, n, strict, include_overlaps, ob, op, od, (const u32 *)nullptr);
         } else {
             u32 *cnt; u64 *offs;
             IVX_TRY(ctx->get_scratch(WS_T3, n * sizeof(u32), (void **)&cnt));

@@ -223,10 +223,27 @@ def test_nearest_random(ctx, seed):
         bs[::23] = bs[1::23][: len(bs[::23])]            # duplicate starts -> tie-breaks on end/row
     ix = ctx.build(pyivx.KIND_NEAREST, bk, bs, be, n_keys=nk + 1)
     for k, ovl, strict in [(1, True, False), (1, False, False), (1, True, True), (3, True, False), (4, False, True), (2, True, True)]:
-        gb, gp, gd = ctx.nearest(ix, pk, ps, pe, k=k, overlap=ovl, strict=strict)
         wb, wp, wd = orc.nearest(bk, bs, be, pk, ps, pe, k=k, overlap=ovl, strict=strict)
-        assert len(gb) == len(wb), (k, ovl, strict)
-        assert (gb == wb).all() and (gp == wp).all() and (gd == wd).all(), (k, ovl, strict)
+        for path in ("direct", "routed"):                   # k = 1: gathers in input order / probe rows routed by region first
+            os.environ["IVX_NEAREST_PATH"] = path
+            try:
+                gb, gp, gd = ctx.nearest(ix, pk, ps, pe, k=k, overlap=ovl, strict=strict)
+                if k == 1:
+                    gb2, gp2 = ctx.nearest(ix, pk, ps, pe, k=k, overlap=ovl, strict=strict, distance=False)[:2]
+                    assert (gb2 == wb).all() and (gp2 == wp).all(), (k, ovl, strict, path, "no distance")
+            finally:
+                del os.environ["IVX_NEAREST_PATH"]
+            assert len(gb) == len(wb), (k, ovl, strict, path)
+            assert (gb == wb).all() and (gp == wp).all() and (gd == wd).all(), (k, ovl, strict, path)
+    # probe rows already in (key, start) order: the routed path moves nothing and answers in place
+    o = np.lexsort((ps, pk)); pk, ps, pe = pk[o].copy(), ps[o].copy(), pe[o].copy()
+    wb, wp, wd = orc.nearest(bk, bs, be, pk, ps, pe, k=1)
+    os.environ["IVX_NEAREST_PATH"] = "routed"
+    try:
+        gb, gp, gd = ctx.nearest(ix, pk, ps, pe, k=1)
+    finally:
+        del os.environ["IVX_NEAREST_PATH"]
+    assert (gb == wb).all() and (gp == wp).all() and (gd == wd).all()
 
 
 @pytest.mark.parametrize("variant", ["sorted", "one_inversion", "ends_descending"])

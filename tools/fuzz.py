@@ -43,6 +43,7 @@ for it in range(iters):
     strict = bool(rng.integers(0, 2))
     path = str(rng.choice(["direct", "regions"]))
     os.environ["IVX_JOIN_PATH"] = path; os.environ["IVX_ROWVAL_PATH"] = path
+    os.environ["IVX_NEAREST_PATH"] = "routed" if path == "regions" else "direct"
     dense = str(rng.choice(["0", "1", ""]))                       # pair writer of the region path: ring, count-scan-write, by density
     if dense: os.environ["IVX_DENSE"] = dense
     else: os.environ.pop("IVX_DENSE", None)
