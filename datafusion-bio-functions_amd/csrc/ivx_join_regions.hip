@@ -977,10 +977,10 @@ ivx_status ivx_rowval_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 n
 namespace {
 
 // two values per row back into input order: the un-permute above for (u32, i64) pairs with one-tile chunks; rows that
-// were never routed get (IVX_NULL_IDX, -1); op = the row's own index
+// were never routed get (IVX_NULL_IDX, dflt); op = the row's own index; vb / ob / op may be null (one i64 value per row)
 __global__ __launch_bounds__(PA_T) void k_unpermute_pair(const u32 *__restrict__ vb, const i64 *__restrict__ vd, const unsigned short *__restrict__ cidx,
                                                          const u32 *__restrict__ offs, u32 nblk, u64 n, u32 *__restrict__ ob, u32 *__restrict__ op,
-                                                         i64 *__restrict__ od, const u32 *unsorted)
+                                                         i64 *__restrict__ od, const u32 *unsorted, i64 dflt)
 {
     constexpr int ND = 1024;
     __shared__ u32 s_b[PA_TILE];
@@ -997,7 +997,7 @@ __global__ __launch_bounds__(PA_T) void k_unpermute_pair(const u32 *__restrict__
     const u32 ex = block_excl_scan<u32, PA_T>(c, scan_lds, &tot);
     s_pre[tid] = ex; s_g[tid] = g;
     if (tid == 0) s_pre[ND] = tot;
-    for (u32 t = tid; t < PA_TILE; t += PA_T) { s_b[t] = IVX_NULL_IDX; s_d[t] = -1; }
+    for (u32 t = tid; t < PA_TILE; t += PA_T) { s_b[t] = IVX_NULL_IDX; s_d[t] = dflt; }
     __syncthreads();
     const u32 wv = tid / IVX_WAVE, ln = lane_id();
     const u32 per = (tot + PA_T / IVX_WAVE - 1) / (PA_T / IVX_WAVE);
@@ -1008,11 +1008,15 @@ __global__ __launch_bounds__(PA_T) void k_unpermute_pair(const u32 *__restrict__
         while (r + 1 < ND && s_pre[r + 1] <= t) r++;
         const u64 at = (u64)s_g[r] + (t - s_pre[r]);
         const u32 ci = cidx[at];
-        s_b[ci] = vb[at];
+        if (vb) s_b[ci] = vb[at];
         if (vd) s_d[ci] = vd[at];
     }
     __syncthreads();
-    for (u32 t = tid; t < len; t += PA_T) { ob[lo + t] = s_b[t]; op[lo + t] = (u32)(lo + t); if (od) od[lo + t] = s_d[t]; }
+    for (u32 t = tid; t < len; t += PA_T) {
+        if (ob) ob[lo + t] = s_b[t];
+        if (op) op[lo + t] = (u32)(lo + t);
+        if (od) od[lo + t] = vd ? s_d[t] : dflt;
+    }
 }
 
 }  // namespace
@@ -1041,9 +1045,9 @@ ivx_status ivx_route_rows(ivx_ctx *ctx, const JoinIndexView &rv, const u32 *key,
     return IVX_OK;
 }
 
-ivx_status ivx_unroute_pair(ivx_ctx *ctx, const ivx_routed &r, u64 n, const u32 *vb, const i64 *vd, u32 *ob, u32 *op, i64 *od)
+ivx_status ivx_unroute_pair(ivx_ctx *ctx, const ivx_routed &r, u64 n, const u32 *vb, const i64 *vd, u32 *ob, u32 *op, i64 *od, i64 dflt)
 {
-    hipLaunchKernelGGL(k_unpermute_pair, dim3(r.nblk), dim3(PA_T), 0, ctx->stream, vb, vd, r.cidx, r.hist, r.nblk, n, ob, op, od, r.unsorted);
+    hipLaunchKernelGGL(k_unpermute_pair, dim3(r.nblk), dim3(PA_T), 0, ctx->stream, vb, vd, r.cidx, r.hist, r.nblk, n, ob, op, od, r.unsorted, dflt);
     IVX_HIP(ctx, hipGetLastError());
     return IVX_OK;
 }

@@ -34,22 +34,28 @@ ivx_status check_keyflag(ivx_ctx *ctx)
 
 // ======================================================================= a4
 
+__device__ __forceinline__ i64 count_one(const RankGridView &gs, const RankGridView &ge, u32 shs, u32 she, u32 k, i32 qs, i32 qe)
+{
+    if (k < gs.nkeys && gs.kcnt[k] != 0 && !(qe < qs)) {                 // :42-44, unknown contig -> 0 (:265)
+        const u32 started = grid_rank_le(gs, shs, k, qe);                // starts.partition_point(|v| v <= end)
+        const u32 ended_before = grid_rank_lt(ge, she, k, qs);           // ends.partition_point(|v| v < start)
+        return (i64)started - (i64)ended_before;
+    }
+    return 0;
+}
+
+// gate (nullable): run only if *gate == 0 (the routed path found the probe rows in region order and moved nothing)
 __global__ __launch_bounds__(OT) void k_probe_count(RankGridView gs, RankGridView ge, const u32 *__restrict__ pkey,
                                                     const i32 *__restrict__ ps, const i32 *__restrict__ pe, u64 n,
-                                                    int strict, i64 *__restrict__ out)
+                                                    int strict, i64 *__restrict__ out, const u32 *gate)
 {
+    if (gate && *gate != 0) return;
     const u32 shs = gs.hdr[0], she = ge.hdr[0];
     for (u64 i = (u64)blockIdx.x * OT + threadIdx.x; i < n; i += (u64)gridDim.x * OT) {
         const u32 k = pkey ? pkey[i] : 0u;
         i32 qs = ps[i], qe = pe[i];
         if (strict) { qs = wadd(qs, 1); qe = wsub(qe, 1); }              // interval_tree.rs:253-256
-        i64 c = 0;
-        if (k < gs.nkeys && gs.kcnt[k] != 0 && !(qe < qs)) {             // :42-44, unknown contig -> 0 (:265)
-            const u32 started = grid_rank_le(gs, shs, k, qe);            // starts.partition_point(|v| v <= end)
-            const u32 ended_before = grid_rank_lt(ge, she, k, qs);       // ends.partition_point(|v| v < start)
-            c = (i64)started - (i64)ended_before;
-        }
-        out[i] = c;
+        out[i] = count_one(gs, ge, shs, she, k, qs, qe);
     }
 }
 
@@ -116,15 +122,8 @@ __device__ __forceinline__ i32 cov_term(i32 qs, i32 qe, i32 first, i32 last)
     return d > 1 ? d : 1;
 }
 
-__global__ __launch_bounds__(OT) void k_probe_coverage(CoverageView cv, const u32 *__restrict__ pkey,
-                                                       const i32 *__restrict__ ps, const i32 *__restrict__ pe, u64 n,
-                                                       int strict, i64 *__restrict__ out)
+__device__ __forceinline__ i64 coverage_one(const CoverageView &cv, u32 shf, u32 shl, u32 k, i32 qs, i32 qe)
 {
-    const u32 shf = cv.first.hdr[0], shl = cv.last.hdr[0];
-    for (u64 i = (u64)blockIdx.x * OT + threadIdx.x; i < n; i += (u64)gridDim.x * OT) {
-        const u32 k = pkey ? pkey[i] : 0u;
-        i32 qs = ps[i], qe = pe[i];
-        if (strict) { qs = wadd(qs, 1); qe = wsub(qe, 1); }              // :185-188
         i32 cov = 0;
         if (k < cv.first.nkeys && cv.first.kcnt[k] != 0) {
             // merged nodes are disjoint and ascending: those with first <= qe are a prefix [..hi),
@@ -142,7 +141,46 @@ __global__ __launch_bounds__(OT) void k_probe_coverage(CoverageView cv, const u3
                 }
             }
         }
-        out[i] = (i64)cov;                                               // :207 `count as i64`
+        return (i64)cov;                                                 // :207 `count as i64`
+}
+
+__global__ __launch_bounds__(OT) void k_probe_coverage(CoverageView cv, const u32 *__restrict__ pkey,
+                                                       const i32 *__restrict__ ps, const i32 *__restrict__ pe, u64 n,
+                                                       int strict, i64 *__restrict__ out, const u32 *gate)
+{
+    if (gate && *gate != 0) return;
+    const u32 shf = cv.first.hdr[0], shl = cv.last.hdr[0];
+    for (u64 i = (u64)blockIdx.x * OT + threadIdx.x; i < n; i += (u64)gridDim.x * OT) {
+        const u32 k = pkey ? pkey[i] : 0u;
+        i32 qs = ps[i], qe = pe[i];
+        if (strict) { qs = wadd(qs, 1); qe = wsub(qe, 1); }              // :185-188
+        out[i] = coverage_one(cv, shf, shl, k, qs, qe);
+    }
+}
+
+// count_overlaps / coverage over probe rows routed by coordinate region (ivx_route_rows; build sides too big for the
+// LDS-slice pipeline): the rank-grid gathers of a wavefront then fall into one stretch of the grids.  XCD x sweeps the
+// x-th eighth of the routed rows (gridDim.x is a multiple of 8); values at the routed positions.
+template <bool COVERAGE>
+__global__ __launch_bounds__(OT) void k_rowval_routed(RankGridView gs, RankGridView ge, CoverageView cv, const u32 *__restrict__ rkey, u32 nreg,
+                                                      const u64 *__restrict__ pse, const u32 *__restrict__ offs, u32 nblk,
+                                                      i64 *__restrict__ vd, const u32 *unsorted)
+{
+    __shared__ u32 s_rfirst[IVX_MAXREG_WIDE + 2];
+    if (*unsorted == 0) return;
+    for (u32 t = threadIdx.x; t <= nreg; t += OT) s_rfirst[t] = offs[(u64)t * nblk];
+    __syncthreads();
+    const u64 total = s_rfirst[nreg];
+    const u32 sa = COVERAGE ? cv.first.hdr[0] : gs.hdr[0], sb = COVERAGE ? cv.last.hdr[0] : ge.hdr[0];
+    const u32 xcd = blockIdx.x & 7u, nb = gridDim.x >> 3, bi = blockIdx.x >> 3;
+    const u64 seg_lo = total * xcd / 8, seg_hi = total * (xcd + 1) / 8;
+    for (u64 i = seg_lo + (u64)bi * OT + threadIdx.x; i < seg_hi; i += (u64)nb * OT) {
+        u32 a = 0, b = nreg;                                            // last region whose first row is <= i
+        while (a < b) { const u32 m = (a + b + 1) >> 1; if (s_rfirst[m] <= i) a = m; else b = m - 1; }
+        const u32 k = rkey[a];
+        const u64 w = pse[i];
+        const i32 qs = (i32)(u32)w, qe = (i32)(u32)(w >> 32);           // strict-adjusted by the routing pass
+        vd[i] = COVERAGE ? coverage_one(cv, sa, sb, k, qs, qe) : count_one(gs, ge, sa, sb, k, qs, qe);
     }
 }
 
@@ -508,6 +546,27 @@ ivx_status nearest_sorted_records(ivx_ctx *ctx, const u32 *key, const i32 *s, co
     return IVX_OK;
 }
 
+// regions that only ROUTE big unsorted probe batches (no cells of their own): per-key spans of rank grid g.  The
+// region count arrives on the host with the caller's next synchronisation (route_view_ready).
+ivx_status build_route_view(ivx_ctx *ctx, ivx_index *ix, const RankGridView &g)
+{
+    hipStream_t st = ctx->stream;
+    const u32 nkeys = ix->nkeys;
+    u32 *kreg, *rkey, *rhdr;
+    IVX_TRY(ivx_index_alloc(ctx, ix, ((size_t)nkeys + 1) * sizeof(u32), (void **)&kreg));
+    IVX_TRY(ivx_index_alloc(ctx, ix, ((size_t)IVX_MAXREG_WIDE + 1) * sizeof(u32), (void **)&rkey));
+    IVX_TRY(ivx_index_alloc(ctx, ix, HDR_WORDS * sizeof(u32), (void **)&rhdr));
+    IVX_HIP(ctx, hipMemsetAsync(rhdr, 0, HDR_WORDS * sizeof(u32), st));
+    hipLaunchKernelGGL(k_nroute_layout, dim3(1), dim3(1024), 0, st, g.origin, g.span, g.kcnt, nkeys, kreg, rkey, rhdr);
+    IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 48, rhdr, HDR_WORDS * sizeof(u32), hipMemcpyDeviceToHost, st));
+    ix->nroute = JoinIndexView{};
+    ix->nroute.origin = g.origin; ix->nroute.span = g.span; ix->nroute.kcnt = g.kcnt; ix->nroute.kreg = kreg; ix->nroute.rkey = rkey;
+    ix->nroute.hdr = rhdr; ix->nroute.nkeys = nkeys;
+    IVX_HIP(ctx, hipGetLastError());
+    return IVX_OK;
+}
+void route_view_ready(ivx_ctx *ctx, ivx_index *ix) { ix->nroute_nreg = ((const u32 *)(ctx->h_scalars + 48))[HDR_NREG]; }
+
 }  // namespace
 
 // ---------------------------------------------------------------------------- builds
@@ -522,9 +581,11 @@ ivx_status ivx_count_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i3
     if (n) hipLaunchKernelGGL(k_any_inverted, dim3(grid1(n)), dim3(OT), 0, ctx->stream, s, e, n, (u32 *)(ctx->d_scalars + 9));
     IVX_TRY(ivx_grid_build(ctx, ix, key, s, n, ix->nkeys, &ix->gs));     // starts, sorted independently (:35)
     IVX_TRY(ivx_grid_build(ctx, ix, key, e, n, ix->nkeys, &ix->ge));     // ends (:36)
+    IVX_TRY(build_route_view(ctx, ix, ix->gs));
     IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 9, ctx->d_scalars + 9, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
     IVX_TRY(check_keyflag(ctx));                                          // synchronises
     if (*(u32 *)(ctx->h_scalars + 9) == 0) ix->flags |= IVX_IXF_REGION_ROWVAL;
+    route_view_ready(ctx, ix);
     return IVX_OK;
 }
 
@@ -575,7 +636,9 @@ ivx_status ivx_coverage_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const
     ix->cv.nfirst = nfirst; ix->cv.nlast = nlast; ix->cv.pw = (const i64 *)pw;
     IVX_HIP(ctx, hipGetLastError());
     // overlap index over the merged nodes for the region-partitioned probe of big batches
-    IVX_TRY(ivx_join_build(ctx, ix, rk, nfirst, nlast, m));
+    IVX_TRY(build_route_view(ctx, ix, ix->cv.first));
+    IVX_TRY(ivx_join_build(ctx, ix, rk, nfirst, nlast, m));             // (synchronises)
+    route_view_ready(ctx, ix);
     ix->flags |= IVX_IXF_REGION_ROWVAL;
     return IVX_OK;
 }
@@ -603,32 +666,50 @@ ivx_status ivx_nearest_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const 
     IVX_TRY(ivx_grid_build(ctx, ix, ks, &re->a, n, nkeys, &ix->nv.by_end, true, 4));
     IVX_TRY(ivx_grid_build(ctx, ix, ks, &rs->pmax, n, nkeys, &ix->nv.pmax, true, 4));
     ix->nv.rs = rs; ix->nv.re = re;
-    {   // regions that route big unsorted probe batches (no cells of their own: the by_start grid's per-key spans)
-        u32 *kreg, *rkey, *rhdr;
-        IVX_TRY(ivx_index_alloc(ctx, ix, ((size_t)nkeys + 1) * sizeof(u32), (void **)&kreg));
-        IVX_TRY(ivx_index_alloc(ctx, ix, ((size_t)IVX_MAXREG_WIDE + 1) * sizeof(u32), (void **)&rkey));
-        IVX_TRY(ivx_index_alloc(ctx, ix, HDR_WORDS * sizeof(u32), (void **)&rhdr));
-        IVX_HIP(ctx, hipMemsetAsync(rhdr, 0, HDR_WORDS * sizeof(u32), st));
-        const RankGridView &g = ix->nv.by_start;
-        hipLaunchKernelGGL(k_nroute_layout, dim3(1), dim3(1024), 0, st, g.origin, g.span, g.kcnt, nkeys, kreg, rkey, rhdr);
-        IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 32, rhdr, HDR_WORDS * sizeof(u32), hipMemcpyDeviceToHost, st));
-        ix->nroute = JoinIndexView{};
-        ix->nroute.origin = g.origin; ix->nroute.span = g.span; ix->nroute.kcnt = g.kcnt; ix->nroute.kreg = kreg; ix->nroute.rkey = rkey;
-        ix->nroute.hdr = rhdr; ix->nroute.nkeys = nkeys;
-    }
+    IVX_TRY(build_route_view(ctx, ix, ix->nv.by_start));
     IVX_HIP(ctx, hipGetLastError());
     IVX_TRY(check_keyflag(ctx));                                          // synchronises
-    ix->nroute_nreg = ((const u32 *)(ctx->h_scalars + 32))[HDR_NREG];
+    route_view_ready(ctx, ix);
     return IVX_OK;
 }
 
 // ---------------------------------------------------------------------------- probes (called from ivx_capi.hip)
 
+// big batches the LDS-slice pipeline cannot take (too many regions, or build rows with end < start): route the probe
+// rows by coordinate region, gather from the rank grids in that order, put the values back
+static bool rowval_routed_wanted(const ivx_index *ix, u64 n)
+{
+    if (ix->nroute_nreg == 0) return false;
+    const char *f = getenv("IVX_ROWVAL_PATH");                          // tests: "direct" | "regions" | "routed"
+    if (f && !strcmp(f, "routed")) return true;
+    if (f) return false;
+    return n >= (1u << 21);
+}
+
+static ivx_status rowval_routed(ivx_ctx *ctx, const ivx_index *ix, bool coverage, const u32 *key, const i32 *s, const i32 *e, u64 n, int strict, i64 *out)
+{
+    hipStream_t st = ctx->stream;
+    ivx_routed R;
+    IVX_TRY(ivx_route_rows(ctx, ix->nroute, key, s, e, n, strict ? 1u : 0u, &R));
+    i64 *vd;
+    IVX_TRY(ctx->get_scratch(WS_T3, n * sizeof(i64), (void **)&vd));
+    const u32 grid = (ivx_stream_grid(n, OT * 4) + 7u) & ~7u;
+    if (coverage) hipLaunchKernelGGL((k_rowval_routed<true>), dim3(grid), dim3(OT), 0, st, ix->gs, ix->ge, ix->cv, ix->nroute.rkey, ix->nroute_nreg, R.pse, R.hist, R.nblk, vd, R.unsorted);
+    else hipLaunchKernelGGL((k_rowval_routed<false>), dim3(grid), dim3(OT), 0, st, ix->gs, ix->ge, ix->cv, ix->nroute.rkey, ix->nroute_nreg, R.pse, R.hist, R.nblk, vd, R.unsorted);
+    IVX_TRY(ivx_unroute_pair(ctx, R, n, nullptr, vd, nullptr, nullptr, out, 0));      // rows that could not be routed: 0, as the reference answers
+    // rows that came in region order were not moved: the plain kernels answer them in place
+    if (coverage) hipLaunchKernelGGL(k_probe_coverage, dim3(ivx_stream_grid(n, OT * 4)), dim3(OT), 0, st, ix->cv, key, s, e, n, strict, out, R.unsorted);
+    else hipLaunchKernelGGL(k_probe_count, dim3(ivx_stream_grid(n, OT * 4)), dim3(OT), 0, st, ix->gs, ix->ge, key, s, e, n, strict, out, R.unsorted);
+    IVX_HIP(ctx, hipGetLastError());
+    return IVX_OK;
+}
+
 ivx_status ivx_count_probe(ivx_ctx *ctx, const ivx_index *ix, const u32 *key, const i32 *s, const i32 *e, u64 n, int strict, i64 *out)
 {
     if (n == 0) return IVX_OK;
     if (rowval_regions_wanted(ix, n)) return ivx_rowval_probe_regions(ctx, ix->jv, ix->jv_nreg, IVX_RV_COUNT, key, s, e, n, strict, out, nullptr);
-    hipLaunchKernelGGL(k_probe_count, dim3(ivx_stream_grid(n, OT * 4)), dim3(OT), 0, ctx->stream, ix->gs, ix->ge, key, s, e, n, strict, out);
+    if (rowval_routed_wanted(ix, n)) return rowval_routed(ctx, ix, false, key, s, e, n, strict, out);
+    hipLaunchKernelGGL(k_probe_count, dim3(ivx_stream_grid(n, OT * 4)), dim3(OT), 0, ctx->stream, ix->gs, ix->ge, key, s, e, n, strict, out, (const u32 *)nullptr);
     IVX_HIP(ctx, hipGetLastError());
     return IVX_OK;
 }
@@ -637,7 +718,8 @@ ivx_status ivx_coverage_probe(ivx_ctx *ctx, const ivx_index *ix, const u32 *key,
 {
     if (n == 0) return IVX_OK;
     if (rowval_regions_wanted(ix, n)) return ivx_rowval_probe_regions(ctx, ix->jv, ix->jv_nreg, IVX_RV_COVERAGE, key, s, e, n, strict, out, nullptr);
-    hipLaunchKernelGGL(k_probe_coverage, dim3(ivx_stream_grid(n, OT * 4)), dim3(OT), 0, ctx->stream, ix->cv, key, s, e, n, strict, out);
+    if (rowval_routed_wanted(ix, n)) return rowval_routed(ctx, ix, true, key, s, e, n, strict, out);
+    hipLaunchKernelGGL(k_probe_coverage, dim3(ivx_stream_grid(n, OT * 4)), dim3(OT), 0, ctx->stream, ix->cv, key, s, e, n, strict, out, (const u32 *)nullptr);
     IVX_HIP(ctx, hipGetLastError());
     return IVX_OK;
 }
@@ -662,7 +744,7 @@ ivx_status ivx_nearest_probe(ivx_ctx *ctx, const ivx_index *ix, const u32 *key, 
             if (od) IVX_TRY(ctx->get_scratch(WS_T3, n * sizeof(i64), (void **)&vd));
             hipLaunchKernelGGL(k_nearest_routed, dim3((ivx_stream_grid(n, NR_T * 4) + 7u) & ~7u), dim3(NR_T), 0, st, ix->nv, ix->nroute.rkey, ix->nroute_nreg, R.pse,
                                R.hist, R.nblk, strict ? 1u : 0u, include_overlaps, vb, vd, R.unsorted);
-            IVX_TRY(ivx_unroute_pair(ctx, R, n, vb, vd, ob, op, od));
+            IVX_TRY(ivx_unroute_pair(ctx, R, n, vb, vd, ob, op, od, -1));
             // rows that came in region order were not moved: the plain kernel answers them in place
             hipLaunchKernelGGL(k_probe_nearest1, dim3(ivx_stream_grid(n, OT * 4)), dim3(OT), 0, st, ix->nv, key, s, e, n, strict, include_overlaps, ob, op, od, R.unsorted);
         } else if (k == 1) {

@@ -28,8 +28,9 @@ def _i32(*a):
 
 
 def _paths():
-    """count_overlaps / coverage probes: rank-grid gathers ("direct") and the region partition ("regions")"""
-    for path in ("direct", "regions"):
+    """count_overlaps / coverage probes: rank-grid gathers in input order ("direct"), the region partition with LDS
+    slices ("regions"), rank-grid gathers over probe rows routed by coordinate region ("routed")"""
+    for path in ("direct", "regions", "routed"):
         os.environ["IVX_ROWVAL_PATH"] = path
         try:
             yield path

@@ -42,7 +42,7 @@ for it in range(iters):
     pk, ps, pe = rows(rng, npr, nk, span, int(rng.choice([1, 150, 5000])), inverted=float(rng.choice([0, 0.01])), sort=srt, unknown=int(rng.choice([0, 2])))
     strict = bool(rng.integers(0, 2))
     path = str(rng.choice(["direct", "regions"]))
-    os.environ["IVX_JOIN_PATH"] = path; os.environ["IVX_ROWVAL_PATH"] = path
+    os.environ["IVX_JOIN_PATH"] = path; os.environ["IVX_ROWVAL_PATH"] = path if rng.random() < 0.7 else "routed"
     os.environ["IVX_NEAREST_PATH"] = "routed" if path == "regions" else "direct"
     dense = str(rng.choice(["0", "1", ""]))                       # pair writer of the region path: ring, count-scan-write, by density
     if dense: os.environ["IVX_DENSE"] = dense
