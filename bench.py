@@ -133,6 +133,8 @@ def main():
     for _ in range(args.warmup):
         step()
     probe_ms.clear(); build_ms.clear()
+    import gc
+    gc.collect(); gc.disable()                                  # no collector pauses inside the 10-odd milliseconds being timed
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -143,6 +145,7 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     tot_pairs, tot_rows = pairs, n_probe
     if dist is not None:
         elapsed = shard.max_over_ranks(dist, elapsed, dev)

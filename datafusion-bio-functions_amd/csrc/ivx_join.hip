@@ -175,9 +175,10 @@ __global__ __launch_bounds__(1024) void k_join_layout(const i32 *kmin, const i32
         for (u32 k = t; k < nkeys; k += 1024) { const u64 c = cells_of(kcnt[k], span[k], sh0); a += (c + r - 1) / r; }
         return block_sum<u64, 1024>(a, red);
     };
-    if (R && regions_for(1ull << 40) > regmax) R = 0;                   // more keys with rows than region slots: no region probe for this index
+    if (R && nkeys > regmax && regions_for(1ull << 40) > regmax) R = 0; // more keys with rows than region slots: no region probe for this index
     if (R) {
-        while (regions_for(R) > regmax) { R *= 2; }                     // the caller's tables hold regmax regions
+        // (a power-of-two R straight from the search above is known to fit: s_tot[clo] regions)
+        if (!(pow2 && clo < 32 && s_tot[clo] <= regmax)) while (regions_for(R) > regmax) { R *= 2; }   // the caller's tables hold regmax regions
         if (!pow2) {
             u64 mc = 0;
             for (u32 k = t; k < nkeys; k += 1024) { const u64 c = cells_of(kcnt[k], span[k], sh0); mc = c > mc ? c : mc; }
