@@ -172,7 +172,8 @@ int build_keys(brh_session *s, const std::vector<std::pair<brh_batch, brh_column
         for (size_t k = 0; k < cols[t].size(); k++) { if (k) scratch.push_back('\x1f'); scratch.append(cols[t][k].at(i)); }
         return scratch;
     };
-    // pass 1: unique keys (composite keys are materialised once per table)
+    // pass 1: unique keys (composite keys are materialised once per table).  Rows of one contig come in runs in
+    // coordinate-sorted tables: a key equal to the previous row's is not looked up again.
     for (size_t t = 0; t < tables.size(); t++) {
         const int64_t n = tables[t].first.array->length;
         if (cols[t].size() > 1) {
@@ -180,8 +181,11 @@ int build_keys(brh_session *s, const std::vector<std::pair<brh_batch, brh_column
             std::string scratch;
             for (int64_t i = 0; i < n; i++) composite[t][i] = std::string(key_of(t, i, scratch));
         }
+        std::string_view last; bool have = false;
         for (int64_t i = 0; i < n; i++) {
             std::string_view k = cols[t].size() > 1 ? std::string_view(composite[t][i]) : cols[t][0].at(i);
+            if (have && k == last) continue;
+            last = k; have = true;
             if (seen.emplace(k, 0).second) uniq.push_back(k);
         }
     }
@@ -189,12 +193,23 @@ int build_keys(brh_session *s, const std::vector<std::pair<brh_batch, brh_column
     for (uint32_t i = 0; i < uniq.size(); i++) seen[uniq[i]] = i;
     kd->names.assign(uniq.begin(), uniq.end());
     kd->ids.resize(tables.size());
+    // pass 2: ids.  Names of up to 7 bytes ("chr1" ... ) are compared and looked up as one packed 64-bit word.
+    auto pack = [](std::string_view k) -> uint64_t { uint64_t w = 0; std::memcpy(&w, k.data(), k.size()); return w | ((uint64_t)(k.size() + 1) << 56); };
+    std::unordered_map<uint64_t, uint32_t> short_ids;
+    for (const auto &kv : seen) if (kv.first.size() <= 7) short_ids.emplace(pack(kv.first), kv.second);
     for (size_t t = 0; t < tables.size(); t++) {
         const int64_t n = tables[t].first.array->length;
         kd->ids[t].resize((size_t)n);
+        std::string_view last; uint64_t last_packed = 0; uint32_t last_id = 0; bool have = false;
         for (int64_t i = 0; i < n; i++) {
             std::string_view k = cols[t].size() > 1 ? std::string_view(composite[t][i]) : cols[t][0].at(i);
-            kd->ids[t][i] = seen[k];
+            if (k.size() <= 7) {
+                const uint64_t w = pack(k);
+                if (w != last_packed) { last_id = short_ids.find(w)->second; last_packed = w; have = false; }
+            } else if (!have || k != last) {
+                last_id = seen[k]; last = k; have = true; last_packed = 0;
+            }
+            kd->ids[t][i] = last_id;
         }
     }
     return 0;
