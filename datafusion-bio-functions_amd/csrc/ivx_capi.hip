@@ -293,6 +293,12 @@ extern "C" uint64_t ivx_index_device_bytes(const ivx_index *ix) { return ix ? ix
 
 // ---------------------------------------------------------------- a3 probes
 
+static bool rowval_routed_ok(u64 n)
+{
+    if (const char *f = getenv("IVX_JOIN_PATH")) return !strcmp(f, "routed");      // tests: "direct" | "regions" | "routed"
+    return n >= (1u << 21);
+}
+
 static ivx_status overlap_common(ivx_ctx *ctx, const ivx_index *ix, int mem, int mode,
                                  const u32 *key, const i32 *start, const i32 *end, u64 n,
                                  u32 *per_row, u8 *exists, u32 *bidx, u32 *pidx, u64 cap, u64 *total)
@@ -337,6 +343,8 @@ static ivx_status overlap_common(ivx_ctx *ctx, const ivx_index *ix, int mem, int
         }
         else if (rowval) IVX_TRY(ivx_rowval_probe_regions(ctx, ix->jv, ix->jv_nreg, mode == JP_PER_ROW ? IVX_RV_PER_ROW : IVX_RV_EXISTS, dk, ds, de, n, 0,
                                                           mode == JP_PER_ROW ? (void *)d_row : (void *)d_ex, ctx->d_scalars));
+        else if (n && (mode == JP_PER_ROW || mode == JP_EXISTS) && ix->nroute_nreg > 0 && rowval_routed_ok(n))
+            IVX_TRY(ivx_join_rowval_routed(ctx, ix, mode, dk, ds, de, n, d_row, d_ex, ctx->d_scalars));   // too many regions for the LDS slices: route, gather, put back
         else IVX_TRY(ivx_join_probe(ctx, ix->jv, mode, dk, ds, de, n, d_row, d_ex, d_b, d_p, cap, ctx->d_scalars));
     }
     u64 tot = 0;

@@ -217,6 +217,11 @@ ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nre
 // per-row-output operators through the same partition (count_overlaps: jv over the build rows, no row with
 // end < start; coverage: jv over the merged nodes)
 enum { IVX_RV_COUNT = 0, IVX_RV_COVERAGE = 1, IVX_RV_PER_ROW = 2, IVX_RV_EXISTS = 3 };
+ivx_status ivx_route_view_build(ivx_ctx *ctx, ivx_index *ix, const i32 *origin, const u32 *span, const u32 *kcnt);
+void ivx_route_view_ready(ivx_ctx *ctx, ivx_index *ix);
+ivx_status ivx_join_rowval_routed(ivx_ctx *ctx, const ivx_index *ix, int mode, const u32 *key, const i32 *s, const i32 *e, u64 n,
+                                  u32 *per_row, u8 *exists, u64 *d_total);
+ivx_status ivx_unroute_u32(ivx_ctx *ctx, const ivx_routed &r, u64 n, const u32 *vb, u32 *out32, u8 *out8);
 ivx_status ivx_route_rows(ivx_ctx *ctx, const JoinIndexView &rv, const u32 *key, const i32 *s, const i32 *e, u64 n, u32 adj, ivx_routed *out);
 ivx_status ivx_unroute_pair(ivx_ctx *ctx, const ivx_routed &r, u64 n, const u32 *vb, const i64 *vd, u32 *ob, u32 *op, i64 *od, i64 dflt);
 ivx_status ivx_rowval_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nreg, int kind,

@@ -284,15 +284,79 @@ constexpr int PT = 256;     // probe workgroup
 constexpr int PI = 4;       // probe rows per thread per tile
 constexpr int PTILE = PT * PI;
 
+// routing regions: 2^sh0-wide cells over every key's span of starts, R (a power of two) cells per
+// region, at most IVX_MAXREG_WIDE regions that never straddle a key; nreg = 0 if more keys than that have rows
+__global__ __launch_bounds__(1024) void k_nroute_layout(const i32 *origin, const u32 *span, const u32 *kcnt, u32 nkeys, u32 *kreg, u32 *rkey, u32 *hdr)
+{
+    __shared__ u64 red[1024 / IVX_WAVE + 1];
+    const u32 t = threadIdx.x;
+    const u32 sh0 = 10;
+    auto regions_for = [&](u32 cs) -> u64 {
+        u64 a = 0;
+        for (u32 k = t; k < nkeys; k += 1024) if (kcnt[k]) a += (((u64)(span[k] >> sh0) + 1) + ((1ull << cs) - 1)) >> cs;
+        return block_sum<u64, 1024>(a, red);
+    };
+    u32 cs = 0;
+    while (cs < 32 && regions_for(cs) > IVX_MAXREG_WIDE) cs++;
+    const bool ok = regions_for(cs) <= IVX_MAXREG_WIDE;
+    u64 rrun = 0;
+    for (u32 k0 = 0; k0 < nkeys; k0 += 1024) {
+        const u32 k = k0 + t;
+        u64 c = (ok && k < nkeys && kcnt[k]) ? ((((u64)(span[k] >> sh0) + 1) + ((1ull << cs) - 1)) >> cs) : 0;
+        u64 tot;
+        const u64 ex = block_excl_scan<u64, 1024>(c, red, &tot);
+        if (k < nkeys) { kreg[k] = (u32)(rrun + ex); for (u64 r = 0; r < c; r++) rkey[rrun + ex + r] = k; }
+        rrun += tot;
+    }
+    if (t == 0) {
+        kreg[nkeys] = (u32)rrun;
+        hdr[HDR_SH0] = sh0; hdr[HDR_CS] = cs < 31 ? cs : 31; hdr[HDR_NREG] = ok ? (u32)rrun : 0u; hdr[HDR_RCELLS] = 1u << (cs < 31 ? cs : 31);
+        hdr[HDR_RMUL_LO] = 0; hdr[HDR_RMUL_HI] = 0;
+    }
+}
+
+// per-row match counts over probe rows ROUTED by coordinate region (ivx_route_rows): build sides with too many regions
+// for the LDS-slice pipeline.  XCD x sweeps the x-th eighth of the routed rows (gridDim.x is a multiple of 8); the key of
+// a row follows from its routing region; counts at the routed positions, their sum onto *total.
+__global__ __launch_bounds__(PT) void k_overlap_rowval_routed(JoinIndexView ix, const u32 *__restrict__ rkey, u32 nreg, const u64 *__restrict__ pse,
+                                                              const u32 *__restrict__ offs, u32 nblk, int exists_only, u32 *__restrict__ vb,
+                                                              unsigned long long *total, const u32 *unsorted)
+{
+    __shared__ u32 s_rfirst[IVX_MAXREG_WIDE + 2];
+    __shared__ u64 lds64[PT / IVX_WAVE];
+    if (*unsorted == 0) return;
+    for (u32 t = threadIdx.x; t <= nreg; t += PT) s_rfirst[t] = offs[(u64)t * nblk];
+    __syncthreads();
+    const u64 nrows = s_rfirst[nreg];
+    const u32 sh0 = ix.hdr[HDR_SH0], nlev = ix.hdr[HDR_NLEV];
+    const u32 xcd = blockIdx.x & 7u, nb = gridDim.x >> 3, bi = blockIdx.x >> 3;
+    const u64 seg_lo = nrows * xcd / 8, seg_hi = nrows * (xcd + 1) / 8;
+    u64 acc = 0;
+    for (u64 i = seg_lo + (u64)bi * PT + threadIdx.x; i < seg_hi; i += (u64)nb * PT) {
+        u32 a = 0, b = nreg;                                            // last region whose first row is <= i
+        while (a < b) { const u32 m = (a + b + 1) >> 1; if (s_rfirst[m] <= i) a = m; else b = m - 1; }
+        const u64 w = pse[i];
+        u32 m = 0;
+        walk(ix, sh0, 0, nlev, rkey[a], (i32)(u32)w, (i32)(u32)(w >> 32), [&](u32) { m++; });
+        vb[i] = m;
+        acc += m;
+    }
+    if (!exists_only && total) {
+        const u64 tot = block_sum<u64, PT>(acc, lds64);
+        if (threadIdx.x == 0 && tot) atomicAdd(total, (unsigned long long)tot);
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(PT) void k_probe_overlap(JoinIndexView ix, const u32 *__restrict__ pkey,
                                                       const i32 *__restrict__ ps, const i32 *__restrict__ pe, u64 n,
                                                       u32 *__restrict__ per_row, u8 *__restrict__ exists,
                                                       u32 *__restrict__ ob, u32 *__restrict__ op, u64 cap,
-                                                      unsigned long long *cursor)
+                                                      unsigned long long *cursor, const u32 *gate)
 {
     __shared__ u32 lds[PT / IVX_WAVE + 1];
     __shared__ unsigned long long s_base;
+    if (gate && *gate != 0) return;                        // (routed callers: only when the probe rows were left in place)
     const u32 sh0 = ix.hdr[HDR_SH0], nlev = ix.hdr[HDR_NLEV];
     const u64 ntiles = (n + PTILE - 1) / PTILE;
     u64 acc = 0;                                           // MODE COUNT / PER_ROW: pairs seen by this thread
@@ -353,6 +417,49 @@ __global__ __launch_bounds__(PT) void k_probe_overlap(JoinIndexView ix, const u3
 
 // ---------------------------------------------------------------------------
 
+// Regions that only ROUTE big unsorted probe batches (no cells of their own) over per-key (origin, span, count)
+// tables that outlive the index.  The region count arrives on the host with the caller's next synchronisation
+// (ivx_route_view_ready).
+ivx_status ivx_route_view_build(ivx_ctx *ctx, ivx_index *ix, const i32 *origin, const u32 *span, const u32 *kcnt)
+{
+    hipStream_t st = ctx->stream;
+    const u32 nkeys = ix->nkeys;
+    u32 *kreg, *rkey, *rhdr;
+    IVX_TRY(ivx_index_alloc(ctx, ix, ((size_t)nkeys + 1) * sizeof(u32), (void **)&kreg));
+    IVX_TRY(ivx_index_alloc(ctx, ix, ((size_t)IVX_MAXREG_WIDE + 1) * sizeof(u32), (void **)&rkey));
+    IVX_TRY(ivx_index_alloc(ctx, ix, HDR_WORDS * sizeof(u32), (void **)&rhdr));
+    IVX_HIP(ctx, hipMemsetAsync(rhdr, 0, HDR_WORDS * sizeof(u32), st));
+    hipLaunchKernelGGL(k_nroute_layout, dim3(1), dim3(1024), 0, st, origin, span, kcnt, nkeys, kreg, rkey, rhdr);
+    IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 48, rhdr, HDR_WORDS * sizeof(u32), hipMemcpyDeviceToHost, st));
+    ix->nroute = JoinIndexView{};
+    ix->nroute.origin = origin; ix->nroute.span = span; ix->nroute.kcnt = kcnt; ix->nroute.kreg = kreg; ix->nroute.rkey = rkey;
+    ix->nroute.hdr = rhdr; ix->nroute.nkeys = nkeys;
+    IVX_HIP(ctx, hipGetLastError());
+    return IVX_OK;
+}
+void ivx_route_view_ready(ivx_ctx *ctx, ivx_index *ix) { ix->nroute_nreg = ((const u32 *)(ctx->h_scalars + 48))[HDR_NREG]; }
+
+// rle_right / exists of a big probe batch on an index with too many regions for the LDS-slice pipeline
+ivx_status ivx_join_rowval_routed(ivx_ctx *ctx, const ivx_index *ix, int mode, const u32 *key, const i32 *s, const i32 *e, u64 n,
+                                  u32 *per_row, u8 *exists, u64 *d_total)
+{
+    hipStream_t st = ctx->stream;
+    ivx_routed R;
+    IVX_TRY(ivx_route_rows(ctx, ix->nroute, key, s, e, n, 0u, &R));
+    u32 *vb;
+    IVX_TRY(ctx->get_scratch(WS_T2, n * sizeof(u32), (void **)&vb));
+    const u32 grid = (ivx_stream_grid(n, PT * 4) + 7u) & ~7u;
+    hipLaunchKernelGGL(k_overlap_rowval_routed, dim3(grid), dim3(PT), 0, st, ix->jv, ix->nroute.rkey, ix->nroute_nreg, R.pse, R.hist, R.nblk,
+                       mode == JP_EXISTS ? 1 : 0, vb, (unsigned long long *)d_total, R.unsorted);
+    IVX_TRY(ivx_unroute_u32(ctx, R, n, vb, per_row, exists));
+    // rows that came in region order were not moved: the plain kernel answers them in place (gated on the flag)
+    const u32 g2 = ivx_stream_grid(n, PTILE, 256 * 8);
+    if (mode == JP_PER_ROW) hipLaunchKernelGGL(k_probe_overlap<JP_PER_ROW>, dim3(g2), dim3(PT), 0, st, ix->jv, key, s, e, n, per_row, exists, (u32 *)nullptr, (u32 *)nullptr, (u64)0, (unsigned long long *)d_total, R.unsorted);
+    else hipLaunchKernelGGL(k_probe_overlap<JP_EXISTS>, dim3(g2), dim3(PT), 0, st, ix->jv, key, s, e, n, per_row, exists, (u32 *)nullptr, (u32 *)nullptr, (u64)0, (unsigned long long *)d_total, R.unsorted);
+    IVX_HIP(ctx, hipGetLastError());
+    return IVX_OK;
+}
+
 ivx_status ivx_join_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32 *s, const i32 *e, u64 n)
 {
     const u32 nkeys = ix->nkeys;
@@ -396,6 +503,7 @@ ivx_status ivx_join_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32
     hipLaunchKernelGGL(k_join_scatter, dim3(grid), dim3(BT), 0, st, s, e, n, (const u32 *)binstart, (const u32 *)cellid, (const u32 *)rank, ent);
     hipLaunchKernelGGL(k_join_regdesc, dim3((u32)((regcap + 255) / 256)), dim3(256), 0, st, origin, span, lbase, hdr, kreg, rkey, binstart, rdesc);
     IVX_HIP(ctx, hipGetLastError());
+    if (ix->kind == IVX_KIND_OVERLAP) IVX_TRY(ivx_route_view_build(ctx, ix, origin, span, kcnt));   // (count / coverage / nearest indexes route on their rank grids)
 
     // key ids are validated on the device; surface the flag (one small D2H)
     IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 8, errflag, sizeof(u32), hipMemcpyDeviceToHost, st));
@@ -403,6 +511,7 @@ ivx_status ivx_join_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32
     IVX_HIP(ctx, hipStreamSynchronize(st));
     if (*(u32 *)(ctx->h_scalars + 8)) return ctx->fail(IVX_ERR_INVALID, "build key id >= n_keys");
     ix->jv_nreg = ((const u32 *)(ctx->h_scalars + 32))[HDR_NREG];
+    if (ix->kind == IVX_KIND_OVERLAP) ivx_route_view_ready(ctx, ix);
 
     ix->jv.origin = origin; ix->jv.span = span; ix->jv.kcnt = kcnt; ix->jv.lbase = lbase;
     ix->jv.binstart = binstart; ix->jv.ent = ent; ix->jv.hdr = hdr; ix->jv.nkeys = nkeys;
@@ -419,16 +528,16 @@ ivx_status ivx_join_probe(ivx_ctx *ctx, const JoinIndexView &jv, int mode,
     unsigned long long *cur = (unsigned long long *)d_cursor;
     switch (mode) {
     case JP_COUNT:
-        hipLaunchKernelGGL(k_probe_overlap<JP_COUNT>, dim3(grid), dim3(PT), 0, ctx->stream, jv, key, s, e, n, per_row, exists, ob, op, cap, cur);
+        hipLaunchKernelGGL(k_probe_overlap<JP_COUNT>, dim3(grid), dim3(PT), 0, ctx->stream, jv, key, s, e, n, per_row, exists, ob, op, cap, cur, (const u32 *)nullptr);
         break;
     case JP_PER_ROW:
-        hipLaunchKernelGGL(k_probe_overlap<JP_PER_ROW>, dim3(grid), dim3(PT), 0, ctx->stream, jv, key, s, e, n, per_row, exists, ob, op, cap, cur);
+        hipLaunchKernelGGL(k_probe_overlap<JP_PER_ROW>, dim3(grid), dim3(PT), 0, ctx->stream, jv, key, s, e, n, per_row, exists, ob, op, cap, cur, (const u32 *)nullptr);
         break;
     case JP_EXISTS:
-        hipLaunchKernelGGL(k_probe_overlap<JP_EXISTS>, dim3(grid), dim3(PT), 0, ctx->stream, jv, key, s, e, n, per_row, exists, ob, op, cap, cur);
+        hipLaunchKernelGGL(k_probe_overlap<JP_EXISTS>, dim3(grid), dim3(PT), 0, ctx->stream, jv, key, s, e, n, per_row, exists, ob, op, cap, cur, (const u32 *)nullptr);
         break;
     default:
-        hipLaunchKernelGGL(k_probe_overlap<JP_FILL>, dim3(grid), dim3(PT), 0, ctx->stream, jv, key, s, e, n, per_row, exists, ob, op, cap, cur);
+        hipLaunchKernelGGL(k_probe_overlap<JP_FILL>, dim3(grid), dim3(PT), 0, ctx->stream, jv, key, s, e, n, per_row, exists, ob, op, cap, cur, (const u32 *)nullptr);
         break;
     }
     IVX_HIP(ctx, hipGetLastError());

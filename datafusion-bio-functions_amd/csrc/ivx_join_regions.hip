@@ -881,10 +881,11 @@ __device__ __forceinline__ void up_store(void *out, u64 i, u32 v)
 template <int OUT, int ND>
 __global__ __launch_bounds__(PA_T) void k_unpermute(const u32 *__restrict__ val, const unsigned short *__restrict__ cidx,
                                                     const u32 *__restrict__ offs, u32 nblk, u32 chunk, u32 nreg, u64 n, void *__restrict__ out,
-                                                    const u32 *unsorted, unsigned long long *total)
+                                                    const u32 *unsorted, unsigned long long *total, int sorted_done = 0)
 {
     __shared__ u64 s_sum[PA_T / IVX_WAVE];
     u64 mysum = 0;
+    if (*unsorted == 0 && sorted_done) return;              // (routed callers: another kernel answered the unmoved rows in place)
     if (*unsorted == 0) {                                   // values already sit in input order
         const u64 lo0 = (u64)blockIdx.x * chunk;
         const u64 hi0 = lo0 + chunk < n ? lo0 + chunk : n;
@@ -1042,6 +1043,17 @@ ivx_status ivx_route_rows(ivx_ctx *ctx, const JoinIndexView &rv, const u32 *key,
     else hipLaunchKernelGGL((k_part_scatter<false, unsigned short, 1024>), dim3(nblk), dim3(PA_T), 0, st, rv, key, s, e, n, nblk, (const u32 *)hist, pse, cidx, chunk, adj, (const u32 *)unsorted, 0);
     IVX_HIP(ctx, hipGetLastError());
     out->hist = hist; out->pse = pse; out->cidx = cidx; out->unsorted = unsorted; out->nblk = nblk; out->chunk = chunk;
+    return IVX_OK;
+}
+
+// one u32 value per routed row back into input order, as u32 (out32) or as "value != 0" bytes (out8); rows that were
+// never routed get 0
+ivx_status ivx_unroute_u32(ivx_ctx *ctx, const ivx_routed &r, u64 n, const u32 *vb, u32 *out32, u8 *out8)
+{
+    hipStream_t st = ctx->stream;
+    if (out32) hipLaunchKernelGGL((k_unpermute<UP_U32, 1024>), dim3(r.nblk), dim3(PA_T), 0, st, vb, r.cidx, r.hist, r.nblk, r.chunk, 1024u, n, (void *)out32, r.unsorted, (unsigned long long *)nullptr, 1);
+    if (out8) hipLaunchKernelGGL((k_unpermute<UP_U8, 1024>), dim3(r.nblk), dim3(PA_T), 0, st, vb, r.cidx, r.hist, r.nblk, r.chunk, 1024u, n, (void *)out8, r.unsorted, (unsigned long long *)nullptr, 1);
+    IVX_HIP(ctx, hipGetLastError());
     return IVX_OK;
 }
 

@@ -361,37 +361,6 @@ __global__ __launch_bounds__(NR_T) void k_nearest_routed(NearestView nv, const u
     }
 }
 
-// routing regions of a nearest index: 2^sh0-wide cells over every key's span of starts, R (a power of two) cells per
-// region, at most IVX_MAXREG_WIDE regions that never straddle a key; nreg = 0 if more keys than that have rows
-__global__ __launch_bounds__(1024) void k_nroute_layout(const i32 *origin, const u32 *span, const u32 *kcnt, u32 nkeys, u32 *kreg, u32 *rkey, u32 *hdr)
-{
-    __shared__ u64 red[1024 / IVX_WAVE + 1];
-    const u32 t = threadIdx.x;
-    const u32 sh0 = 10;
-    auto regions_for = [&](u32 cs) -> u64 {
-        u64 a = 0;
-        for (u32 k = t; k < nkeys; k += 1024) if (kcnt[k]) a += (((u64)(span[k] >> sh0) + 1) + ((1ull << cs) - 1)) >> cs;
-        return block_sum<u64, 1024>(a, red);
-    };
-    u32 cs = 0;
-    while (cs < 32 && regions_for(cs) > IVX_MAXREG_WIDE) cs++;
-    const bool ok = regions_for(cs) <= IVX_MAXREG_WIDE;
-    u64 rrun = 0;
-    for (u32 k0 = 0; k0 < nkeys; k0 += 1024) {
-        const u32 k = k0 + t;
-        u64 c = (ok && k < nkeys && kcnt[k]) ? ((((u64)(span[k] >> sh0) + 1) + ((1ull << cs) - 1)) >> cs) : 0;
-        u64 tot;
-        const u64 ex = block_excl_scan<u64, 1024>(c, red, &tot);
-        if (k < nkeys) { kreg[k] = (u32)(rrun + ex); for (u64 r = 0; r < c; r++) rkey[rrun + ex + r] = k; }
-        rrun += tot;
-    }
-    if (t == 0) {
-        kreg[nkeys] = (u32)rrun;
-        hdr[HDR_SH0] = sh0; hdr[HDR_CS] = cs < 31 ? cs : 31; hdr[HDR_NREG] = ok ? (u32)rrun : 0u; hdr[HDR_RCELLS] = 1u << (cs < 31 ? cs : 31);
-        hdr[HDR_RMUL_LO] = 0; hdr[HDR_RMUL_HI] = 0;
-    }
-}
-
 // k > 1: up to k candidates per probe row into tmp[i*k ..], rows-per-probe into cnt[i]
 __global__ __launch_bounds__(OT) void k_probe_nearestk(NearestView nv, const u32 *__restrict__ pkey, const i32 *__restrict__ ps,
                                                        const i32 *__restrict__ pe, u64 n, int strict, int include_overlaps, u32 kk,
@@ -546,26 +515,9 @@ ivx_status nearest_sorted_records(ivx_ctx *ctx, const u32 *key, const i32 *s, co
     return IVX_OK;
 }
 
-// regions that only ROUTE big unsorted probe batches (no cells of their own): per-key spans of rank grid g.  The
-// region count arrives on the host with the caller's next synchronisation (route_view_ready).
-ivx_status build_route_view(ivx_ctx *ctx, ivx_index *ix, const RankGridView &g)
-{
-    hipStream_t st = ctx->stream;
-    const u32 nkeys = ix->nkeys;
-    u32 *kreg, *rkey, *rhdr;
-    IVX_TRY(ivx_index_alloc(ctx, ix, ((size_t)nkeys + 1) * sizeof(u32), (void **)&kreg));
-    IVX_TRY(ivx_index_alloc(ctx, ix, ((size_t)IVX_MAXREG_WIDE + 1) * sizeof(u32), (void **)&rkey));
-    IVX_TRY(ivx_index_alloc(ctx, ix, HDR_WORDS * sizeof(u32), (void **)&rhdr));
-    IVX_HIP(ctx, hipMemsetAsync(rhdr, 0, HDR_WORDS * sizeof(u32), st));
-    hipLaunchKernelGGL(k_nroute_layout, dim3(1), dim3(1024), 0, st, g.origin, g.span, g.kcnt, nkeys, kreg, rkey, rhdr);
-    IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 48, rhdr, HDR_WORDS * sizeof(u32), hipMemcpyDeviceToHost, st));
-    ix->nroute = JoinIndexView{};
-    ix->nroute.origin = g.origin; ix->nroute.span = g.span; ix->nroute.kcnt = g.kcnt; ix->nroute.kreg = kreg; ix->nroute.rkey = rkey;
-    ix->nroute.hdr = rhdr; ix->nroute.nkeys = nkeys;
-    IVX_HIP(ctx, hipGetLastError());
-    return IVX_OK;
-}
-void route_view_ready(ivx_ctx *ctx, ivx_index *ix) { ix->nroute_nreg = ((const u32 *)(ctx->h_scalars + 48))[HDR_NREG]; }
+// routing regions over rank grid g's per-key spans (ivx_route_view_build, ivx_join.hip)
+ivx_status build_route_view(ivx_ctx *ctx, ivx_index *ix, const RankGridView &g) { return ivx_route_view_build(ctx, ix, g.origin, g.span, g.kcnt); }
+void route_view_ready(ivx_ctx *ctx, ivx_index *ix) { ivx_route_view_ready(ctx, ix); }
 
 }  // namespace
 

@@ -29,9 +29,10 @@ def _check_join(ctx, bk, bs, be, pk, ps, pe, nkeys):
     assert (per_row.astype(np.uint64) == want_cnt).all()
     # both probe paths: gathers straight from the index, and region-partitioned through LDS
     # ... and for the latter both ways of writing the pairs: staging ring (IVX_DENSE=0) and count-scan-write (1)
-    for path in ("direct", "regions", "regions-dense"):
+    # "routed": rle_right / exists over probe rows routed by coordinate region, gathers from the index (big build sides)
+    for path in ("direct", "regions", "regions-dense", "routed"):
         os.environ["IVX_JOIN_PATH"] = path.split("-")[0]
-        if path != "direct":
+        if path.startswith("regions"):
             os.environ["IVX_DENSE"] = "1" if path.endswith("dense") else "0"
         try:
             assert ctx.overlap_count(ix, pk, ps, pe) == total, path

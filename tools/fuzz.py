@@ -41,9 +41,9 @@ for it in range(iters):
     bk, bs, be = rows(rng, nb, nk, span, bmean, inverted=float(rng.choice([0, 0, 0.02])))
     pk, ps, pe = rows(rng, npr, nk, span, int(rng.choice([1, 150, 5000])), inverted=float(rng.choice([0, 0.01])), sort=srt, unknown=int(rng.choice([0, 2])))
     strict = bool(rng.integers(0, 2))
-    path = str(rng.choice(["direct", "regions"]))
-    os.environ["IVX_JOIN_PATH"] = path; os.environ["IVX_ROWVAL_PATH"] = path if rng.random() < 0.7 else "routed"
-    os.environ["IVX_NEAREST_PATH"] = "routed" if path == "regions" else "direct"
+    path = str(rng.choice(["direct", "regions", "regions", "routed"]))
+    os.environ["IVX_JOIN_PATH"] = path; os.environ["IVX_ROWVAL_PATH"] = path if (path != "routed" and rng.random() < 0.7) else "routed"
+    os.environ["IVX_NEAREST_PATH"] = "routed" if path != "direct" else "direct"
     dense = str(rng.choice(["0", "1", ""]))                       # pair writer of the region path: ring, count-scan-write, by density
     if dense: os.environ["IVX_DENSE"] = dense
     else: os.environ.pop("IVX_DENSE", None)
