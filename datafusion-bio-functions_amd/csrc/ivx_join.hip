@@ -503,7 +503,10 @@ ivx_status ivx_join_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32
     hipLaunchKernelGGL(k_join_scatter, dim3(grid), dim3(BT), 0, st, s, e, n, (const u32 *)binstart, (const u32 *)cellid, (const u32 *)rank, ent);
     hipLaunchKernelGGL(k_join_regdesc, dim3((u32)((regcap + 255) / 256)), dim3(256), 0, st, origin, span, lbase, hdr, kreg, rkey, binstart, rdesc);
     IVX_HIP(ctx, hipGetLastError());
-    if (ix->kind == IVX_KIND_OVERLAP) IVX_TRY(ivx_route_view_build(ctx, ix, origin, span, kcnt));   // (count / coverage / nearest indexes route on their rank grids)
+    // routing regions for the per-row modes of build sides that outgrow the LDS-slice pipeline (more than 1023 regions
+    // takes > 5 M rows); count / coverage / nearest indexes route on their rank grids
+    const bool want_route = ix->kind == IVX_KIND_OVERLAP && n >= (4u << 20);
+    if (want_route) IVX_TRY(ivx_route_view_build(ctx, ix, origin, span, kcnt));
 
     // key ids are validated on the device; surface the flag (one small D2H)
     IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 8, errflag, sizeof(u32), hipMemcpyDeviceToHost, st));
@@ -511,7 +514,7 @@ ivx_status ivx_join_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32
     IVX_HIP(ctx, hipStreamSynchronize(st));
     if (*(u32 *)(ctx->h_scalars + 8)) return ctx->fail(IVX_ERR_INVALID, "build key id >= n_keys");
     ix->jv_nreg = ((const u32 *)(ctx->h_scalars + 32))[HDR_NREG];
-    if (ix->kind == IVX_KIND_OVERLAP) ivx_route_view_ready(ctx, ix);
+    if (want_route) ivx_route_view_ready(ctx, ix);
 
     ix->jv.origin = origin; ix->jv.span = span; ix->jv.kcnt = kcnt; ix->jv.lbase = lbase;
     ix->jv.binstart = binstart; ix->jv.ent = ent; ix->jv.hdr = hdr; ix->jv.nkeys = nkeys;
