@@ -58,14 +58,14 @@ if "merge" in which or "subtract" in which or "cluster" in which or "complement"
         k, s64, e64 = k[o].contiguous(), s64[o].contiguous(), e64[o].contiguous()
         del o
     if "merge" in which:
-        tm, out = timed(lambda: ctx.merge(k, s64, e64, n_keys=24), reps=2)
+        tm, out = timed(lambda: ctx.merge(k, s64, e64, n_keys=24), reps=4)
         m = out[0].numel()
         report(f"merge {n}", tm, 20 * n + 28 * m, f"kernel {ctx.last_kernel_ms():.3f} ms out rows {m}")
     if "subtract" in which:
         nr = n // 10
         rk, rs, re = synth.gen_torch(nr, 150, 24, 0x5EED0009, dev)
         rs64, re64 = rs.to(torch.int64), re.to(torch.int64) + 1
-        ts, out = timed(lambda: ctx.subtract(k, s64, e64, rk, rs64, re64, n_keys=24), reps=2)
+        ts, out = timed(lambda: ctx.subtract(k, s64, e64, rk, rs64, re64, n_keys=24), reps=4)
         m = out[0].numel()
         report(f"subtract {n}-{nr} (count+fill)", ts, 20 * (n + nr) + 20 * m, f"out rows {m}")
     if "subtract" in which:
