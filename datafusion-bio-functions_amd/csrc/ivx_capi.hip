@@ -351,7 +351,8 @@ static ivx_status overlap_common(ivx_ctx *ctx, const ivx_index *ix, int mem, int
     if (mode != JP_EXISTS) IVX_TRY(read_scalar(ctx, 0, &tot));
     if (mode == JP_COUNT && regions && pl.valid) pl.total = tot;
     if (total) *total = tot;
-    if (mode == JP_FILL && tot > cap) return ctx->fail(IVX_ERR_CAPACITY, "pair buffers too small");
+    if (mode == JP_FILL && tot > cap) return ctx->fail(IVX_ERR_CAPACITY, "pair buffers too small");   // (a plan survives this: the retry with bigger buffers reuses it)
+    if (planned) pl.valid = false;                          // a plan serves ONE successful fill: a caller that refills the same buffers with its next batch must not get this batch's rows
     IVX_TRY(copy_out(ctx, mem, per_row, d_row, n));
     IVX_TRY(copy_out(ctx, mem, exists, d_ex, n));
     if (mode == JP_FILL) { IVX_TRY(copy_out(ctx, mem, bidx, d_b, tot)); IVX_TRY(copy_out(ctx, mem, pidx, d_p, tot)); }
@@ -551,6 +552,7 @@ extern "C" ivx_status ivx_subtract(ivx_ctx *ctx, int mem,
                                 : ivx_subtract_device(ctx, dlk, dls, dle, nl, drk, drs, dre, nr, n_keys, strict, ok, os, oe, orow, cap, &m);
         *n_out = m;
         if (st != IVX_OK) { if (st != IVX_ERR_CAPACITY) pl.valid = false; return st; }
+        if (planned) pl.valid = false;                      // consumed: the next fill call sorts and counts again (its input columns may have been refilled in place)
         if (sizing && pl.valid) { memcpy(pl.in, in, sizeof(in)); pl.mem = mem; }
     }
     if (cap) {

@@ -104,6 +104,9 @@ const char *ivx_version(void);
 ivx_status ivx_index_build(ivx_ctx *ctx, int kind, int mem,
                            const uint32_t *key /* nullable */, const int32_t *start, const int32_t *end,
                            uint64_t n, uint32_t n_keys, ivx_index **out);
+/* The caller must have synchronised (ivx_ctx_synchronize) every ctx that probed the index with
+ * IVX_MEM_DEVICE buffers: those calls may return with kernels still in flight, and the index's
+ * device buffers go back to a pool that later builds draw from. */
 void       ivx_index_free(ivx_index *ix);
 uint64_t   ivx_index_rows(const ivx_index *ix);
 uint64_t   ivx_index_device_bytes(const ivx_index *ix);
@@ -127,8 +130,9 @@ ivx_status ivx_probe_overlap_count(ivx_ctx *ctx, const ivx_index *ix, int mem,
  *       the device) in the context: the fill call for the same index, column
  *       pointers, n and stream that is the next call on that context skips that
  *       work (and takes the counted total, not cap, as the density hint) --
- *       the three columns must not change between the two calls.  Any
- *       other call drops that state and the fill call does everything itself. */
+ *       the three columns must not change between the two calls.  The state
+ *       serves ONE successful fill call (it survives an IVX_ERR_CAPACITY
+ *       retry); any other call drops it and a fill call does everything itself. */
 ivx_status ivx_probe_overlap_fill(ivx_ctx *ctx, const ivx_index *ix, int mem,
                                   const uint32_t *key, const int32_t *start, const int32_t *end, uint64_t n,
                                   uint32_t *build_idx, uint32_t *probe_idx, uint64_t cap, uint64_t *written);
@@ -181,8 +185,9 @@ ivx_status ivx_merge(ivx_ctx *ctx, int mem,
  *      the same input pointers, sizes, n_keys, strict and stream that is the next
  *      sort/sweep call on that context runs the output pass only -- the six input
  *      columns must not change between the two calls (the size would be stale
- *      anyway).  Any other call on the context drops that state; a fill call then
- *      (or one made without a sizing call) does all the work itself. */
+ *      anyway).  The state serves ONE successful fill call (it survives an
+ *      IVX_ERR_CAPACITY retry); any other call on the context drops it; a fill call
+ *      then (or one made without a sizing call) does all the work itself. */
 ivx_status ivx_subtract(ivx_ctx *ctx, int mem,
                         const uint32_t *lkey, const int64_t *lstart, const int64_t *lend, uint64_t nl,
                         const uint32_t *rkey, const int64_t *rstart, const int64_t *rend, uint64_t nr,

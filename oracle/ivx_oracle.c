@@ -199,6 +199,68 @@ uint64_t orc_join_tree(const uint32_t *bkey, const int32_t *bs, const int32_t *b
     return total;
 }
 
+/* The same join in ONE walk per probe row, as the reference's probe loop does it
+ * (interval_join.rs:1614-1653: every partition appends its matches to growable index builders and
+ * emits them batch by batch): thread t walks the t-th contiguous share of the probe rows and appends
+ * to its own buffers; the shares are concatenated in probe order afterwards.  This is the form timed as
+ * bench.py's cpu_baseline (orc_join_tree above walks the tree twice: count, then emit). */
+typedef struct { uint32_t *b, *p; uint64_t n, cap; uint32_t probe; } grow_t;
+typedef struct { int threads; grow_t *part; uint64_t total; } join1_t;
+
+static void emit_grow(const iv32_t *iv, void *c)
+{
+    grow_t *g = (grow_t *)c;
+    if (g->n == g->cap) {
+        g->cap = g->cap ? g->cap * 2 : 4096;
+        g->b = (uint32_t *)realloc(g->b, g->cap * sizeof(uint32_t));
+        g->p = (uint32_t *)realloc(g->p, g->cap * sizeof(uint32_t));
+    }
+    g->b[g->n] = iv->row; g->p[g->n] = g->probe; g->n++;
+}
+
+void *orc_join_single_run(const uint32_t *bkey, const int32_t *bs, const int32_t *be, uint64_t nb,
+                          const uint32_t *pkey, const int32_t *ps, const int32_t *pe, uint64_t np, int threads)
+{
+    tree_index_t t = tree_index_build(bkey, bs, be, nb);
+    if (threads < 1) threads = 1;
+    join1_t *j = (join1_t *)calloc(1, sizeof(join1_t));
+    j->threads = threads;
+    j->part = (grow_t *)calloc((size_t)threads, sizeof(grow_t));
+#pragma omp parallel for num_threads(threads) schedule(static, 1)
+    for (int w = 0; w < threads; w++) {
+        grow_t *g = &j->part[w];
+        const uint64_t lo = np * (uint64_t)w / (uint64_t)threads, hi = np * (uint64_t)(w + 1) / (uint64_t)threads;
+        for (uint64_t i = lo; i < hi; i++) {
+            uint32_t k = pkey[i];
+            if (k >= t.g.nkeys) continue;
+            g->probe = (uint32_t)i;
+            tree_query(t.iv, t.maxe, (int64_t)t.g.off[k], (int64_t)t.g.off[k + 1], ps[i], pe[i], emit_grow, g);
+        }
+    }
+    for (int w = 0; w < threads; w++) j->total += j->part[w].n;
+    tree_index_free(&t);
+    return j;
+}
+uint64_t orc_join_single_total(const void *h) { return ((const join1_t *)h)->total; }
+void orc_join_single_copy(const void *h, uint32_t *out_build, uint32_t *out_probe)
+{
+    const join1_t *j = (const join1_t *)h;
+    uint64_t at = 0;
+    for (int w = 0; w < j->threads; w++) {
+        if (j->part[w].n) {
+            memcpy(out_build + at, j->part[w].b, j->part[w].n * sizeof(uint32_t));
+            memcpy(out_probe + at, j->part[w].p, j->part[w].n * sizeof(uint32_t));
+        }
+        at += j->part[w].n;
+    }
+}
+void orc_join_single_free(void *h)
+{
+    join1_t *j = (join1_t *)h;
+    for (int w = 0; w < j->threads; w++) { free(j->part[w].b); free(j->part[w].p); }
+    free(j->part); free(j);
+}
+
 void orc_join_exists(const uint32_t *bkey, const int32_t *bs, const int32_t *be, uint64_t nb,
                      const uint32_t *pkey, const int32_t *ps, const int32_t *pe, uint64_t np,
                      uint8_t *exists)
@@ -236,10 +298,11 @@ static uint64_t pp_lt(const int32_t *a, uint64_t n, int32_t x)
     return lo;
 }
 
-void orc_count_overlaps(const uint32_t *bkey, const int32_t *bs, const int32_t *be, uint64_t nb,
-                        const uint32_t *pkey, const int32_t *ps, const int32_t *pe, uint64_t np,
-                        int strict, int64_t *out)
+void orc_count_overlaps_mt(const uint32_t *bkey, const int32_t *bs, const int32_t *be, uint64_t nb,
+                           const uint32_t *pkey, const int32_t *ps, const int32_t *pe, uint64_t np,
+                           int strict, int64_t *out, int threads)
 {
+    if (threads < 1) threads = 1;
     groups_t g = group_by_key(bkey, nb);
     int32_t *S = (int32_t *)malloc((nb ? nb : 1) * sizeof(int32_t));
     int32_t *E = (int32_t *)malloc((nb ? nb : 1) * sizeof(int32_t));
@@ -248,7 +311,9 @@ void orc_count_overlaps(const uint32_t *bkey, const int32_t *bs, const int32_t *
         qsort(S + g.off[k], g.off[k + 1] - g.off[k], sizeof(int32_t), cmp_i32);
         qsort(E + g.off[k], g.off[k + 1] - g.off[k], sizeof(int32_t), cmp_i32);
     }
-    for (uint64_t i = 0; i < np; i++) {
+    /* probe rows are independent (one DataFusion partition per thread over a shared index) */
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (int64_t i = 0; i < (int64_t)np; i++) {
         int32_t qs = ps[i], qe = pe[i];
         if (strict) { qs = wrap_add32(qs, 1); qe = wrap_sub32(qe, 1); }   /* :253-256 */
         uint32_t k = pkey[i];
@@ -259,6 +324,13 @@ void orc_count_overlaps(const uint32_t *bkey, const int32_t *bs, const int32_t *
         out[i] = (int64_t)(started - ended_before);                       /* :48 */
     }
     free(S); free(E); groups_free(&g);
+}
+
+void orc_count_overlaps(const uint32_t *bkey, const int32_t *bs, const int32_t *be, uint64_t nb,
+                        const uint32_t *pkey, const int32_t *ps, const int32_t *pe, uint64_t np,
+                        int strict, int64_t *out)
+{
+    orc_count_overlaps_mt(bkey, bs, be, nb, pkey, ps, pe, np, strict, out, 1);
 }
 
 /* ------------------------------------------------------ a5: coverage */
@@ -299,10 +371,11 @@ static void cov_visit(const iv32_t *iv, void *c)
     q->cov = wrap_add32(q->cov, ov);
 }
 
-void orc_coverage(const uint32_t *bkey, const int32_t *bs, const int32_t *be, uint64_t nb,
-                  const uint32_t *pkey, const int32_t *ps, const int32_t *pe, uint64_t np,
-                  int strict, int64_t *out)
+void orc_coverage_mt(const uint32_t *bkey, const int32_t *bs, const int32_t *be, uint64_t nb,
+                     const uint32_t *pkey, const int32_t *ps, const int32_t *pe, uint64_t np,
+                     int strict, int64_t *out, int threads)
 {
+    if (threads < 1) threads = 1;
     groups_t g = group_by_key(bkey, nb);
     /* merged nodes per key, then the same augmented tree over them */
     iv32_t *iv = (iv32_t *)malloc((nb ? nb : 1) * sizeof(iv32_t));
@@ -323,7 +396,8 @@ void orc_coverage(const uint32_t *bkey, const int32_t *bs, const int32_t *be, ui
         free(s); free(e);
     }
     moff[g.nkeys] = w;
-    for (uint64_t i = 0; i < np; i++) {
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (int64_t i = 0; i < (int64_t)np; i++) {
         int32_t qs = ps[i], qe = pe[i];
         if (strict) { qs = wrap_add32(qs, 1); qe = wrap_sub32(qe, 1); }   /* :185-188 */
         uint32_t k = pkey[i];
@@ -333,6 +407,13 @@ void orc_coverage(const uint32_t *bkey, const int32_t *bs, const int32_t *be, ui
         out[i] = (int64_t)c.cov;                                          /* :207 */
     }
     free(iv); free(maxe); free(moff); groups_free(&g);
+}
+
+void orc_coverage(const uint32_t *bkey, const int32_t *bs, const int32_t *be, uint64_t nb,
+                  const uint32_t *pkey, const int32_t *ps, const int32_t *pe, uint64_t np,
+                  int strict, int64_t *out)
+{
+    orc_coverage_mt(bkey, bs, be, nb, pkey, ps, pe, np, strict, out, 1);
 }
 
 /* ------------------------------------------------------- a6: nearest */

@@ -53,6 +53,14 @@ uint64_t orc_join_tree(const uint32_t *bkey, const int32_t *bs, const int32_t *b
                        uint32_t *out_build, uint32_t *out_probe, uint64_t cap,
                        uint64_t *per_row, int threads);
 
+/* The same pair set in a single walk per probe row with per-thread growable buffers (the shape of the
+ * reference's probe loop, interval_join.rs:1614-1653).  run -> total -> copy -> free. */
+void *orc_join_single_run(const uint32_t *bkey, const int32_t *bs, const int32_t *be, uint64_t nb,
+                          const uint32_t *pkey, const int32_t *ps, const int32_t *pe, uint64_t np, int threads);
+uint64_t orc_join_single_total(const void *h);
+void orc_join_single_copy(const void *h, uint32_t *out_build, uint32_t *out_probe);
+void orc_join_single_free(void *h);
+
 /* a3': RightSemi / RightAnti existence (interval_join.rs:1014-1024, :1433-1447)
  * exists[i] = 1 iff probe row i has at least one match. */
 void orc_join_exists(const uint32_t *bkey, const int32_t *bs, const int32_t *be, uint64_t nb,
@@ -67,11 +75,19 @@ void orc_count_overlaps(const uint32_t *bkey, const int32_t *bs, const int32_t *
                         const uint32_t *pkey, const int32_t *ps, const int32_t *pe, uint64_t np,
                         int strict, int64_t *out);
 
+void orc_count_overlaps_mt(const uint32_t *bkey, const int32_t *bs, const int32_t *be, uint64_t nb,
+                           const uint32_t *pkey, const int32_t *ps, const int32_t *pe, uint64_t np,
+                           int strict, int64_t *out, int threads);
+
 /* ---- a5: coverage (interval_tree.rs:52-73 merge_intervals, :145-152
  * get_coverage, :181-208 stream loop) ------------------------------------ */
 void orc_coverage(const uint32_t *bkey, const int32_t *bs, const int32_t *be, uint64_t nb,
                   const uint32_t *pkey, const int32_t *ps, const int32_t *pe, uint64_t np,
                   int strict, int64_t *out);
+
+void orc_coverage_mt(const uint32_t *bkey, const int32_t *bs, const int32_t *be, uint64_t nb,
+                     const uint32_t *pkey, const int32_t *ps, const int32_t *pe, uint64_t np,
+                     int strict, int64_t *out, int threads);
 
 /* merge_intervals alone (interval_tree.rs:52-73) on one key, in place on
  * (s,e) of length n; returns the merged length. */

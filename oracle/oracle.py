@@ -89,6 +89,32 @@ def join(bkey, bs, be, pkey, ps, pe, brute=False, threads=1, per_row=False):
     return (ob, op, cnt) if per_row else (ob, op)
 
 
+def join_single(bkey, bs, be, pkey, ps, pe, threads=1):
+    """The join in one walk per probe row with per-thread buffers (the reference's probe-loop shape);
+    -> (build_rows u32[], probe_rows u32[]) grouped by probe row in probe order."""
+    L = lib()
+    L.orc_join_single_run.restype = C.c_void_p
+    L.orc_join_single_total.restype = C.c_uint64
+    bk, bs_, be_, nb = _side32(bkey, bs, be)
+    pk, ps_, pe_, npr = _side32(pkey, ps, pe)
+    h = C.c_void_p(L.orc_join_single_run(_p(bk), _p(bs_), _p(be_), nb, _p(pk), _p(ps_), _p(pe_), npr, C.c_int(threads)))
+    try:
+        n = L.orc_join_single_total(h)
+        ob = np.empty(n, np.uint32); op = np.empty(n, np.uint32)
+        L.orc_join_single_copy(h, _p(ob), _p(op))
+    finally:
+        L.orc_join_single_free(h)
+    return ob, op
+
+
+def pair_keys(b, p):
+    """(build_row, probe_row) pairs as sorted uint64 keys build<<32|probe: the order-free form two pair
+    multisets are compared in (the reference pins only the row multiset, never the match order)."""
+    k = (np.asarray(b).astype(np.uint64) << np.uint64(32)) | np.asarray(p).astype(np.uint64)
+    k.sort()
+    return k
+
+
 def join_count(bkey, bs, be, pkey, ps, pe, threads=1):
     """Total pairs + per-row counts, nothing materialised."""
     L = lib()
@@ -109,21 +135,21 @@ def join_exists(bkey, bs, be, pkey, ps, pe):
     return out
 
 
-def count_overlaps(bkey, bs, be, pkey, ps, pe, strict=False):
+def count_overlaps(bkey, bs, be, pkey, ps, pe, strict=False, threads=1):
     L = lib()
     bk, bs_, be_, nb = _side32(bkey, bs, be)
     pk, ps_, pe_, npr = _side32(pkey, ps, pe)
     out = np.zeros(len(pk), np.int64)
-    L.orc_count_overlaps(_p(bk), _p(bs_), _p(be_), nb, _p(pk), _p(ps_), _p(pe_), npr, C.c_int(int(strict)), _p(out))
+    L.orc_count_overlaps_mt(_p(bk), _p(bs_), _p(be_), nb, _p(pk), _p(ps_), _p(pe_), npr, C.c_int(int(strict)), _p(out), C.c_int(threads))
     return out
 
 
-def coverage(bkey, bs, be, pkey, ps, pe, strict=False):
+def coverage(bkey, bs, be, pkey, ps, pe, strict=False, threads=1):
     L = lib()
     bk, bs_, be_, nb = _side32(bkey, bs, be)
     pk, ps_, pe_, npr = _side32(pkey, ps, pe)
     out = np.zeros(len(pk), np.int64)
-    L.orc_coverage(_p(bk), _p(bs_), _p(be_), nb, _p(pk), _p(ps_), _p(pe_), npr, C.c_int(int(strict)), _p(out))
+    L.orc_coverage_mt(_p(bk), _p(bs_), _p(be_), nb, _p(pk), _p(ps_), _p(pe_), npr, C.c_int(int(strict)), _p(out), C.c_int(threads))
     return out
 
 

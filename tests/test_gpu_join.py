@@ -324,6 +324,50 @@ def test_join_count_then_fill_reuses_the_routed_rows(ctx, device):
         del os.environ["IVX_JOIN_PATH"]
 
 
+@pytest.mark.parametrize("device", [False, True])
+def test_join_plan_is_consumed_by_its_fill(ctx, device):
+    """count(A), fill(A), then the caller refills the SAME buffers with its next batch and calls fill again with a
+    blanket capacity (a streaming caller with a fixed staging buffer): the second fill must see the new rows, not the
+    rows the count call routed (the plan serves one successful fill; it survives an IVX_ERR_CAPACITY retry)."""
+    bk, bs, be = synth(60_000, 311, nkeys=4, mean_len=800, span=8_000_000)
+    A = synth(300_000, 312, nkeys=4, mean_len=150, span=8_000_000)
+    B = synth(300_000, 313, nkeys=4, mean_len=200, span=8_000_000)
+    want_a = pair_set(*orc.join(bk, bs, be, *A, threads=4)); want_b = pair_set(*orc.join(bk, bs, be, *B, threads=4))
+    assert len(want_a) != len(want_b)
+    if device:
+        import torch
+        buf = [torch.from_numpy(x.view(np.int32) if x.dtype == np.uint32 else x).cuda() for x in A]
+        def refill(cols):
+            for t, x in zip(buf, cols):
+                t.copy_(torch.from_numpy(x.view(np.int32) if x.dtype == np.uint32 else x))
+            torch.cuda.synchronize()
+    else:
+        buf = [x.copy() for x in A]
+        def refill(cols):
+            for t, x in zip(buf, cols):
+                t[:] = x
+
+    def pairs(ob, op):
+        if device:
+            ctx.synchronize()
+            ob, op = ob.cpu().numpy().view(np.uint32), op.cpu().numpy().view(np.uint32)
+        return pair_set(ob, op)
+
+    os.environ["IVX_JOIN_PATH"] = "regions"
+    try:
+        ix = ctx.build(pyivx.KIND_OVERLAP, bk, bs, be, n_keys=4)
+        assert ctx.overlap_count(ix, *buf) == len(want_a)
+        with pytest.raises(pyivx.IvxError):                      # too small: the needed size comes back, the plan stays
+            ctx.overlap_fill(ix, *buf, cap=len(want_a) - 1)
+        assert (pairs(*ctx.overlap_fill(ix, *buf, cap=len(want_a))) == want_a).all()
+        refill(B)                                                # same addresses, same n, new rows
+        cap = 2 * max(len(want_a), len(want_b))
+        assert (pairs(*ctx.overlap_fill(ix, *buf, cap=cap)) == want_b).all()
+        ix.free()
+    finally:
+        del os.environ["IVX_JOIN_PATH"]
+
+
 def test_two_contexts_in_two_threads():
     """One ivx_ctx per DataFusion partition: two host threads, each with its own context (own stream and scratch),
     join different data at the same time on one GPU (ctypes drops the GIL inside the calls)."""

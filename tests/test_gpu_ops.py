@@ -435,6 +435,39 @@ def test_subtract_sizing_then_fill_plan(ctx, device):
         assert len(g) == len(w) and (g.view(w.dtype) == w).all()
 
 
+@pytest.mark.parametrize("device", [False, True])
+def test_subtract_plan_is_consumed_by_its_fill(ctx, device):
+    """sizing(A), fill(A), the caller refills the same buffers with other rows, fill again with a blanket capacity:
+    the second fill must subtract the NEW rows (the plan serves one successful fill)."""
+    rk, rs, re = synth(70_000, 192, nkeys=6, mean_len=300, span=1_000_000, dtype=np.int64)
+    re += 1
+    A = list(synth(50_000, 182, nkeys=5, mean_len=1500, span=1_000_000, dtype=np.int64)); A[2] = A[2] + 1
+    B = list(synth(50_000, 183, nkeys=5, mean_len=900, span=1_000_000, dtype=np.int64)); B[2] = B[2] + 1
+    want_a = orc.subtract(*A, rk, rs, re); want_b = orc.subtract(*B, rk, rs, re)
+    assert len(want_a[0]) != len(want_b[0])
+    if device:
+        import torch
+        t = lambda a: torch.from_numpy(a.view(np.int32) if a.dtype == np.uint32 else a).cuda()
+        buf = [t(a) for a in A]; right = [t(a) for a in (rk, rs, re)]
+        def refill(cols):
+            for d, x in zip(buf, cols):
+                d.copy_(t(x))
+            torch.cuda.synchronize()
+    else:
+        buf = [a.copy() for a in A]; right = [rk, rs, re]
+        def refill(cols):
+            for d, x in zip(buf, cols):
+                d[:] = x
+    def check(got, want):
+        for g, w in zip(got, want):
+            if device:
+                ctx.synchronize(); g = g.cpu().numpy()
+            assert len(g) == len(w) and (g.view(w.dtype) == w).all()
+    check(ctx.subtract(*buf, *right, n_keys=6), want_a)        # sizing + planned fill
+    refill(B)
+    check(ctx.subtract(*buf, *right, n_keys=6, cap=len(want_a[0]) + len(want_b[0])), want_b)
+
+
 def test_subtract_empty_sides(ctx):
     e64 = np.empty(0, np.int64); ek = np.empty(0, np.uint32)
     lk = np.zeros(3, np.uint32); ls = np.array([1, 5, 9], np.int64); le = np.array([3, 8, 20], np.int64)
