@@ -52,6 +52,10 @@ struct ivx_join_plan {
     const u32 *hist = nullptr; const u64 *pse = nullptr; const u32 *prow = nullptr;
     const i32 *ds = nullptr, *de = nullptr;     // device copies of the start / end columns (read in place when the rows were in region order)
     u32 chunk = 0, nblk = 0;
+    // one-pass routing (ivx_join_regions.hip): the rows sit in pages; hist = first routed row of every region,
+    // ptab = [region][page slot] -> page + 1
+    bool paged = false;
+    const u32 *ptab = nullptr; u32 pstride = 0, lgpg = 0;
 };
 
 struct ivx_ctx {
@@ -114,7 +118,12 @@ struct ivx_ent { i32 s, e; u32 row; };          // 12-byte AoS entry of the over
 
 // header words written by the layout kernel (device resident, read by probes)
 enum { HDR_SH0 = 0, HDR_NLEV = 1, HDR_NBINS = 2, HDR_CS = 3 /* log2(cells per region) or ~0u */, HDR_NREG = 4,
-       HDR_RCELLS = 5 /* cells per region */, HDR_RMUL_LO = 6, HDR_RMUL_HI = 7 /* ceil(2^40 / cells per region) */, HDR_LEVCNT = 8 /* .. +IVX_MAXL */, HDR_WORDS = 8 + IVX_MAXL };
+       HDR_RCELLS = 5 /* cells per region */, HDR_RMUL_LO = 6, HDR_RMUL_HI = 7 /* ceil(2^40 / cells per region) */, HDR_LEVCNT = 8 /* .. +IVX_MAXL */,
+       HDR_FG = 8 + IVX_MAXL /* log2(block width) of the occupancy bitmap, or ~0u: no bitmap */, HDR_FBITS = 9 + IVX_MAXL /* its size in bits */, HDR_WORDS = 10 + IVX_MAXL };
+// Occupancy bitmap of the build side ("can a probe row match anything at all"): per key one bit per 2^g-wide block of
+// [origin, origin + span] plus one overflow block behind it; a bit is set when some build row touches the block.  Sized to
+// stay resident in an XCD's 4 MiB L2 next to the streamed probe rows.
+#define IVX_FBITS_MAX (1u << 24)    // 2 MiB
 #define IVX_MAXREG 255   // probe regions routed with ONE partition pass (one radix digit; 255 = rows that cannot match)
 #define IVX_MAXREG_WIDE 1023   // ... still one pass, with 1024 digits (overlap join count / fill only)
 #define IVX_MAXREG2 65025u   // most regions at all: beyond 255 the probe rows are routed by a two-digit stable sort
@@ -139,6 +148,8 @@ struct JoinIndexView {
     const u32 *kreg;        // [nkeys+1] first probe region of the key (regions never straddle keys)
     const u32 *rkey;        // [IVX_MAXREG2+1] key of a region
     const ivx_regdesc *rdesc;   // [IVX_MAXREG2+1] slice window of a region
+    const u32 *fbits;       // occupancy bitmap words (+2 words of padding), valid when hdr[HDR_FG] != ~0u
+    const u32 *fbase;       // [nkeys] first bit of the key (a multiple of 32)
     u32 nkeys;
 };
 
@@ -184,6 +195,7 @@ struct ivx_index {
     std::vector<size_t> alloc_caps;
     JoinIndexView jv{};
     u32 jv_nreg = 0;            // >0: the region-partitioned probe is available
+    bool jv_filter = false;     // jv carries an occupancy bitmap (hdr[HDR_FG] != ~0u)
     RankGridView gs{}, ge{};
     CoverageView cv{};
     NearestView nv{};
@@ -212,7 +224,7 @@ enum { JP_COUNT = 0, JP_PER_ROW = 1, JP_EXISTS = 2, JP_FILL = 3 };
 // join_regions.hip: partition the probe rows by index region, probe each region from LDS
 ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nreg, int mode,
                                   const u32 *key, const i32 *s, const i32 *e, u64 n,
-                                  u32 *ob, u32 *op, u64 cap, u64 *d_cursor, bool planned = false);
+                                  u32 *ob, u32 *op, u64 cap, u64 *d_cursor, bool planned = false, bool has_filter = false);
 
 // per-row-output operators through the same partition (count_overlaps: jv over the build rows, no row with
 // end < start; coverage: jv over the merged nodes)

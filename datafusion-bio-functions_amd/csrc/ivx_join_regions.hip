@@ -23,7 +23,7 @@
 #include <type_traits>
 #include "ivx_join.hpp"
 #include <cstdlib>
-#include <cstdlib>
+#include <cstring>
 
 namespace {
 
@@ -270,6 +270,252 @@ __global__ __launch_bounds__(PA_T) void k_part_scatter(JoinIndexView ix, const u
     }
 }
 
+// ------------------------------------------------------------------ one-pass partition into region pages
+// The two-pass partition above reads the probe rows twice (histogram, then scatter) because a region's rows must end
+// up contiguous, and where a region starts depends on every other tile.  Here a region's rows go to PAGES instead
+// (2^lgpg rows each, taken from one pool on demand), so a tile needs nothing from the others but a position in its
+// regions' row streams:
+//   - the tile's rows are ranked by region in LDS as before; rows that cannot match anything are dropped first:
+//     unknown keys, keys without build rows, rows that end before the key's first start, and rows whose blocks of
+//     the build side's occupancy bitmap are all empty (filter_pass; the bitmap sits in L2, the rows stream past it);
+//   - the thread that owns region r reserves the tile's run in r's stream with ONE returning atomicAdd on rcur[r]
+//     (virtual row numbers v .. v+c-1); virtual page p of region r lives wherever ptab[r][p] says.  The tile whose run
+//     holds a page's first row takes a page from the pool (atomicAdd on *pool_next) and publishes it; a tile that finds
+//     the entry still empty polls it -- the publisher never waits for anything between its reservation and the
+//     publication, so the poll ends (the entries are 4-byte granules written and read at agent scope);
+//   - rows leave LDS as contiguous runs as before, into their pages.
+// The probe kernels read region r's rows through the same table (PAGED).  Order inside a region is free, as everywhere.
+// per-key tables of the one-pass partition.  KLDS (at most KT_MAX keys): cached in LDS; otherwise read from the index.
+// The two sets are never mixed in one pointer: a pointer that may be LDS or global becomes flat loads with full waits.
+struct KeyTab2 {
+    const i32 *s_origin; const u32 *s_span, *s_kreg, *s_fbase;      // LDS; kreg = 0xFFFFFFFF: key has no build rows
+    const u32 *fbits;
+    u32 nkeys, sh0, cs, fg;
+    u64 rmul;
+};
+
+template <bool KLDS>
+__device__ __forceinline__ void keytab2_load(const JoinIndexView &ix, i32 *s_origin, u32 *s_span, u32 *s_kreg, u32 *s_fbase, KeyTab2 &kt, bool use_filter)
+{
+    kt.nkeys = ix.nkeys; kt.sh0 = ix.hdr[HDR_SH0]; kt.cs = ix.hdr[HDR_CS]; kt.fg = use_filter ? ix.hdr[HDR_FG] : 0xFFFFFFFFu;
+    kt.rmul = (u64)ix.hdr[HDR_RMUL_LO] | ((u64)ix.hdr[HDR_RMUL_HI] << 32);
+    kt.fbits = ix.fbits;
+    if (KLDS) {
+        for (u32 k = threadIdx.x; k < ix.nkeys; k += blockDim.x) {
+            s_origin[k] = ix.origin[k]; s_span[k] = ix.span[k];
+            s_kreg[k] = ix.kcnt[k] ? ix.kreg[k] : 0xFFFFFFFFu;
+            s_fbase[k] = kt.fg != 0xFFFFFFFFu ? ix.fbase[k] : 0u;
+        }
+    }
+    kt.s_origin = s_origin; kt.s_span = s_span; kt.s_kreg = s_kreg; kt.s_fbase = s_fbase;
+}
+
+// Which region a row is routed to, in two steps so that a thread can have the bitmap gathers of all its rows in flight
+// together (a branch on one row's looked-up word would make the next row's gather wait for it):
+//   route_prep   region of the row (NO_REGION: unknown key, key without build rows, row ends before the key's first
+//                start) and the position of its window of the occupancy bitmap: first bit | (blocks - 1) << 26
+//                (0x3F blocks-1 = more than 32 blocks: not tested)
+//   route_test   whether any block of the window is set, given the 8 bytes that start at the 4-byte word holding the
+//                window's first bit (up to 32 blocks always fit)
+template <bool KLDS, bool FILT>
+__device__ __forceinline__ u32 route_prep(const JoinIndexView &ix, const KeyTab2 &kt, u32 k, i32 qs, i32 qe, u32 &fpos)
+{
+    const bool kok = k < kt.nkeys;
+    const u32 kk = kok ? k : 0u;
+    const u32 kreg = KLDS ? kt.s_kreg[kk] : (ix.kcnt[kk] ? ix.kreg[kk] : 0xFFFFFFFFu);
+    const i64 o = KLDS ? kt.s_origin[kk] : ix.origin[kk];
+    const u32 span = KLDS ? kt.s_span[kk] : ix.span[kk];
+    const i64 hi = (i64)qe - o;                                     // < 0: every build row of the key starts behind qe
+    const i64 d = (i64)qs - o;
+    const bool ok = kok & (kreg != 0xFFFFFFFFu) & (hi >= 0);
+    fpos = 0;
+    if (FILT) {
+        const u32 lastb = (span >> kt.fg) + 1u;                     // the overflow block
+        const u64 x0 = (u64)(d < 0 ? 0 : d) >> kt.fg, x1 = (u64)(hi < 0 ? 0 : hi) >> kt.fg;
+        const u32 c0 = x0 > lastb ? lastb : (u32)x0, c1 = x1 > lastb ? lastb : (u32)x1;
+        const u32 b0 = c0 < c1 ? c0 : c1, b1 = c0 < c1 ? c1 : c0;   // (a row with end < start matches build rows that contain [end, start])
+        const u32 nb1 = b1 - b0;                                    // blocks - 1
+        const u32 fb = KLDS ? kt.s_fbase[kk] : ix.fbase[kk];
+        fpos = ok ? (fb + b0) | ((nb1 > 31u ? 0x3Fu : nb1) << 26) : 0u;
+    }
+    const u32 last = span >> kt.sh0;
+    const i64 c64 = d <= 0 ? 0 : (d >> kt.sh0);
+    const u32 c = c64 > (i64)last ? last : (u32)c64;
+    const u32 reg = kreg + (kt.cs != 0xFFFFFFFFu ? c >> kt.cs : (u32)(((u64)c * kt.rmul) >> 40));
+    return ok ? reg : NO_REGION;
+}
+
+__device__ __forceinline__ bool route_test(u32 fpos, u64 win)
+{
+    const u32 nb1 = fpos >> 26;
+    const u64 m = (2ull << (nb1 & 31u)) - 1ull;
+    return (nb1 == 0x3Fu) | (((win >> (fpos & 31u)) & m) != 0);
+}
+
+struct PageTab { u32 *ptab; u32 pstride, lgpg; };                 // [region][page slot] -> pool page + 1 (0 = not there yet)
+
+__device__ __forceinline__ u32 page_wait(u32 *slot)
+{
+    u32 v;
+    while ((v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) __builtin_amdgcn_s_sleep(2);
+    return v - 1u;
+}
+
+// four consecutive rows per lane, streamed past the caches' keep-lists (the occupancy bitmap should stay in L2)
+template <bool VEC>
+__device__ __forceinline__ void load4nt(const u32 *__restrict__ pkey, const i32 *__restrict__ ps, const i32 *__restrict__ pe,
+                                        u64 i, u64 hi, u32 (&k)[4], i32 (&s)[4], i32 (&e)[4])
+{
+    if (VEC && i + 4 <= hi) {
+        typedef u32 __attribute__((ext_vector_type(4))) v4u;
+        typedef i32 __attribute__((ext_vector_type(4))) v4i;
+        const v4u kv = pkey ? __builtin_nontemporal_load(reinterpret_cast<const v4u *>(pkey + i)) : v4u{0u, 0u, 0u, 0u};
+        const v4i sv = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(ps + i));
+        const v4i ev = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(pe + i));
+        k[0] = kv.x; k[1] = kv.y; k[2] = kv.z; k[3] = kv.w;
+        s[0] = sv.x; s[1] = sv.y; s[2] = sv.z; s[3] = sv.w;
+        e[0] = ev.x; e[1] = ev.y; e[2] = ev.z; e[3] = ev.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const bool ok = i + j < hi;
+            k[j] = ok ? (pkey ? pkey[i + j] : 0u) : 0xFFFFFFFFu;
+            s[j] = ok ? ps[i + j] : 0;
+            e[j] = ok ? pe[i + j] : 0;
+        }
+    }
+}
+
+// ND digits (256 / 1024), I rows per thread and tile (tile = 1024 * I rows <= one page)
+template <bool VEC, int ND, int I, bool KLDS, bool FILT>
+__global__ __launch_bounds__(PA_T) void k_part_onepass(JoinIndexView ix, const u32 *__restrict__ pkey, const i32 *__restrict__ ps,
+                                                       const i32 *__restrict__ pe, u64 n, u32 chunk, u32 *__restrict__ rcur, PageTab pt,
+                                                       u32 *pool_next, u64 *__restrict__ out_se, u32 *__restrict__ out_row)
+{
+    constexpr int TILE = PA_T * I;
+    __shared__ u64 r_se[TILE];
+    __shared__ unsigned short r_slot[TILE];
+    using DigT = typename std::conditional<(ND > 256), unsigned short, unsigned char>::type;
+    __shared__ DigT r_dig[TILE];
+    __shared__ u32 dstart[ND], vbase[ND], pg0[ND];
+    __shared__ u32 scan_lds[PA_T / IVX_WAVE + 1];
+    __shared__ i32 s_origin[KT_MAX];
+    __shared__ u32 s_span[KT_MAX], s_kreg[KT_MAX], s_fbase[KT_MAX];
+
+    const u32 tid = threadIdx.x;
+    KeyTab2 kt;
+    keytab2_load<KLDS>(ix, s_origin, s_span, s_kreg, s_fbase, kt, FILT);
+    const u32 pmask = (1u << pt.lgpg) - 1u;
+    const u64 lo = (u64)blockIdx.x * chunk;
+    const u64 hi = lo + chunk < n ? lo + chunk : n;
+    for (u64 t0 = lo; t0 < hi; t0 += TILE) {
+        if (tid < ND) dstart[tid] = 0;
+        __syncthreads();
+        u64 se[I]; u32 dig[I], lrank[I];
+        {
+            // all of the tile's row loads first, then all of its bitmap gathers: straight-line code (no per-row branches),
+            // so that the loads of a stage are in flight together
+            u32 kk[I]; i32 qs[I], qe[I];
+            if (VEC && t0 + TILE <= hi) {
+                typedef u32 __attribute__((ext_vector_type(4))) v4u;
+                typedef i32 __attribute__((ext_vector_type(4))) v4i;
+#pragma unroll
+                for (int v = 0; v < I / 4; v++) {
+                    const u64 i = t0 + ((u64)v * PA_T + tid) * 4;
+                    const v4u kv = pkey ? __builtin_nontemporal_load(reinterpret_cast<const v4u *>(pkey + i)) : v4u{0u, 0u, 0u, 0u};
+                    const v4i sv = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(ps + i));
+                    const v4i ev = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(pe + i));
+                    kk[v * 4] = kv.x; kk[v * 4 + 1] = kv.y; kk[v * 4 + 2] = kv.z; kk[v * 4 + 3] = kv.w;
+                    qs[v * 4] = sv.x; qs[v * 4 + 1] = sv.y; qs[v * 4 + 2] = sv.z; qs[v * 4 + 3] = sv.w;
+                    qe[v * 4] = ev.x; qe[v * 4 + 1] = ev.y; qe[v * 4 + 2] = ev.z; qe[v * 4 + 3] = ev.w;
+                }
+            } else {
+#pragma unroll
+                for (int v = 0; v < I / 4; v++) {
+                    u32 k4[4]; i32 s4[4], e4[4];
+                    load4nt<false>(pkey, ps, pe, t0 + ((u64)v * PA_T + tid) * 4, hi, k4, s4, e4);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { kk[v * 4 + j] = k4[j]; qs[v * 4 + j] = s4[j]; qe[v * 4 + j] = e4[j]; }
+                }
+            }
+            u32 fpos[I];
+#pragma unroll
+            for (int k = 0; k < I; k++) {
+                se[k] = (u64)(u32)qs[k] | ((u64)(u32)qe[k] << 32);
+                dig[k] = route_prep<KLDS, FILT>(ix, kt, kk[k], qs[k], qe[k], fpos[k]);
+            }
+            if (FILT) {
+                u64 win[I];
+#pragma unroll
+                for (int k = 0; k < I; k++) __builtin_memcpy(&win[k], kt.fbits + ((fpos[k] & 0x3FFFFFFu) >> 5), sizeof(u64));
+#pragma unroll
+                for (int k = 0; k < I; k++) dig[k] = route_test(fpos[k], win[k]) ? dig[k] : NO_REGION;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < I; k++) lrank[k] = lds_count_up(dstart, dig[k], dig[k] != NO_REGION);
+        __syncthreads();
+        // ---- reserve the tile's run in every region's row stream; take / look up the pages it touches
+        const u32 mine = tid < ND ? dstart[tid] : 0u;
+        u32 v = 0;
+        if (mine) v = atomicAdd(&rcur[tid], mine);
+        u32 tot;
+        const u32 ds = block_excl_scan<u32, PA_T>(mine, scan_lds, &tot);     // (barriers inside: every counter is read before any is overwritten)
+        if (tid < ND) dstart[tid] = ds;
+        __syncthreads();
+        // (the returned v is first needed after the LDS re-order below, which runs while the atomics are in flight)
+#pragma unroll
+        for (int k = 0; k < I; k++) {
+            if (dig[k] != NO_REGION) {
+                const u32 pos = dstart[dig[k]] + lrank[k];
+                r_se[pos] = se[k];
+                r_slot[pos] = (unsigned short)(((k / 4) * PA_T + tid) * 4 + (k % 4));
+                r_dig[pos] = (DigT)dig[k];
+            }
+        }
+        if (mine) {
+            u32 *row = pt.ptab + (u64)tid * pt.pstride;
+            const u32 p0 = v >> pt.lgpg, p1 = (v + mine - 1u) >> pt.lgpg;       // TILE <= page: at most one page border inside the run
+            const bool own0 = (v & pmask) == 0u, own1 = p1 != p0;
+            u32 got = 0;
+            if (own0 || own1) {
+                got = atomicAdd(pool_next, (own0 ? 1u : 0u) + (own1 ? 1u : 0u));
+                if (own0) __hip_atomic_store(&row[p0], got + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (own1) __hip_atomic_store(&row[p1], got + (own0 ? 2u : 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            vbase[tid] = v;
+            pg0[tid] = own0 ? got : page_wait(&row[p0]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < I; k++) {
+            const u32 j = k * PA_T + tid;
+            if (j < tot) {
+                const u32 d = r_dig[j];
+                const u32 x = vbase[d] + (j - dstart[d]);                       // virtual row number in region d
+                u32 pg = pg0[d];
+                if ((x >> pt.lgpg) != (vbase[d] >> pt.lgpg)) pg = page_wait(pt.ptab + (u64)d * pt.pstride + (x >> pt.lgpg));   // the run's second page
+                const u64 g = ((u64)pg << pt.lgpg) + (x & pmask);
+                out_se[g] = r_se[j];
+                out_row[g] = (u32)(t0 + r_slot[j]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// first routed row of every region (exclusive scan of the regions' row counts; nreg <= IVX_MAXREG_WIDE), as the probe
+// kernels' region table
+__global__ __launch_bounds__(1024) void k_page_bounds(const u32 *__restrict__ rcur, u32 nreg, u32 *__restrict__ rfirst)
+{
+    __shared__ u32 red[1024 / IVX_WAVE + 1];
+    const u32 t = threadIdx.x;
+    u32 tot;
+    const u32 ex = block_excl_scan<u32, 1024>(t < nreg ? rcur[t] : 0u, red, &tot);
+    if (t < nreg) rfirst[t] = ex;
+    if (t == 0) rfirst[nreg] = tot;
+}
+
 // ------------------------------------------------------------------ region probe
 
 constexpr int RP_T = 1024;                 // one workgroup per CU (LDS-bound), 16 wavefronts
@@ -289,6 +535,7 @@ constexpr u32 RP_CCAP = 8192 + RP_HALO + 2;
 constexpr u32 RP_ECAP = IVX_RP_ECAP;       // entries staged per slice
 constexpr u32 RP_RING = IVX_RP_RING;       // per-wavefront ring of staged pairs: two consecutive rounds must fit (power of two)
 constexpr u32 RP_NSLOT = 4;                // rounds whose reservation state is kept (see round_publish)
+constexpr u32 RP_NPG = 64;                 // page ids of one region segment kept in LDS (paged rows)
 constexpr u32 RP_GRID = 256;                // fill pass: one workgroup per CU (LDS-bound)
 #ifndef IVX_RP_VGRID
 #define IVX_RP_VGRID 512
@@ -582,24 +829,60 @@ __device__ __forceinline__ void round_copy_out(const ProbeLds &L, u32 mine, u32 
 //   MODE 1 (fill): single walk, see batch_walk / round_publish / round_copy_out.
 //   MODE RV_COUNT / RV_COVERAGE: one 32-bit value per row, written at the row's partitioned position
 //           (`ob`), no synchronisation at all; k_unpermute puts the values back in input order.
-template <int MODE, int B, bool IDENT>
+// rows per lane and wavefront batch of the fill pass, chosen on the device from the pairs expected per ROUTED row
+// (`hint` pairs over the rows the partition kept): the same rule as fill_rows_per_lane below
+__global__ void k_pick_rows(const u32 *__restrict__ rfirst, u32 nreg, u64 hint, u32 force, u32 *bsel)
+{
+    const u32 routed = rfirst[nreg];
+    const float per_row = (float)((double)hint / (double)(routed ? routed : 1u));
+    *bsel = force ? force : per_row <= 0.45f ? 8u : per_row <= 0.9f ? 4u : per_row <= 1.8f ? 2u : 1u;
+}
+
+template <int MODE, int B, bool IDENT, bool PAGED = false>
 __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const void *__restrict__ rows_a, const void *__restrict__ rows_b,
                                                         const u32 *__restrict__ offs, u32 nblk, u32 vpb,
                                                         u32 *__restrict__ ob, u32 *__restrict__ op, u64 cap,
                                                         unsigned long long *cursor, u32 prow_stride, u32 adj,
-                                                        const u32 *unsorted, int dbg)
+                                                        const u32 *unsorted, int dbg, PageTab pt = PageTab{nullptr, 0u, 0u},
+                                                        const u32 *bsel = nullptr)
 {
     constexpr bool FILL = MODE == 1;
+    if (bsel != nullptr && *bsel != (u32)B) return;                   // (every B is launched; k_pick_rows chose one)
     // IDENT: the input already is in region order (k_part_hist left `unsorted` at 0): the partitioned arrays
     // were never written and row i IS input row i.  Both instantiations are launched; the one whose case
     // does not apply returns at once (the host never waits for the flag).
     if ((unsorted != nullptr && *unsorted == 0) != IDENT) return;
-    // rows_a / rows_b: the partitioned (qs,qe) and row-id arrays, or -- IDENT -- the input start and end columns
+    // rows_a / rows_b: the partitioned (qs,qe) and row-id arrays, or -- IDENT -- the input start and end columns, or --
+    // PAGED -- the page pool of the one-pass partition: routed row i of region r (whose first routed row is rf) sits at
+    // row_at(i, r, rf) of the pool
+    static_assert(!(IDENT && PAGED), "paged rows are never read in place");
+    __shared__ u32 s_pg[RP_NPG];                                      // the pages of the region segment being walked
+    u32 pg_first = 0;
+    // (the page id always comes from LDS: a choice between an LDS and a global pointer becomes a flat load with
+    //  vmcnt(0) waits that serialise the row loads)
+    auto row_at = [&](u64 i, u32, u64 rf) -> u64 {
+        if (!PAGED) return i;
+        const u32 x = (u32)(i - rf);
+        const u32 pg = s_pg[(x >> pt.lgpg) - pg_first] - 1u;
+        return ((u64)pg << pt.lgpg) + (x & ((1u << pt.lgpg) - 1u));
+    };
+    // (all threads; barriers inside) the page ids of routed rows [lo, c_hi) of region r; c_hi is cut back to what RP_NPG
+    // pages hold (the caller then walks the rest of the region as another segment)
+    auto pages_load = [&](u64 lo, u64 &c_hi, u32 r, u64 rf) {
+        if (!PAGED) return;
+        __syncthreads();
+        pg_first = (u32)(lo - rf) >> pt.lgpg;
+        const u64 lim = (rf + ((u64)(pg_first + RP_NPG) << pt.lgpg)) & ~63ull;   // (a cut falls between two 64-row granules)
+        if (c_hi > lim) c_hi = lim;
+        const u32 npg = ((u32)(c_hi - 1 - rf) >> pt.lgpg) - pg_first + 1u;
+        if (threadIdx.x < npg) s_pg[threadIdx.x] = pt.ptab[(u64)r * pt.pstride + pg_first + threadIdx.x];
+        __syncthreads();
+    };
     auto row_se = [&](u64 i) -> u64 {
         if (IDENT) return (u64)(u32)((u32)((const i32 *)rows_a)[i] + adj) | ((u64)(u32)((u32)((const i32 *)rows_b)[i] - adj) << 32);
         return ((const u64 *)rows_a)[i];
     };
-    auto row_id = [&](u64 i) -> u32 { return IDENT ? (u32)i : ((const u32 *)rows_b)[i * prow_stride]; };
+    auto row_id = [&](u64 i, u64 at) -> u32 { return IDENT ? (u32)i : ((const u32 *)rows_b)[at * prow_stride]; };
     dbg = IVX_DBG_ARG(dbg);
     constexpr u32 WB = IVX_WAVE * B;                                  // rows per wavefront batch
     IVX_PROBE_LDS(FILL)
@@ -631,7 +914,7 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
             }
             for (; lo < hi; r++) {
                 const u64 rend = rfirst(r + 1);
-                const u64 c_hi = hi < rend ? hi : rend;
+                u64 c_hi = hi < rend ? hi : rend;
                 if (c_hi <= lo) continue;
                 // every wavefront streams one batch of WB rows per round; the next round's rows are in
                 // flight while the current batch walks the LDS slice (the first batch while the slice loads)
@@ -639,11 +922,14 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
                 // a round is RP_W * WB consecutive rows; wavefront w takes the 64-row granules w, w+16, ... of it, so
                 // that dense and empty stretches of sorted input are shared evenly by the 16 wavefronts
                 u64 b0 = lo + (u64)wv * IVX_WAVE;
+                const u64 rf = PAGED ? rfirst(r) : 0;
+                pages_load(lo, c_hi, r, rf);
 #pragma unroll
                 for (int q = 0; q < B; q++) {
                     const u64 i = b0 + (u64)q * (RP_W * IVX_WAVE) + ln;
-                    nx[q] = i < c_hi ? row_se(i) : 0;
-                    nxr[q] = (FILL && i < c_hi) ? row_id(i) : 0u;
+                    const u64 at = i < c_hi ? row_at(i, r, rf) : 0;
+                    nx[q] = i < c_hi ? row_se(at) : 0;
+                    nxr[q] = (FILL && i < c_hi) ? row_id(i, at) : 0u;
                 }
                 slice_load(ix, S, L, r, r != loaded_r);
                 loaded_r = r;
@@ -660,8 +946,9 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
 #pragma unroll
                         for (int q = 0; q < B; q++) {
                             const u64 i = b1 + (u64)q * (RP_W * IVX_WAVE) + ln;
-                            nx[q] = i < c_hi ? row_se(i) : 0;
-                            nxr[q] = (FILL && i < c_hi) ? row_id(i) : 0u;
+                            const u64 at = i < c_hi ? row_at(i, r, rf) : 0;
+                            nx[q] = i < c_hi ? row_se(at) : 0;
+                            nxr[q] = (FILL && i < c_hi) ? row_id(i, at) : 0u;
                         }
                     }
                     if (MODE >= RV_COUNT) {
@@ -689,6 +976,7 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
                     pend_mine = got; pend_start = start; round++;
                 }
                 lo = c_hi;
+                if (PAGED && lo < hi && lo < rend) r--;               // the segment was cut at the page window: same region again
             }
         }
         if (MODE == 0) {
@@ -710,17 +998,41 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
 //   PASS 1  the piece is walked again in lock step (every lane steps through its candidates together); the lanes
 //           that match in a step take consecutive positions after the piece's running offset by ballot rank, so
 //           the stores of a step are contiguous.  Order inside a piece is arbitrary, like everywhere else.
-template <int PASS, bool IDENT>
+template <int PASS, bool IDENT, bool PAGED = false>
 __global__ __launch_bounds__(RP_T) void k_probe_dense(JoinIndexView ix, const void *__restrict__ rows_a, const void *__restrict__ rows_b,
                                                       const u32 *__restrict__ offs, u32 nblk, u32 prow_stride, const u32 *unsorted,
-                                                      u64 *__restrict__ pcount, u32 *__restrict__ ob, u32 *__restrict__ op, u64 cap)
+                                                      u64 *__restrict__ pcount, u32 *__restrict__ ob, u32 *__restrict__ op, u64 cap,
+                                                      PageTab pt = PageTab{nullptr, 0u, 0u})
 {
     if ((unsorted != nullptr && *unsorted == 0) != IDENT) return;
+    static_assert(!(IDENT && PAGED), "paged rows are never read in place");
+    __shared__ u32 s_pg[RP_NPG];
+    u32 pg_first = 0;
+    // (the page id always comes from LDS: a choice between an LDS and a global pointer becomes a flat load with
+    //  vmcnt(0) waits that serialise the row loads)
+    auto row_at = [&](u64 i, u32, u64 rf) -> u64 {
+        if (!PAGED) return i;
+        const u32 x = (u32)(i - rf);
+        const u32 pg = s_pg[(x >> pt.lgpg) - pg_first] - 1u;
+        return ((u64)pg << pt.lgpg) + (x & ((1u << pt.lgpg) - 1u));
+    };
+    // (all threads; barriers inside) the page ids of routed rows [lo, c_hi) of region r; c_hi is cut back to what RP_NPG
+    // pages hold (the caller then walks the rest of the region as another segment)
+    auto pages_load = [&](u64 lo, u64 &c_hi, u32 r, u64 rf) {
+        if (!PAGED) return;
+        __syncthreads();
+        pg_first = (u32)(lo - rf) >> pt.lgpg;
+        const u64 lim = (rf + ((u64)(pg_first + RP_NPG) << pt.lgpg)) & ~63ull;   // (a cut falls between two 64-row granules)
+        if (c_hi > lim) c_hi = lim;
+        const u32 npg = ((u32)(c_hi - 1 - rf) >> pt.lgpg) - pg_first + 1u;
+        if (threadIdx.x < npg) s_pg[threadIdx.x] = pt.ptab[(u64)r * pt.pstride + pg_first + threadIdx.x];
+        __syncthreads();
+    };
     auto row_se = [&](u64 i) -> u64 {
         if (IDENT) return (u64)(u32)((const i32 *)rows_a)[i] | ((u64)(u32)((const i32 *)rows_b)[i] << 32);
         return ((const u64 *)rows_a)[i];
     };
-    auto row_id = [&](u64 i) -> u32 { return IDENT ? (u32)i : ((const u32 *)rows_b)[i * prow_stride]; };
+    auto row_id = [&](u64 i, u64 at) -> u32 { return IDENT ? (u32)i : ((const u32 *)rows_b)[at * prow_stride]; };
     __shared__ unsigned short s_off[RP_CCAP];
     __shared__ u64 s_ent[RP_ECAP];
     __shared__ u32 s_row[RP_ECAP];
@@ -743,20 +1055,22 @@ __global__ __launch_bounds__(RP_T) void k_probe_dense(JoinIndexView ix, const vo
     { u32 a = 0, b = nreg; while (a < b) { const u32 m = (a + b + 1) >> 1; if (rfirst(m) <= lo) a = m; else b = m - 1; } r = a; }
     for (; lo < hi; r++) {
         const u64 rend = rfirst(r + 1);
-        const u64 c_hi = hi < rend ? hi : rend;
+        u64 c_hi = hi < rend ? hi : rend;
         if (c_hi <= lo) continue;
-        const u64 g1 = (c_hi + 63) >> 6;
         u64 g = (lo >> 6) + wv;
         // the first granule's rows are in flight while the slice loads
         u64 nx = 0; u32 nxr = 0;
-        { const u64 i = g * 64 + ln; const bool ok = g < g1 && i >= lo && i < c_hi; nx = ok ? row_se(i) : 0; nxr = (PASS == 1 && ok) ? row_id(i) : 0u; }
+        const u64 rf = PAGED ? rfirst(r) : 0;
+        pages_load(lo, c_hi, r, rf);
+        const u64 g1 = (c_hi + 63) >> 6;
+        { const u64 i = g * 64 + ln; const bool ok = g < g1 && i >= lo && i < c_hi; const u64 at = ok ? row_at(i, r, rf) : 0; nx = ok ? row_se(at) : 0; nxr = (PASS == 1 && ok) ? row_id(i, at) : 0u; }
         slice_load(ix, S, L, r, true);
         for (; g < g1; g += RP_W) {
             const u64 i = g * 64 + ln;
             const bool ok = i >= lo && i < c_hi;
             const i32 qs = (i32)(u32)nx, qe = (i32)(u32)(nx >> 32);
             const u32 rowv = nxr;
-            { const u64 g2 = g + RP_W; const u64 i2 = g2 * 64 + ln; const bool ok2 = g2 < g1 && i2 >= lo && i2 < c_hi; nx = ok2 ? row_se(i2) : 0; nxr = (PASS == 1 && ok2) ? row_id(i2) : 0u; }
+            { const u64 g2 = g + RP_W; const u64 i2 = g2 * 64 + ln; const bool ok2 = g2 < g1 && i2 >= lo && i2 < c_hi; const u64 at = ok2 ? row_at(i2, r, rf) : 0; nx = ok2 ? row_se(at) : 0; nxr = (PASS == 1 && ok2) ? row_id(i2, at) : 0u; }
             const u64 slot = g + r;
             if (PASS == 0) {
                 u32 c = 0;
@@ -844,6 +1158,7 @@ __global__ __launch_bounds__(RP_T) void k_probe_dense(JoinIndexView ix, const vo
             }
         }
         lo = c_hi;
+        if (PAGED && lo < hi && lo < rend) r--;                       // cut at the page window: same region again
     }
 }
 
@@ -1184,7 +1499,7 @@ static bool dense_fill_wanted(u64 cap, u64 n)
 
 ivx_status dense_fill(ivx_ctx *ctx, const JoinIndexView &jv, u32 nreg, const void *rows_se, const void *rows_id, u32 prow_stride,
                       const i32 *s, const i32 *e, const u32 *offs, u32 nblk, const u32 *unsorted, u64 n,
-                      u32 *ob, u32 *op, u64 cap, u64 *d_cursor)
+                      u32 *ob, u32 *op, u64 cap, u64 *d_cursor, const PageTab *pt = nullptr)
 {
     hipStream_t st = ctx->stream;
     const u64 slots = (n >> 6) + nreg + 3;
@@ -1192,6 +1507,7 @@ ivx_status dense_fill(ivx_ctx *ctx, const JoinIndexView &jv, u32 nreg, const voi
     IVX_TRY(ctx->get_scratch(WS_T3, slots * sizeof(u64), (void **)&pcount));
     IVX_HIP(ctx, hipMemsetAsync(pcount, 0, slots * sizeof(u64), st));
 #define IVX_DENSE_PASS(P_) do { \
+        if (pt) { hipLaunchKernelGGL((k_probe_dense<P_, false, true>), dim3(RP_VGRID), dim3(RP_T), 0, st, jv, rows_se, rows_id, offs, nblk, prow_stride, unsorted, pcount, ob, op, cap, *pt); break; } \
         hipLaunchKernelGGL((k_probe_dense<P_, false>), dim3(RP_VGRID), dim3(RP_T), 0, st, jv, rows_se, rows_id, offs, nblk, prow_stride, unsorted, pcount, ob, op, cap); \
         if (unsorted) hipLaunchKernelGGL((k_probe_dense<P_, true>), dim3(RP_VGRID), dim3(RP_T), 0, st, jv, (const void *)s, (const void *)e, offs, nblk, 1u, unsorted, pcount, ob, op, cap); } while (0)
     IVX_DENSE_PASS(0);
@@ -1255,7 +1571,7 @@ ivx_status probe_two_level(ivx_ctx *ctx, const JoinIndexView &jv, int mode, u32 
     hipLaunchKernelGGL(k_p2_bounds, dim3(bgrid), dim3(WR_T), 0, st, nreg, G, nsuper, (const u32 *)hist1, nblk1, nh1, (const u32 *)tprefix, (const u32 *)hist2, rfirst, (const u32 *)unsorted);
     hipLaunchKernelGGL(k_sorted_bounds, dim3(bgrid), dim3(WR_T), 0, st, jv, key, s, n, nreg, rfirst, (const u32 *)unsorted);
     if (mode == JP_COUNT) {                                             // leave the routed rows for the fill call (ivx_capi.hip fills in whose they are)
-        pl.hist = rfirst; pl.pse = pse2; pl.prow = prow2; pl.ds = s; pl.de = e; pl.chunk = 0; pl.nblk = 1;
+        pl.hist = rfirst; pl.pse = pse2; pl.prow = prow2; pl.ds = s; pl.de = e; pl.chunk = 0; pl.nblk = 1; pl.paged = false;
         pl.slots = 0;
         for (int slot : {WS_SORTHIST, WS_T0, WS_T1, WS_T2, WS_SA0, WS_SA1, WS_T4, WS_T5, WS_T6, WS_IN_START, WS_IN_END}) pl.slots |= 1ull << slot;
         pl.valid = true;
@@ -1284,7 +1600,7 @@ ivx_status probe_two_level(ivx_ctx *ctx, const JoinIndexView &jv, int mode, u32 
 
 ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nreg, int mode,
                                   const u32 *key, const i32 *s, const i32 *e, u64 n,
-                                  u32 *ob, u32 *op, u64 cap, u64 *d_cursor, bool planned)
+                                  u32 *ob, u32 *op, u64 cap, u64 *d_cursor, bool planned, bool has_filter)
 {
     if (n == 0) return IVX_OK;
     ivx_join_plan &pl = ctx->join_plan;
@@ -1295,6 +1611,71 @@ ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nre
 #else
     const int dbg = 0;
 #endif
+    // one partition pass into region pages (k_part_onepass), unless the old two-pass partition is asked for
+    // (IVX_PART=two: A/B measurements and the tests that pin both)
+    const bool two_pass = getenv("IVX_PART") && !strcmp(getenv("IVX_PART"), "two");
+    if ((planned && pl.paged) || (!planned && !two_pass)) {
+        const bool wide = nreg > IVX_MAXREG;
+        PageTab pt; const u32 *rfirst; const u64 *pool_se; const u32 *pool_row;
+        if (planned) {
+            pt = PageTab{const_cast<u32 *>(pl.ptab), pl.pstride, pl.lgpg};
+            rfirst = pl.hist; pool_se = pl.pse; pool_row = pl.prow;
+        } else {
+            u32 lgpg = 14;                                              // a page holds at least a tile; at most ~4096 pages per region
+            while (lgpg < 31 && (n >> lgpg) > 4096) lgpg++;
+            const u64 pstride = (n >> lgpg) + 2;
+            const u64 npages = (n >> lgpg) + nreg + 1;
+            u32 *ctl, *ptab; u64 *pse; u32 *prow;
+            IVX_TRY(ctx->get_scratch(WS_SORTHIST, (1024 + 8 + 1032) * sizeof(u32), (void **)&ctl));   // rcur[1024] | pool_next | .. | rfirst[<= 1025]
+            IVX_TRY(ctx->get_scratch(WS_T2, (size_t)nreg * pstride * sizeof(u32), (void **)&ptab));
+            IVX_TRY(ctx->get_scratch(WS_T0, (size_t)(npages << lgpg) * sizeof(u64), (void **)&pse));
+            IVX_TRY(ctx->get_scratch(WS_T1, (size_t)(npages << lgpg) * sizeof(u32), (void **)&prow));
+            IVX_HIP(ctx, hipMemsetAsync(ctl, 0, (1024 + 8) * sizeof(u32), st));
+            IVX_HIP(ctx, hipMemsetAsync(ptab, 0, (size_t)nreg * pstride * sizeof(u32), st));
+            pt = PageTab{ptab, (u32)pstride, lgpg};
+            u32 *rcur = ctl, *pool_next = ctl + 1024, *rf = ctl + 1032;
+            const bool vec = (((uintptr_t)key | (uintptr_t)s | (uintptr_t)e) & 15) == 0;
+            const u32 tile = wide ? PA_T * 8u : PA_T * 12u;
+            const u32 tiles = n >= (16u << 20) ? 4u : n >= (4u << 20) ? 2u : 1u;
+            const u32 chunk1 = tile * tiles;
+            const u32 nblk1 = (u32)((n + chunk1 - 1) / chunk1);
+#define IVX_ONEPASS3(V_, ND_, I_, K_, F_) hipLaunchKernelGGL((k_part_onepass<V_, ND_, I_, K_, F_>), dim3(nblk1), dim3(PA_T), 0, st, jv, key, s, e, n, chunk1, rcur, pt, pool_next, pse, prow)
+#define IVX_ONEPASS2(V_, ND_, I_, K_) do { if (use_filter) IVX_ONEPASS3(V_, ND_, I_, K_, true); else IVX_ONEPASS3(V_, ND_, I_, K_, false); } while (0)
+#define IVX_ONEPASS(V_, ND_, I_) do { if (jv.nkeys <= KT_MAX) IVX_ONEPASS2(V_, ND_, I_, true); else IVX_ONEPASS2(V_, ND_, I_, false); } while (0)
+            const bool filter_off = getenv("IVX_FILTER") && !strcmp(getenv("IVX_FILTER"), "0");   // experiments: IVX_FILTER=0 routes every row
+            const bool use_filter = has_filter && !filter_off;
+            if (wide) { if (vec) IVX_ONEPASS(true, 1024, 8); else IVX_ONEPASS(false, 1024, 8); }
+            else { if (vec) IVX_ONEPASS(true, 256, 12); else IVX_ONEPASS(false, 256, 12); }
+#undef IVX_ONEPASS2
+#undef IVX_ONEPASS3
+#undef IVX_ONEPASS
+            hipLaunchKernelGGL(k_page_bounds, dim3(1), dim3(1024), 0, st, (const u32 *)rcur, nreg, rf);
+            rfirst = rf; pool_se = pse; pool_row = prow;
+            if (mode == JP_COUNT) {
+                pl.hist = rf; pl.pse = pse; pl.prow = prow; pl.ds = s; pl.de = e; pl.chunk = 0; pl.nblk = 1;
+                pl.paged = true; pl.ptab = ptab; pl.pstride = (u32)pstride; pl.lgpg = lgpg;
+                pl.slots = (1ull << WS_SORTHIST) | (1ull << WS_T0) | (1ull << WS_T1) | (1ull << WS_T2) | (1ull << WS_IN_START) | (1ull << WS_IN_END);
+                pl.valid = true;
+            }
+        }
+        unsigned long long *cur = (unsigned long long *)d_cursor;
+        // the rows the probe walks are the routed ones: the density hint is pairs per INPUT row, as the caller sized it
+        const u64 hint = planned && pl.total < cap ? pl.total : cap;
+        if (mode == JP_FILL && dense_fill_wanted(hint, n))
+            return dense_fill(ctx, jv, nreg, (const void *)pool_se, (const void *)pool_row, 1u, nullptr, nullptr, rfirst, 1u, nullptr, n, ob, op, cap, d_cursor, &pt);
+        if (mode == JP_FILL) {
+            u32 *bsel = (u32 *)(ctx->d_scalars + 11);
+            const u32 force = getenv("IVX_RP_ROWS") ? (u32)atoi(getenv("IVX_RP_ROWS")) : 0u;
+            hipLaunchKernelGGL(k_pick_rows, dim3(1), dim3(1), 0, st, rfirst, nreg, hint, force, bsel);
+#define IVX_FILLP(B_) hipLaunchKernelGGL((k_probe_regions<1, B_, false, true>), dim3(RP_GRID), dim3(RP_T), 0, st, jv, (const void *)pool_se, (const void *)pool_row, rfirst, 1u, RP_VGRID / RP_GRID, ob, op, cap, cur, 1u, 0u, (const u32 *)nullptr, 0, pt, (const u32 *)bsel)
+            IVX_FILLP(8); IVX_FILLP(4); IVX_FILLP(2); IVX_FILLP(1);
+#undef IVX_FILLP
+        } else {
+            hipLaunchKernelGGL((k_probe_regions<0, RP_B, false, true>), dim3(RP_VGRID), dim3(RP_T), 0, st, jv, (const void *)pool_se, (const void *)pool_row, rfirst, 1u, 1u, ob, op, cap, cur, 1u, 0u, (const u32 *)nullptr, 0, pt);
+        }
+        IVX_HIP(ctx, hipGetLastError());
+        return IVX_OK;
+    }
     u32 *unsorted = (u32 *)(ctx->d_scalars + 10);                       // stays 0 if the rows already come in region order
     u32 chunk, nblk; u32 *hist; u64 *pse; u32 *prow;
     if (planned) {
@@ -1322,7 +1703,7 @@ ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nre
 #undef IVX_PART
         if (mode == JP_COUNT) {
             // leave the routed rows for the fill call (ivx_capi.hip fills in whose columns they are)
-            pl.hist = hist; pl.pse = pse; pl.prow = prow; pl.ds = s; pl.de = e; pl.chunk = chunk; pl.nblk = nblk;
+            pl.hist = hist; pl.pse = pse; pl.prow = prow; pl.ds = s; pl.de = e; pl.chunk = chunk; pl.nblk = nblk; pl.paged = false;
             pl.slots = (1ull << WS_SORTHIST) | (1ull << WS_T0) | (1ull << WS_T1) | (1ull << WS_IN_START) | (1ull << WS_IN_END);
             pl.valid = true;
         }

@@ -23,32 +23,71 @@ def ctx():
 
 def _check_join(ctx, bk, bs, be, pk, ps, pe, nkeys):
     ix = ctx.build(pyivx.KIND_OVERLAP, bk, bs, be, n_keys=nkeys)
+    os.environ["IVX_FILTER"] = "force"                       # a second index that carries the occupancy bitmap whatever the density
+    try:
+        ixf = ctx.build(pyivx.KIND_OVERLAP, bk, bs, be, n_keys=nkeys)
+    finally:
+        del os.environ["IVX_FILTER"]
     want_b, want_p, want_cnt = orc.join(bk, bs, be, pk, ps, pe, per_row=True, threads=4)
     total, per_row = ctx.overlap_count(ix, pk, ps, pe, per_row=True)
     assert total == len(want_b)
     assert (per_row.astype(np.uint64) == want_cnt).all()
     # both probe paths: gathers straight from the index, and region-partitioned through LDS
-    # ... and for the latter both ways of writing the pairs: staging ring (IVX_DENSE=0) and count-scan-write (1)
+    # ... for the latter both ways of writing the pairs: staging ring (IVX_DENSE=0) and count-scan-write (1),
+    # both partitions (one pass into region pages, "two": histogram + scatter) and the bitmap-filtered routing
     # "routed": rle_right / exists over probe rows routed by coordinate region, gathers from the index (big build sides)
-    for path in ("direct", "regions", "regions-dense", "routed"):
+    for path in ("direct", "regions", "regions-dense", "regions-two", "regions-two-dense", "regions-filter", "regions-filter-dense", "routed"):
         os.environ["IVX_JOIN_PATH"] = path.split("-")[0]
         if path.startswith("regions"):
             os.environ["IVX_DENSE"] = "1" if path.endswith("dense") else "0"
+            if "-two" in path:
+                os.environ["IVX_PART"] = "two"
+        x = ixf if "-filter" in path else ix
         try:
-            assert ctx.overlap_count(ix, pk, ps, pe) == total, path
-            ob, op = ctx.overlap_fill(ix, pk, ps, pe, cap=total)
-            t2, pr2 = ctx.overlap_count(ix, pk, ps, pe, per_row=True)     # rle_right and semi/anti through the same partition
-            ex2 = ctx.exists(ix, pk, ps, pe)
+            assert ctx.overlap_count(x, pk, ps, pe) == total, path
+            ob, op = ctx.overlap_fill(x, pk, ps, pe, cap=total)         # (planned: reuses the count call's routing)
+            ob2, op2 = ctx.overlap_fill(x, pk, ps, pe, cap=total + 7)   # (does its own)
+            t2, pr2 = ctx.overlap_count(x, pk, ps, pe, per_row=True)     # rle_right and semi/anti through the same partition
+            ex2 = ctx.exists(x, pk, ps, pe)
         finally:
             del os.environ["IVX_JOIN_PATH"]
             os.environ.pop("IVX_DENSE", None)
-        assert len(ob) == total, path
+            os.environ.pop("IVX_PART", None)
+        assert len(ob) == total and len(ob2) == total, path
         assert (pair_set(ob, op) == pair_set(want_b, want_p)).all(), path
+        assert (pair_set(ob2, op2) == pair_set(want_b, want_p)).all(), path
         assert t2 == total and (pr2.astype(np.uint64) == want_cnt).all(), path
         assert (ex2 == (want_cnt > 0)).all(), path
     ex = ctx.exists(ix, pk, ps, pe)
     assert (ex == (want_cnt > 0)).all()
-    ix.free()
+    ix.free(); ixf.free()
+
+
+def test_join_sparse_build_side_is_filtered(ctx):
+    """A build side that touches a few percent of the coordinate space gets the occupancy bitmap by itself
+    (the default rule); most probe rows are then dropped before they are routed.  Probe rows that reach over many
+    blocks, lie before / behind every build row of their key, or are inverted go through it too."""
+    rng = np.random.default_rng(77)
+    nk = 6
+    bk, bs, be = synth(3_000, 701, nkeys=nk - 1, mean_len=400, span=200_000_000)         # key 5 has no build rows
+    pk, ps, pe = synth(400_000, 702, nkeys=nk + 1, mean_len=150, span=200_000_000)       # key 6 is unknown to the index
+    pe[::50] = ps[::50] + rng.integers(0, 3_000_000, len(ps[::50])).astype(np.int32)       # long rows (more than 32 bitmap blocks)
+    pe[1::97] = ps[1::97] - rng.integers(1, 5_000, len(ps[1::97])).astype(np.int32)        # inverted rows
+    ps[2::101] = -5_000 + rng.integers(0, 10_000, len(ps[2::101])).astype(np.int32); pe[2::101] = ps[2::101] + 3_000   # around the keys' first starts
+    ps[3::103] = 199_990_000 + rng.integers(0, 20_000, len(ps[3::103])).astype(np.int32); pe[3::103] = ps[3::103] + 700   # around / behind the last
+    # near matches: probes hugging build rows on both sides
+    j = rng.integers(0, len(bs), 60_000)
+    ps[:60_000] = bs[j] + rng.integers(-600, 600, 60_000).astype(np.int32); pe[:60_000] = ps[:60_000] + rng.integers(0, 300, 60_000).astype(np.int32)
+    pk[:60_000] = bk[j]
+    _check_join(ctx, bk, bs, be, pk, ps, pe, nk)
+    os.environ["IVX_JOIN_PATH"] = "regions"
+    try:
+        ix = ctx.build(pyivx.KIND_OVERLAP, bk, bs, be, n_keys=nk)     # default rule
+        want = pair_set(*orc.join(bk, bs, be, pk, ps, pe, threads=4))
+        assert (pair_set(*ctx.overlap_fill(ix, pk, ps, pe)) == want).all()
+        ix.free()
+    finally:
+        del os.environ["IVX_JOIN_PATH"]
 
 
 def test_join_golden_tables(ctx, golden):
