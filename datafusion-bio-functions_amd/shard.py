@@ -24,30 +24,57 @@ def assign_keys_lpt(weights, n_ranks):
     return rank_of
 
 
+def comm_device(dist, device, group=None):
+    """Where tensors must live to go through the process group: the GPU for "nccl" (RCCL), host memory for "gloo"
+    (CPU tests, and rehearsals of several ranks on one GPU, where RCCL refuses two ranks per device)."""
+    import torch
+    return torch.device("cpu") if dist.get_backend(group) == "gloo" else device
+
+
 def allgatherv(dist, tensors, group=None):
-    """All-gather a tuple of equally long 1-D tensors whose length differs per rank
-    (the (build_idx, probe_idx) pair buffers).  Returns the concatenation over ranks
-    in rank order.  One size all-gather + one padded all-gather per tensor."""
+    """All-gather a tuple of equally long 1-D tensors whose length differs per rank (the (build_idx, probe_idx)
+    pair buffers).  Returns (the concatenations over ranks in rank order, the per-rank sizes).
+
+    One small all-gather of the sizes, then every rank's slice travels ONCE to each peer, straight into its place
+    (exact offset, exact length) of the preallocated result: a single group of point-to-point sends / receives
+    (RCCL groups them into one all-gatherv-shaped exchange over xGMI; no padding to the longest rank, no staging
+    copies, no concatenation afterwards)."""
     import torch
     world = dist.get_world_size(group)
-    n = torch.tensor([tensors[0].numel()], dtype=torch.int64, device=tensors[0].device)
-    sizes = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(sizes, n, group=group)
-    sizes = [int(s) for s in sizes]
-    mx = max(max(sizes), 1)
-    outs = []
+    me = dist.get_rank(group)
+    home = tensors[0].device
+    dev = comm_device(dist, home, group)
+    tensors = [t.to(dev) for t in tensors]
+    n = torch.tensor([tensors[0].numel()], dtype=torch.int64, device=dev)
+    all_n = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(all_n, n, group=group)
+    sizes = [int(x) for x in all_n.tolist()]
+    offs = [0]
+    for x in sizes:
+        offs.append(offs[-1] + x)
+    outs, ops = [], []
     for t in tensors:
-        pad = torch.zeros(mx, dtype=t.dtype, device=t.device)
-        pad[: t.numel()] = t
-        parts = [torch.empty_like(pad) for _ in range(world)]
-        dist.all_gather(parts, pad, group=group)
-        outs.append(torch.cat([p[:s] for p, s in zip(parts, sizes)]))
-    return tuple(outs), sizes
+        t = t.contiguous()
+        out = torch.empty(offs[-1], dtype=t.dtype, device=dev)
+        out[offs[me]:offs[me + 1]] = t
+        for r in range(world):
+            if r == me:
+                continue
+            peer = dist.get_global_rank(group, r) if group is not None else r
+            if sizes[me]:
+                ops.append(dist.P2POp(dist.isend, t, peer, group))
+            if sizes[r]:
+                ops.append(dist.P2POp(dist.irecv, out[offs[r]:offs[r + 1]], peer, group))
+        outs.append(out)
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return tuple(o.to(home) for o in outs), sizes
 
 
 def max_over_ranks(dist, seconds, device):
     import torch
-    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    t = torch.tensor([seconds], dtype=torch.float64, device=comm_device(dist, device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t[0])
 
@@ -60,6 +87,7 @@ def cluster_key_base(dist, key_clusters, group=None):
     scan over keys in id order (= contig names in byte order) is the id of each key's
     first cluster, identical on all ranks -- the key_base argument of ivx_cluster."""
     import torch
-    tot = key_clusters.clone().to(torch.int64)
+    tot = key_clusters.clone().to(torch.int64).to(comm_device(dist, key_clusters.device, group))
     dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
+    tot = tot.to(key_clusters.device)
     return torch.cumsum(tot, 0) - tot

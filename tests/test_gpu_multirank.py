@@ -1,0 +1,38 @@
+"""-m gpu: the N > 1 path on real HIP compute.  Two ranks share the box's one GPU (RCCL refuses two ranks per device, so
+the process group is gloo and tensors cross it through host memory; the sharding, the per-rank joins and the exact-size
+all-gatherv are the code an 8-GPU node runs over RCCL).  bench.py --check-union makes rank 0 compare the gathered pair
+set of the strong-scaling job with a single-rank join of the whole job."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(extra):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29700 + os.getpid() % 200), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--one-device",
+           "--backend", "gloo", "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--probe-rows", "20000000"] + extra
+    # a fresh child: the launcher starts before anything touches the GPU
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    return json.loads(line)
+
+
+def test_two_ranks_strong_scaling_union_equals_single_rank_join():
+    out = _run(["--scaling", "strong", "--check-union"])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["gather"] is True
+    assert out["union_check"] == "gathered pair set == single-rank join"
+
+
+def test_two_ranks_weak_scaling_line_and_strong_extra():
+    out = _run(["--scaling", "weak"])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["strong"]["value"] > 0 and out["strong"]["gather"] is True
