@@ -180,9 +180,13 @@ class Session:
         names = [f"l.{n}" for n in build.schema.names] + [f"r.{n}" for n in probe.schema.names]
         return pa.table(cols, names=names)
 
-    def join_stream(self, build, cols_build=DEFAULT_COLS, cols_probe=DEFAULT_COLS, strict_predicate=False, coalesce_rows=0):
-        """IntervalJoinStream as a push interface: index `build` once, then push probe batches; see JoinStream."""
-        return JoinStream(self, build, cols_build, cols_probe, strict_predicate, coalesce_rows)
+    def join_stream(self, build, cols_build=DEFAULT_COLS, cols_probe=DEFAULT_COLS, strict_predicate=False, coalesce_rows=0,
+                    join_type="inner", max_output_rows=0):
+        """IntervalJoinStream as a push interface: index `build` once, then push probe batches; see JoinStream.
+        join_type: "inner" | "right_semi" | "right_anti" | "nearest" (Algorithm::CoitreesNearest);
+        max_output_rows: 0 = one result per group, N = the low-memory stream's output budget, "env" = the reference's
+        default (BIO_MAX_OUTPUT_BATCH_SIZE or 100000)."""
+        return JoinStream(self, build, cols_build, cols_probe, strict_predicate, coalesce_rows, join_type, max_output_rows)
 
     # ---- overlap UDTF (overlap.rs:154-226): FROM right AS b, left AS a  => the user's RIGHT table is the build side
     def overlap(self, left, right, mode="join", cols_left=DEFAULT_COLS, cols_right=DEFAULT_COLS, strict=False):
@@ -290,26 +294,31 @@ class Session:
 class JoinStream:
     """brh_join_stream: the build side indexed once, probe RecordBatches pushed one by one and coalesced into
     groups before they go to the GPU.  push()/finish() return the results that became ready, each a dict
-    first_batch, n_batches, build_idx, probe_idx (rows counted over the group's concatenated batches), batch_offsets."""
+    first_batch, n_batches, group_done, build_idx, probe_idx (rows counted over the group's concatenated batches),
+    batch_offsets."""
 
-    def __init__(self, session, build, cols_build, cols_probe, strict_predicate, coalesce_rows):
+    JOIN_TYPES = {"inner": 0, "right_semi": 1, "right_anti": 2, "nearest": 3}
+
+    def __init__(self, session, build, cols_build, cols_probe, strict_predicate, coalesce_rows, join_type="inner", max_output_rows=0):
         self.session = session
+        budget = (1 << 64) - 1 if max_output_rows == "env" else int(max_output_rows)
         self.h = C.c_void_p()
         B = _Exported(build)
         try:
             session._chk(lib().brh_join_stream_open(session.h, B.c, _cols(cols_build), _cols(cols_probe), C.c_int(int(strict_predicate)),
-                                                    C.c_uint64(int(coalesce_rows)), C.byref(self.h)))
+                                                    C.c_uint64(int(coalesce_rows)), C.c_int(self.JOIN_TYPES[join_type]), C.c_uint64(budget),
+                                                    C.byref(self.h)))
         finally:
             B.close()
 
     def _drain(self, n):
         out = []
         for _ in range(n):
-            first, nb = C.c_uint64(0), C.c_uint64(0)
+            first, nb, done = C.c_uint64(0), C.c_uint64(0), C.c_int(0)
             (ba, bs), (pa_, ps), (oa, os_) = _out(), _out(), _out()
-            self.session._chk(lib().brh_join_stream_next(self.h, C.byref(first), C.byref(nb), C.byref(ba), C.byref(bs),
+            self.session._chk(lib().brh_join_stream_next(self.h, C.byref(first), C.byref(nb), C.byref(done), C.byref(ba), C.byref(bs),
                                                          C.byref(pa_), C.byref(ps), C.byref(oa), C.byref(os_)))
-            out.append({"first_batch": first.value, "n_batches": nb.value, "build_idx": _import(ba, bs),
+            out.append({"first_batch": first.value, "n_batches": nb.value, "group_done": bool(done.value), "build_idx": _import(ba, bs),
                         "probe_idx": _import(pa_, ps), "batch_offsets": _import(oa, os_)})
         return out
 

@@ -689,29 +689,96 @@ struct brh_join_stream {
     // the open group
     std::vector<uint32_t> gk; std::vector<int32_t> gs, ge; std::vector<int64_t> goff;
     uint64_t first_batch = 0, n_pushed = 0;
-    struct Result { uint64_t first_batch, n_batches; std::vector<uint32_t> bi, pi; std::vector<int64_t> off; };
+    int join_type = BRH_JOIN_INNER;                                 // BRH_JOIN_* or BRH_JOIN_NEAREST (Algorithm::CoitreesNearest)
+    uint64_t max_rows = 0;                                          // output rows per result (0 = a group's rows in one result)
+    struct Result { uint64_t first_batch, n_batches; std::vector<uint32_t> bi, pi; std::vector<uint8_t> bvalid; std::vector<int64_t> off; bool last; };
     std::deque<Result> ready;
     ~brh_join_stream() { if (ix) ivx_index_free(ix); }
 };
 
 namespace {
 
+// One group of coalesced probe batches -> one result, or -- with an output budget (the reference's low-memory
+// stream, interval_join.rs:1153-1299; BIO_MAX_OUTPUT_BATCH_SIZE, :543-548) -- several: a result holds whole probe rows
+// and ends after the row at which its running output-row count reaches the budget (:1199-1216, :1256-1273), so it
+// stays below budget + the matches of its last row.  probe_idx always counts over the group's concatenated rows.
 int stream_flush(brh_join_stream *js)
 {
     brh_session *s = js->s;
     if (js->goff.empty()) return 0;
-    brh_join_stream::Result r;
-    r.first_batch = js->first_batch; r.n_batches = js->goff.size();
-    r.off = js->goff; r.off.push_back((int64_t)js->gs.size());
     const uint64_t np = js->gs.size();
-    uint64_t total = 0, written = 0;
-    ivx_status st = ivx_probe_overlap_count(s->ctx, js->ix, IVX_MEM_HOST, js->gk.data(), js->gs.data(), js->ge.data(), np, nullptr, &total);
-    if (st != IVX_OK) return fail_ivx(s, st);
-    r.bi.resize(total ? total : 1); r.pi.resize(total ? total : 1);
-    st = ivx_probe_overlap_fill(s->ctx, js->ix, IVX_MEM_HOST, js->gk.data(), js->gs.data(), js->ge.data(), np, r.bi.data(), r.pi.data(), total, &written);
-    if (st != IVX_OK) return fail_ivx(s, st);
-    r.bi.resize(written); r.pi.resize(written);
-    js->ready.push_back(std::move(r));
+    std::vector<int64_t> off = js->goff; off.push_back((int64_t)np);
+    const uint64_t first = js->first_batch, nb = js->goff.size();
+    auto emit = [&](std::vector<uint32_t> &&bi, std::vector<uint32_t> &&pi, std::vector<uint8_t> &&bv, bool last) {
+        brh_join_stream::Result r;
+        r.first_batch = first; r.n_batches = nb; r.off = off; r.last = last;
+        r.bi = std::move(bi); r.pi = std::move(pi); r.bvalid = std::move(bv);
+        js->ready.push_back(std::move(r));
+    };
+    const uint32_t *gk = js->gk.data(); const int32_t *gs = js->gs.data(), *ge = js->ge.data();
+    ivx_status st;
+    if (js->join_type == BRH_JOIN_RIGHT_SEMI || js->join_type == BRH_JOIN_RIGHT_ANTI) {          // :1014-1024, :1167-1202, :1433-1447
+        std::vector<uint8_t> ex(np ? np : 1);
+        st = ivx_probe_exists(s->ctx, js->ix, IVX_MEM_HOST, gk, gs, ge, np, ex.data());
+        if (st != IVX_OK) return fail_ivx(s, st);
+        const bool want = js->join_type == BRH_JOIN_RIGHT_SEMI;
+        std::vector<uint32_t> pi;
+        for (uint64_t i = 0; i < np; i++) {
+            if ((ex[i] != 0) == want) pi.push_back((uint32_t)i);
+            if (js->max_rows && pi.size() >= js->max_rows && i + 1 < np) { emit({}, std::move(pi), {}, false); pi.clear(); }
+        }
+        emit({}, std::move(pi), {}, true);
+    } else if (js->join_type == BRH_JOIN_NEAREST) {                                              // :864-870, :1226-1238: one row per probe row
+        std::vector<uint32_t> bi(np ? np : 1), pi(np ? np : 1);
+        uint64_t rows = 0;
+        st = ivx_probe_nearest(s->ctx, js->ix, IVX_MEM_HOST, gk, gs, ge, np, 0, 1, 1, bi.data(), pi.data(), nullptr, np, &rows);
+        if (st != IVX_OK) return fail_ivx(s, st);
+        const uint64_t step = js->max_rows ? js->max_rows : (rows ? rows : 1);
+        for (uint64_t a = 0; a < rows || a == 0; a += step) {
+            const uint64_t b = std::min(rows, a + step);
+            std::vector<uint32_t> sb(bi.begin() + a, bi.begin() + b), sp(pi.begin() + a, pi.begin() + b);
+            std::vector<uint8_t> bv(b - a);
+            for (uint64_t i = 0; i < b - a; i++) { bv[i] = sb[i] != IVX_NULL_IDX; if (!bv[i]) sb[i] = 0; }   // NULL build row (u32::MAX marker, :1233)
+            emit(std::move(sb), std::move(sp), std::move(bv), b >= rows);
+            if (b >= rows) break;
+        }
+    } else if (!js->max_rows) {
+        uint64_t total = 0, written = 0;
+        st = ivx_probe_overlap_count(s->ctx, js->ix, IVX_MEM_HOST, gk, gs, ge, np, nullptr, &total);
+        if (st != IVX_OK) return fail_ivx(s, st);
+        std::vector<uint32_t> bi(total ? total : 1), pi(total ? total : 1);
+        st = ivx_probe_overlap_fill(s->ctx, js->ix, IVX_MEM_HOST, gk, gs, ge, np, bi.data(), pi.data(), total, &written);
+        if (st != IVX_OK) return fail_ivx(s, st);
+        bi.resize(written); pi.resize(written);
+        emit(std::move(bi), std::move(pi), {}, true);
+    } else {
+        // rle_right of the whole group first (ONE device call), then the pairs slice by slice of probe rows
+        std::vector<uint32_t> rle(np ? np : 1);
+        uint64_t total = 0;
+        st = ivx_probe_overlap_count(s->ctx, js->ix, IVX_MEM_HOST, gk, gs, ge, np, rle.data(), &total);
+        if (st != IVX_OK) return fail_ivx(s, st);
+        uint64_t r0 = 0;
+        while (r0 < np || r0 == 0) {
+            uint64_t r1 = r0, sum = 0;
+            while (r1 < np && sum < js->max_rows) sum += rle[r1++];       // ends after the row that reaches the budget
+            if (total - sum == 0 || r1 >= np) {                            // nothing but matchless rows behind it: this is the last result
+                for (; r1 < np; r1++) sum += rle[r1];
+            }
+            std::vector<uint32_t> bi(sum ? sum : 1), pi(sum ? sum : 1);
+            uint64_t written = 0;
+            if (sum) {
+                st = ivx_probe_overlap_fill(s->ctx, js->ix, IVX_MEM_HOST, gk + r0, gs + r0, ge + r0, r1 - r0, bi.data(), pi.data(), sum, &written);
+                if (st != IVX_OK) return fail_ivx(s, st);
+                if (written != sum) return fail(s, "join stream: a slice's pair count changed between the count and the fill call");
+                for (uint64_t i = 0; i < written; i++) pi[i] += (uint32_t)r0;
+            }
+            bi.resize(written); pi.resize(written);
+            total -= sum;
+            emit(std::move(bi), std::move(pi), {}, r1 >= np);
+            r0 = r1;
+            if (r0 >= np) break;
+        }
+    }
     js->first_batch = js->n_pushed;
     js->gk.clear(); js->gs.clear(); js->ge.clear(); js->goff.clear();
     return 0;
@@ -720,23 +787,32 @@ int stream_flush(brh_join_stream *js)
 }  // namespace
 
 extern "C" int brh_join_stream_open(brh_session *s, brh_batch build, brh_columns bcols, brh_columns pcols, int strict_predicate,
-                                    uint64_t coalesce_rows, brh_join_stream **out)
+                                    uint64_t coalesce_rows, int join_type, uint64_t max_output_rows, brh_join_stream **out)
 {
     if (!s || !out) return 1;
     *out = nullptr;
+    if (join_type < BRH_JOIN_INNER || join_type > BRH_JOIN_NEAREST) return fail(s, "join stream: unsupported join type");
+    if (max_output_rows == BRH_MAX_OUTPUT_ENV) {                  // the reference's low-memory default (interval_join.rs:543-548)
+        const char *e = std::getenv("BIO_MAX_OUTPUT_BATCH_SIZE");
+        char *end = nullptr;
+        const unsigned long long v = e ? std::strtoull(e, &end, 10) : 0;
+        max_output_rows = (e && end != e && *end == 0 && v > 0) ? v : 100000;
+    }
     if (pcols.n_keys != bcols.n_keys || pcols.n_keys < 1) return fail(s, "both sides need the same number (>= 1) of key columns");
     KeyDict kd; Side32 B;
     if (build_keys(s, {{build, bcols}}, &kd) || load_side32(s, build, bcols, &B)) return 1;
     if (strict_predicate) for (auto &v : B.e) v = (int32_t)((uint32_t)v - 1u);          // intervals.rs:85-115
     std::unique_ptr<brh_join_stream> js(new brh_join_stream());
     js->s = s; js->strict = strict_predicate != 0;
+    js->join_type = join_type; js->max_rows = max_output_rows;
     js->coalesce_rows = coalesce_rows ? coalesce_rows : (4u << 20);
     js->nk = (uint32_t)kd.names.size();
     for (uint32_t i = 0; i < js->nk; i++) js->dict.emplace(kd.names[i], i);
     for (int k = 0; k < pcols.n_keys; k++) js->pkeys.emplace_back(pcols.keys[k]);
     js->pstart = pcols.start; js->pend = pcols.end;
     // one key id more than the build side has: "contig the build side does not know", never matches
-    ivx_status st = ivx_index_build(s->ctx, IVX_KIND_OVERLAP, IVX_MEM_HOST, kd.ids[0].data(), B.s.data(), B.e.data(), B.s.size(), js->nk + 1, &js->ix);
+    ivx_status st = ivx_index_build(s->ctx, join_type == BRH_JOIN_NEAREST ? IVX_KIND_NEAREST : IVX_KIND_OVERLAP, IVX_MEM_HOST, kd.ids[0].data(),
+                                    B.s.data(), B.e.data(), B.s.size(), js->nk + 1, &js->ix);
     if (st != IVX_OK) return fail_ivx(s, st);
     *out = js.release();
     return 0;
@@ -807,7 +883,7 @@ extern "C" int brh_join_stream_finish(brh_join_stream *js, int *n_ready)
     return 0;
 }
 
-extern "C" int brh_join_stream_next(brh_join_stream *js, uint64_t *first_batch, uint64_t *n_batches,
+extern "C" int brh_join_stream_next(brh_join_stream *js, uint64_t *first_batch, uint64_t *n_batches, int *group_done,
                                     ArrowArray *build_idx, ArrowSchema *build_idx_schema, ArrowArray *probe_idx, ArrowSchema *probe_idx_schema,
                                     ArrowArray *batch_offsets, ArrowSchema *batch_offsets_schema)
 {
@@ -816,7 +892,9 @@ extern "C" int brh_join_stream_next(brh_join_stream *js, uint64_t *first_batch, 
     brh_join_stream::Result &r = js->ready.front();
     if (first_batch) *first_batch = r.first_batch;
     if (n_batches) *n_batches = r.n_batches;
-    make_primitive<uint32_t>(build_idx, r.bi.data(), (int64_t)r.bi.size(), nullptr); make_schema(build_idx_schema, "I", "build_idx", false);
+    if (group_done) *group_done = r.last ? 1 : 0;
+    const bool nullable = js->join_type == BRH_JOIN_NEAREST;
+    make_primitive<uint32_t>(build_idx, r.bi.data(), (int64_t)r.bi.size(), nullable ? r.bvalid.data() : nullptr); make_schema(build_idx_schema, "I", "build_idx", nullable);
     make_primitive<uint32_t>(probe_idx, r.pi.data(), (int64_t)r.pi.size(), nullptr); make_schema(probe_idx_schema, "I", "probe_idx", false);
     make_primitive<int64_t>(batch_offsets, r.off.data(), (int64_t)r.off.size(), nullptr); make_schema(batch_offsets_schema, "l", "batch_offsets", false);
     js->ready.pop_front();

@@ -57,7 +57,9 @@ const char *brh_last_error(const brh_session *s);
 /* FilterOp (R/src/filter_op.rs:4-10) */
 enum { BRH_WEAK = 0, BRH_STRICT = 1 };
 /* JoinType subset with real semantics in IntervalJoinExec (interval_join.rs:1014-1024) */
-enum { BRH_JOIN_INNER = 0, BRH_JOIN_RIGHT_SEMI = 1, BRH_JOIN_RIGHT_ANTI = 2 };
+enum { BRH_JOIN_INNER = 0, BRH_JOIN_RIGHT_SEMI = 1, BRH_JOIN_RIGHT_ANTI = 2,
+       BRH_JOIN_NEAREST = 3 /* join stream only: Inner with Algorithm::CoitreesNearest (interval_join.rs:864-870) */ };
+#define BRH_MAX_OUTPUT_ENV UINT64_MAX   /* join stream: take the output budget from BIO_MAX_OUTPUT_BATCH_SIZE (default 100000) */
 
 /* count_overlaps('left','right') / coverage(...): CountOverlapsProvider (R/src/count_overlaps.rs:107-169),
  * get_count_stream / get_stream (interval_tree.rs:155-280).  `left` is indexed, `right` streamed;
@@ -134,21 +136,30 @@ int brh_take(brh_session *s, const struct ArrowArray *column, const struct Arrow
              const struct ArrowArray *idx, const struct ArrowSchema *idx_schema,
              struct ArrowArray *out, struct ArrowSchema *out_schema);
 
-/* IntervalJoinStream as a push interface (interval_join.rs:934-1140, :1418-1677), Inner join.  open indexes the
- * build side once (collect_left_input, :584-700); push takes one probe RecordBatch (FetchProbeBatch /
- * ProcessProbeBatch).  Probe batches are coalesced into groups of at least `coalesce_rows` rows (0 = 4 Mi) before
- * they go to the GPU -- the job of CoalesceBatchesExec in a DataFusion plan: a device call per 8192-row batch would
- * be all launch latency.  Every group gives ONE result (next): build_idx / probe_idx UInt32 pairs, probe_idx
- * counted over the group's concatenated rows, plus batch_offsets Int64 [n_batches + 1] = the first row of each of
- * the group's batches, so the caller can concatenate its buffered batches (or split the pairs) and `take` the
- * payload columns as the reference does (:1655-1667).  *n_ready = results waiting in the queue.  Probe rows whose
- * key the build side does not have never match.  finish flushes the last, partial group. */
+/* IntervalJoinStream as a push interface (interval_join.rs:934-1140, :1418-1677).  open indexes the build side once
+ * (collect_left_input, :584-700); push takes one probe RecordBatch (FetchProbeBatch / ProcessProbeBatch).  Probe
+ * batches are coalesced into groups of at least `coalesce_rows` rows (0 = 4 Mi) before they go to the GPU -- the job
+ * of CoalesceBatchesExec in a DataFusion plan: a device call per 8192-row batch would be all launch latency.
+ * join_type:
+ *   BRH_JOIN_INNER       (build_idx, probe_idx) pairs (:1614-1653)
+ *   BRH_JOIN_RIGHT_SEMI / _ANTI   probe_idx only: the probe rows with / without a match, ascending (:1014-1024, :1433-1463)
+ *   BRH_JOIN_NEAREST     Algorithm::CoitreesNearest: one row per probe row, build_idx NULL where the key has no build row
+ *                        (:864-870, :1226-1238, :1628-1635)
+ * max_output_rows: 0 = every group gives ONE result (the regular mode).  > 0 = the reference's low-memory stream
+ *   (:1153-1299): a result holds whole probe rows and ends after the row at which its running output-row count
+ *   reaches the budget (:1199-1216, :1256-1273), so it stays below budget + the matches of its last row;
+ *   BRH_MAX_OUTPUT_ENV = the reference's default, BIO_MAX_OUTPUT_BATCH_SIZE or 100000 (:543-548).
+ * next: probe_idx counts over the group's concatenated rows; batch_offsets Int64 [n_batches + 1] = the first row of
+ * each of the group's batches, so the caller can concatenate its buffered batches (or split the pairs) and `take`
+ * the payload columns as the reference does (:1655-1667); *group_done = 1 with the group's last result (the
+ * caller may drop the group's buffered batches).  *n_ready = results waiting in the queue.  Probe rows whose key
+ * the build side does not have never match.  finish flushes the last, partial group. */
 typedef struct brh_join_stream brh_join_stream;
 int  brh_join_stream_open(brh_session *s, brh_batch build, brh_columns bcols, brh_columns pcols, int strict_predicate,
-                          uint64_t coalesce_rows, brh_join_stream **out);
+                          uint64_t coalesce_rows, int join_type, uint64_t max_output_rows, brh_join_stream **out);
 int  brh_join_stream_push(brh_join_stream *js, brh_batch probe, int *n_ready);
 int  brh_join_stream_finish(brh_join_stream *js, int *n_ready);
-int  brh_join_stream_next(brh_join_stream *js, uint64_t *first_batch, uint64_t *n_batches,
+int  brh_join_stream_next(brh_join_stream *js, uint64_t *first_batch, uint64_t *n_batches, int *group_done,
                           struct ArrowArray *build_idx, struct ArrowSchema *build_idx_schema,
                           struct ArrowArray *probe_idx, struct ArrowSchema *probe_idx_schema,
                           struct ArrowArray *batch_offsets, struct ArrowSchema *batch_offsets_schema);

@@ -24,10 +24,10 @@ extern "C" {
     pub fn brh_session_free(s: *mut BrhSession);
     pub fn brh_last_error(s: *const BrhSession) -> *const c_char;
     pub fn brh_join_stream_open(s: *mut BrhSession, build: BrhBatch, bcols: BrhColumns, pcols: BrhColumns, strict_predicate: c_int,
-                                coalesce_rows: u64, out: *mut *mut BrhJoinStream) -> c_int;
+                                coalesce_rows: u64, join_type: c_int, max_output_rows: u64, out: *mut *mut BrhJoinStream) -> c_int;
     pub fn brh_join_stream_push(js: *mut BrhJoinStream, probe: BrhBatch, n_ready: *mut c_int) -> c_int;
     pub fn brh_join_stream_finish(js: *mut BrhJoinStream, n_ready: *mut c_int) -> c_int;
-    pub fn brh_join_stream_next(js: *mut BrhJoinStream, first_batch: *mut u64, n_batches: *mut u64,
+    pub fn brh_join_stream_next(js: *mut BrhJoinStream, first_batch: *mut u64, n_batches: *mut u64, group_done: *mut c_int,
                                 build_idx: *mut FFI_ArrowArray, build_idx_schema: *mut FFI_ArrowSchema,
                                 probe_idx: *mut FFI_ArrowArray, probe_idx_schema: *mut FFI_ArrowSchema,
                                 batch_offsets: *mut FFI_ArrowArray, batch_offsets_schema: *mut FFI_ArrowSchema) -> c_int;
@@ -67,16 +67,17 @@ impl HipJoinStream {
     }
 
     fn next(&mut self) -> Result<(UInt32Array, UInt32Array, RecordBatch)> {
-        let (mut first, mut nb) = (0u64, 0u64);
+        let (mut first, mut nb, mut done) = (0u64, 0u64, 0 as c_int);
         let (mut ba, mut bs) = (FFI_ArrowArray::empty(), FFI_ArrowSchema::empty());
         let (mut pa, mut ps) = (FFI_ArrowArray::empty(), FFI_ArrowSchema::empty());
         let (mut oa, mut os) = (FFI_ArrowArray::empty(), FFI_ArrowSchema::empty());
-        self.check(unsafe { brh_join_stream_next(self.js, &mut first, &mut nb, &mut ba, &mut bs, &mut pa, &mut ps, &mut oa, &mut os) })?;
+        self.check(unsafe { brh_join_stream_next(self.js, &mut first, &mut nb, &mut done, &mut ba, &mut bs, &mut pa, &mut ps, &mut oa, &mut os) })?;
         let build_idx = UInt32Array::from(unsafe { from_ffi(ba, &bs) }?);
         let probe_idx = UInt32Array::from(unsafe { from_ffi(pa, &ps) }?);
         let _offsets = Int64Array::from(unsafe { from_ffi(oa, &os) }?);   // first row of every batch in the group
-        // the group's batches in push order = the rows probe_idx counts over
-        let group: Vec<RecordBatch> = self.pending.drain(..nb as usize).collect();
+        // the group's batches in push order = the rows probe_idx counts over.  A bounded-output stream
+        // (max_output_rows > 0, the low-memory mode) returns several results per group: the batches go with the last one
+        let group: Vec<RecordBatch> = if done != 0 { self.pending.drain(..nb as usize).collect() } else { self.pending[..nb as usize].to_vec() };
         let probe = concat_batches(&group[0].schema(), &group)?;
         Ok((build_idx, probe_idx, probe))
         // caller: build_batch_from_indices(schema, build_side, &probe, &build_idx, &probe_idx, ..)  (interval_join.rs:1655-1667)

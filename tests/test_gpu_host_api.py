@@ -279,23 +279,32 @@ def test_overlap_udtf_custom_columns(ctx):
     assert out.num_rows == 1 and out.schema.names[0] == "left_chr" and out.schema.names[3] == "right_chr"
 
 
-def _stream_pairs(js, batches):
-    """push the batches, finish, and return the pairs as (build_idx, global probe row) + the number of results"""
-    import numpy as np
-    starts = np.cumsum([0] + [b.num_rows for b in batches])
+def _stream_results(js, batches):
     results = []
     for b in batches:
         results += js.push(b)
     results += js.finish()
+    return results
+
+
+def _stream_pairs(js, batches, results=None, nullable_build=False):
+    """push the batches, finish, and return the pairs as (build_idx, global probe row) + the number of results"""
+    import numpy as np
+    starts = np.cumsum([0] + [b.num_rows for b in batches])
+    if results is None:
+        results = _stream_results(js, batches)
     bi, pi, seen = [], [], 0
     for r in results:
         assert r["first_batch"] == seen                          # results come in push order, every batch in exactly one group
         off = r["batch_offsets"].to_numpy()
         assert len(off) == r["n_batches"] + 1 and off[0] == 0
         assert (np.diff(off) == [batches[seen + j].num_rows for j in range(r["n_batches"])]).all()
-        bi.append(r["build_idx"].to_numpy()); pi.append(r["probe_idx"].to_numpy().astype(np.int64) + starts[seen])
-        seen += r["n_batches"]
-    assert seen == len(batches)
+        b = r["build_idx"]
+        bi.append(b.fill_null(0xFFFFFFFF).to_numpy() if nullable_build else b.to_numpy())
+        pi.append(r["probe_idx"].to_numpy().astype(np.int64) + starts[seen])
+        if r["group_done"]:                                      # a bounded-output stream gives several results per group
+            seen += r["n_batches"]
+    assert seen == len(batches) and (not results or results[-1]["group_done"])
     return (np.concatenate(bi) if bi else np.empty(0, np.uint32)), (np.concatenate(pi) if pi else np.empty(0, np.int64)), len(results)
 
 
@@ -335,6 +344,96 @@ def test_join_stream_matches_one_shot_join(ctx, strict):
         js.close()
         got = np.sort((bi.astype(np.uint64) << np.uint64(32)) | pi.astype(np.uint64))
         assert len(got) == len(want) and (got == want).all(), coalesce
+
+
+def _rand_tables(seed, n_build, n_probe, build_keys=4, probe_keys=5, bmean=800, pmean=150, span=3_000_000):
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    names = np.array(["chr1", "chr10", "chr2", "chrX", "scaffold_77"])
+
+    def tab(n, keys, mean):
+        s = rng.integers(0, span, n)
+        return pa.table({"contig": pa.array(names[rng.integers(0, keys, n)]), "pos_start": pa.array(s, pa.int64()),
+                         "pos_end": pa.array(s + rng.integers(1, 2 * mean, n), pa.int64())})
+    return tab(n_build, build_keys, bmean), tab(n_probe, probe_keys, pmean)
+
+
+@pytest.mark.parametrize("join_type", ["right_semi", "right_anti", "nearest"])
+def test_join_stream_semi_anti_nearest_match_the_one_shot_join(ctx, join_type):
+    """RightSemi / RightAnti (interval_join.rs:1014-1024, :1433-1463) and Algorithm::CoitreesNearest (:864-870, NULL build
+    rows for keys the build side lacks) through the push interface == the one-shot operator on the concatenated probe side."""
+    import numpy as np
+    build, probe = _rand_tables(11, 30_000, 700_000)
+    cuts = [0, 3, 8_195, 8_195, 300_000, 700_000]
+    batches = [probe.slice(a, b - a) for a, b in zip(cuts[:-1], cuts[1:])]
+    if join_type == "nearest":
+        wb, wp = ctx.interval_join(build, probe, nearest_algorithm=True)
+        want_b, want_p = wb.fill_null(0xFFFFFFFF).to_numpy(), wp.to_numpy().astype(np.int64)
+        assert (want_b == 0xFFFFFFFF).any()                          # "scaffold_77" rows have no build side
+    else:
+        _, wp = ctx.interval_join(build, probe, join_type=br.JOIN_RIGHT_SEMI if join_type == "right_semi" else br.JOIN_RIGHT_ANTI)
+        want_p = wp.to_numpy().astype(np.int64)
+    for coalesce, budget in ((100_000, 0), (0, 0), (250_000, 70_000)):
+        js = ctx.join_stream(build, coalesce_rows=coalesce, join_type=join_type, max_output_rows=budget)
+        results = _stream_results(js, batches)
+        js.close()
+        bi, pi, nres = _stream_pairs(None, batches, results, nullable_build=join_type == "nearest")
+        assert (pi == want_p).all()                                  # probe rows ascending, exactly the operator's
+        if join_type == "nearest":
+            assert (bi == want_b).all()
+        else:
+            assert all(len(r["build_idx"]) == 0 for r in results)
+        if budget:
+            assert all(len(r["probe_idx"]) <= budget for r in results) and nres > 3
+
+
+def test_join_stream_bounded_output_on_a_deep_pile_up(ctx):
+    """The low-memory stream (interval_join.rs:1153-1299): a result holds whole probe rows and ends after the row at which
+    its running pair count reaches the budget.  One hot region: every probe row there matches thousands of build rows."""
+    import numpy as np
+    rng = np.random.default_rng(9)
+    bs = np.concatenate([rng.integers(1_000_000, 1_001_000, 5000), [0]])
+    be = np.concatenate([bs[:-1] + rng.integers(100, 2000, 5000), [200_000_000]])
+    build = pa.table({"contig": pa.array(["chr1"] * len(bs)), "pos_start": pa.array(bs, pa.int64()), "pos_end": pa.array(be, pa.int64())})
+    ps = np.concatenate([rng.integers(999_000, 1_003_000, 3000), rng.integers(5_000_000, 9_000_000, 40_000)])
+    rng.shuffle(ps)
+    probe = pa.table({"contig": pa.array(["chr1"] * len(ps)), "pos_start": pa.array(ps, pa.int64()), "pos_end": pa.array(ps + 150, pa.int64())})
+    batches = [probe.slice(a, 8192) for a in range(0, probe.num_rows, 8192)]
+    wb, wp = ctx.interval_join(build, probe)
+    want = np.sort((wb.to_numpy().astype(np.uint64) << np.uint64(32)) | wp.to_numpy().astype(np.uint64))
+    rle = np.bincount(wp.to_numpy(), minlength=probe.num_rows)      # matches per probe row
+    assert rle.max() > 4000 and len(want) > 4_000_000
+    for budget, coalesce in ((100_000, 20_000), (1_000_000, 0), (7, 9_000)):
+        js = ctx.join_stream(build, coalesce_rows=coalesce, max_output_rows=budget)
+        results = _stream_results(js, batches)
+        js.close()
+        bi, pi, nres = _stream_pairs(None, batches, results)
+        got = np.sort((bi.astype(np.uint64) << np.uint64(32)) | pi.astype(np.uint64))
+        assert len(got) == len(want) and (got == want).all(), budget    # the same pair multiset as the unbounded join
+        starts = np.cumsum([0] + [b.num_rows for b in batches])
+        prev_last = -1
+        for r in results:
+            p = r["probe_idx"].to_numpy().astype(np.int64) + starts[r["first_batch"]]     # (pair order inside a result is free)
+            if len(p) == 0:
+                continue
+            rows, cnt = np.unique(p, return_counts=True)
+            assert (cnt == rle[rows]).all()                             # whole probe rows
+            assert rows[0] > prev_last                                  # results walk the probe rows in order
+            prev_last = rows[-1]
+            assert len(p) < budget + rle[rows[-1]]                     # ends right after the row that reached the budget
+            assert r["group_done"] or len(p) >= budget
+        assert nres >= len(want) // (budget + rle.max())
+
+
+def test_join_stream_budget_from_the_environment(ctx, golden, monkeypatch):
+    # BIO_MAX_OUTPUT_BATCH_SIZE (interval_join.rs:543-548); the 16-pair golden join in results of >= 5 pairs
+    reads, targets = table(golden.tables["reads"]), table(golden.tables["targets"])
+    monkeypatch.setenv("BIO_MAX_OUTPUT_BATCH_SIZE", "5")
+    js = ctx.join_stream(reads, max_output_rows="env")
+    results = _stream_results(js, [targets])
+    js.close()
+    sizes = [len(r["probe_idx"]) for r in results]
+    assert sum(sizes) == 16 and len(sizes) >= 3 and all(5 <= n for n in sizes[:-1])
 
 
 def test_join_stream_errors(ctx, golden):

@@ -438,3 +438,58 @@ def test_two_contexts_in_two_threads():
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_one_index_shared_by_probe_partitions():
+    """CollectLeft (interval_join.rs:466-480; create_bio_session forces it, session_context.rs:141-145): ONE built index,
+    N concurrently polled probe partitions.  The index is built on context A (its own stream); five host threads, each with
+    its own context and stream, probe it at the same time with different probe partitions -- device- and host-resident
+    columns, batches on the gather path and on the region-partitioned path, every operator of the overlap index -- and
+    every result must equal the oracle's."""
+    import threading
+    import torch
+    nk = 6
+    bk, bs, be = synth(150_000, 1201, nkeys=nk, mean_len=900, span=9_000_000)
+    a = pyivx.Ctx(0)
+    ix = a.build(pyivx.KIND_OVERLAP, bk, bs, be, n_keys=nk)
+    ixc = a.build(pyivx.KIND_COUNT, bk, bs, be, n_keys=nk)
+    parts = []
+    for t, n in enumerate([2_400_000, 300_000, 2_200_000, 50_000, 2_600_000]):
+        pk, ps, pe = synth(n, 1210 + t, nkeys=nk + 1, mean_len=150, span=9_000_000)
+        wb, wp, cnt = orc.join(bk, bs, be, pk, ps, pe, per_row=True, threads=4)
+        parts.append(((pk, ps, pe), pair_set(wb, wp), cnt, orc.count_overlaps(bk, bs, be, pk, ps, pe, threads=4)))
+    errors = []
+    start = threading.Barrier(len(parts))
+
+    def run(t, part):
+        try:
+            (pk, ps, pe), want, cnt, ccnt = part
+            c = pyivx.Ctx(0)
+            dev = t % 2 == 0
+            if dev:
+                cols = [torch.from_numpy(x.view(np.int32) if x.dtype == np.uint32 else x).cuda() for x in (pk, ps, pe)]
+                torch.cuda.synchronize()
+            else:
+                cols = [pk, ps, pe]
+            host = (lambda x: (c.synchronize(), x.cpu().numpy())[1]) if dev else (lambda x: x)
+            start.wait()
+            for _ in range(3):
+                total, per_row = c.overlap_count(ix, *cols, per_row=True)
+                assert total == len(want) and (host(per_row).view(np.uint32).astype(np.uint64) == cnt).all()
+                ob, op = c.overlap_fill(ix, *cols, cap=total)
+                assert (pair_set(host(ob).view(np.uint32), host(op).view(np.uint32)) == want).all()
+                assert (host(c.exists(ix, *cols)) == (cnt > 0)).all()
+                assert (host(c.count_overlaps(ixc, *cols)) == ccnt).all()
+            c.synchronize()
+            c.close()
+        except BaseException as e:                                    # noqa: BLE001 -- reported by the main thread
+            errors.append((t, e))
+
+    threads = [threading.Thread(target=run, args=(t, p)) for t, p in enumerate(parts)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    ix.free(); ixc.free()
+    a.close()
