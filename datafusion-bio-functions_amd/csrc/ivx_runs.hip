@@ -67,36 +67,45 @@ __device__ __forceinline__ bool merges(i64 s, i64 cur_end, i64 d, int strict)
     return strict ? (s < boundary) : (s <= boundary);
 }
 
-__global__ __launch_bounds__(RT) void k_states(const u32 *__restrict__ ks, const i64 *__restrict__ ss, const i64 *__restrict__ es,
-                                               u64 n, i64 d, int strict, MState *__restrict__ st)
-{
-    const u64 i = (u64)blockIdx.x * RT + threadIdx.x;
-    if (i >= n) return;
-    const bool first = i == 0 || ks[i] != ks[i - 1];
-    const i64 s = ss[i], e = es[i];
-    MState t; t.pad = 0;
-    if (first || (strict && s == INT64_MAX)) {          // strict: s < anything never holds at i64::MAX
-        t.konst = 1; t.M = 0; t.c = e;
-    } else {
-        // smallest cur_end that still merges row i
-        const i64 T = strict ? sat_sub_floor(s + 1, d) : sat_sub_floor(s, d);
-        t.konst = 0; t.M = T > e ? T : e; t.c = e;
+// element i of the cur_end scan: the transfer function of row i (computed from the sorted columns, never stored)
+struct StateIn {
+    const u32 *ks; const i64 *ss, *es; i64 d; int strict;
+    __device__ MState operator()(u64 i) const
+    {
+        const bool first = i == 0 || ks[i] != ks[i - 1];
+        const i64 s = ss[i], e = es[i];
+        MState t; t.pad = 0;
+        if (first || (strict && s == INT64_MAX)) {          // strict: s < anything never holds at i64::MAX
+            t.konst = 1; t.M = 0; t.c = e;
+        } else {
+            // smallest cur_end that still merges row i
+            const i64 T = strict ? sat_sub_floor(s + 1, d) : sat_sub_floor(s, d);
+            t.konst = 0; t.M = T > e ? T : e; t.c = e;
+        }
+        return t;
     }
-    st[i] = t;
-}
+};
+// after the inclusive scan the state of row i is a constant function: its value is cur_end after row i
+struct CurEndOut {
+    i64 *cur_end;
+    __device__ void operator()(u64 i, const MState &t) const { cur_end[i] = t.c; }
+};
+// element i of the run-head scan: does row i start a run (merge.rs:291-296 against cur_end after row i-1)
+struct HeadIn {
+    const u32 *ks; const i64 *ss, *cur_end; i64 d; int strict;
+    __device__ HeadAcc operator()(u64 i) const
+    {
+        const bool head = i == 0 || ks[i] != ks[i - 1] || !merges(ss[i], cur_end[i - 1], d, strict);
+        HeadAcc h; h.heads = head ? 1u : 0u; h.last_head = head ? (u32)i : 0u;
+        return h;
+    }
+};
+struct HeadOut {
+    HeadAcc *ha;
+    __device__ void operator()(u64 i, const HeadAcc &h) const { ha[i] = h; }
+};
 
-// after the inclusive scan st[i].c is cur_end after row i (always a constant function)
-__global__ __launch_bounds__(RT) void k_heads(const u32 *__restrict__ ks, const i64 *__restrict__ ss, const MState *__restrict__ st,
-                                              u64 n, i64 d, int strict, HeadAcc *__restrict__ ha)
-{
-    const u64 i = (u64)blockIdx.x * RT + threadIdx.x;
-    if (i >= n) return;
-    const bool head = i == 0 || ks[i] != ks[i - 1] || !merges(ss[i], st[i - 1].c, d, strict);
-    HeadAcc h; h.heads = head ? 1u : 0u; h.last_head = head ? (u32)i : 0u;
-    ha[i] = h;
-}
-
-__global__ __launch_bounds__(RT) void k_emit_runs(const u32 *__restrict__ ks, const i64 *__restrict__ ss, const MState *__restrict__ st,
+__global__ __launch_bounds__(RT) void k_emit_runs(const u32 *__restrict__ ks, const i64 *__restrict__ ss, const i64 *__restrict__ cur_end,
                                                   const HeadAcc *__restrict__ ha, u64 n, ivx_runs_out out, u64 *m)
 {
     const u64 i = (u64)blockIdx.x * RT + threadIdx.x;
@@ -107,7 +116,7 @@ __global__ __launch_bounds__(RT) void k_emit_runs(const u32 *__restrict__ ks, co
         const u32 id = h.heads - 1;
         if (out.key) out.key[id] = ks[i];
         if (out.start) out.start[id] = ss[h.last_head];
-        if (out.end) out.end[id] = st[i].c;
+        if (out.end) out.end[id] = cur_end[i];
         if (out.count) out.count[id] = (i64)(i - h.last_head + 1);
     }
     if (i + 1 == n) *m = h.heads;
@@ -115,24 +124,23 @@ __global__ __launch_bounds__(RT) void k_emit_runs(const u32 *__restrict__ ks, co
 
 }  // namespace
 
-// states -> scan -> heads -> scan -> runs; leaves st / ha (n entries each) in WS_T5 / WS_T6
+// cur_end scan -> run-head scan -> runs; both scans compute their elements from the sorted columns on the fly (no
+// state array: 124 instead of 232 bytes of traffic per row); leaves cur_end / ha (n entries each) in WS_T5 / WS_T6
 static ivx_status sweep(ivx_ctx *ctx, const u32 *ks, const i64 *ss, const i64 *es, u64 n,
-                        i64 min_dist, int strict, const ivx_runs_out &out, const MState **st_out, const HeadAcc **ha_out, u64 *m)
+                        i64 min_dist, int strict, const ivx_runs_out &out, const HeadAcc **ha_out, u64 *m)
 {
     hipStream_t stq = ctx->stream;
-    MState *st; HeadAcc *ha;
-    IVX_TRY(ctx->get_scratch(WS_T5, n * sizeof(MState), (void **)&st));
+    i64 *cur_end; HeadAcc *ha;
+    IVX_TRY(ctx->get_scratch(WS_T5, n * sizeof(i64), (void **)&cur_end));
     IVX_TRY(ctx->get_scratch(WS_T6, n * sizeof(HeadAcc), (void **)&ha));
     const u32 grid = (u32)((n + RT - 1) / RT);
-    hipLaunchKernelGGL(k_states, dim3(grid), dim3(RT), 0, stq, ks, ss, es, n, min_dist, strict, st);
-    IVX_TRY(ivxscan::inclusive<MergeOp>(ctx, st, n));
-    hipLaunchKernelGGL(k_heads, dim3(grid), dim3(RT), 0, stq, ks, ss, (const MState *)st, n, min_dist, strict, ha);
-    IVX_TRY(ivxscan::inclusive<HeadOp>(ctx, ha, n));
+    IVX_TRY((ivxscan::inclusive_f<MergeOp>(ctx, StateIn{ks, ss, es, min_dist, strict}, CurEndOut{cur_end}, n)));
+    IVX_TRY((ivxscan::inclusive_f<HeadOp>(ctx, HeadIn{ks, ss, cur_end, min_dist, strict}, HeadOut{ha}, n)));
     u64 *d_m = ctx->d_scalars + 2;
-    hipLaunchKernelGGL(k_emit_runs, dim3(grid), dim3(RT), 0, stq, ks, ss, (const MState *)st, (const HeadAcc *)ha, n, out, d_m);
+    hipLaunchKernelGGL(k_emit_runs, dim3(grid), dim3(RT), 0, stq, ks, ss, (const i64 *)cur_end, (const HeadAcc *)ha, n, out, d_m);
     IVX_HIP(ctx, hipGetLastError());
     IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 2, d_m, sizeof(u64), hipMemcpyDeviceToHost, stq));
-    *st_out = st; *ha_out = ha;
+    *ha_out = ha;
     (void)m;
     return IVX_OK;
 }
@@ -142,8 +150,8 @@ ivx_status ivx_merge_runs(ivx_ctx *ctx, const u32 *ks, const i64 *ss, const i64 
 {
     *m = 0;
     if (n == 0) return IVX_OK;
-    const MState *st; const HeadAcc *ha;
-    IVX_TRY(sweep(ctx, ks, ss, es, n, min_dist, strict, out, &st, &ha, m));
+    const HeadAcc *ha;
+    IVX_TRY(sweep(ctx, ks, ss, es, n, min_dist, strict, out, &ha, m));
     IVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *m = ctx->h_scalars[2];
     return IVX_OK;
@@ -200,9 +208,9 @@ ivx_status ivx_cluster_rows(ivx_ctx *ctx, const u32 *ks, const i64 *ss, const i6
     if (n) {
         i64 *run_end;
         IVX_TRY(ctx->get_scratch(WS_T7, n * sizeof(i64), (void **)&run_end));
-        const MState *st; const HeadAcc *ha;
+        const HeadAcc *ha;
         const ivx_runs_out ro{nullptr, nullptr, run_end, nullptr};
-        IVX_TRY(sweep(ctx, ks, ss, es, n, min_dist, strict, ro, &st, &ha, m));
+        IVX_TRY(sweep(ctx, ks, ss, es, n, min_dist, strict, ro, &ha, m));
         const u32 grid = (u32)((n + RT - 1) / RT);
         hipLaunchKernelGGL(k_key_runs, dim3(grid), dim3(RT), 0, stq, ks, ha, n, nkeys, kfirst, klast);
         hipLaunchKernelGGL(k_cluster_rows, dim3(grid), dim3(RT), 0, stq, ks, ss, ha, (const i64 *)run_end, n, nkeys,

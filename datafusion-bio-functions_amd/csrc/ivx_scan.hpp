@@ -147,6 +147,65 @@ ivx_status scan_rec(ivx_ctx *ctx, typename Op::T *data, u64 n, int level, int sl
     return IVX_OK;
 }
 
+// ---- the same scans over elements that are COMPUTED, not stored: `in(i)` yields element i (from whatever columns it is
+// a function of) and `out(i, v)` takes the scanned value (and stores only what later passes need) -- no materialised
+// element array, which for a 24-byte state is most of the traffic of the scan
+template <class Op, class In>
+__global__ __launch_bounds__(T_) void k_reduce_f(In in, u64 n, typename Op::T *__restrict__ sums)
+{
+    using T = typename Op::T;
+    __shared__ T lds[T_ / IVX_WAVE + 1];
+    const u64 base = (u64)blockIdx.x * TILE_ + (u64)threadIdx.x * I_;
+    T s = Op::identity();
+#pragma unroll
+    for (int i = 0; i < I_; i++)
+        if (base + i < n) s = Op::combine(s, in(base + i));
+    T tot;
+    block_incl<Op>(s, lds, &tot);
+    if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+
+template <class Op, class In, class Out>
+__global__ __launch_bounds__(T_) void k_apply_f(In in, Out out, u64 n, const typename Op::T *__restrict__ offs)
+{
+    using T = typename Op::T;
+    __shared__ T lds[T_ / IVX_WAVE + 1];
+    __shared__ T edge[T_ / IVX_WAVE];
+    const u64 base = (u64)blockIdx.x * TILE_ + (u64)threadIdx.x * I_;
+    T v[I_];
+    T s = Op::identity();
+#pragma unroll
+    for (int i = 0; i < I_; i++) { v[i] = base + i < n ? in(base + i) : Op::identity(); s = Op::combine(s, v[i]); }
+    T tot;
+    T inc = block_incl<Op>(s, lds, &tot);
+    T run = offs ? offs[blockIdx.x] : Op::identity();
+    T prev = Op::shfl_up(inc, 1);
+    if (lane_id() == IVX_WAVE - 1) edge[threadIdx.x / IVX_WAVE] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) prev = Op::identity();
+    else if (lane_id() == 0) prev = edge[threadIdx.x / IVX_WAVE - 1];
+    run = Op::combine(run, prev);
+#pragma unroll
+    for (int i = 0; i < I_; i++) { run = Op::combine(run, v[i]); if (base + i < n) out(base + i, run); }
+}
+
+// inclusive scan of in(0..n) into out; the block partials take the stored-array path (they are few)
+template <class Op, class In, class Out>
+ivx_status inclusive_f(ivx_ctx *ctx, In in, Out out, u64 n)
+{
+    using T = typename Op::T;
+    if (n == 0) return IVX_OK;
+    const u64 nblk = (n + TILE_ - 1) / TILE_;
+    T *sums;
+    IVX_TRY(ctx->get_scratch(WS_SCAN0, nblk * sizeof(T), (void **)&sums));
+    if (nblk > 1) {
+        hipLaunchKernelGGL((k_reduce_f<Op, In>), dim3((u32)nblk), dim3(T_), 0, ctx->stream, in, n, sums);
+        IVX_TRY((scan_rec<Op, false>(ctx, sums, nblk, 1, WS_SCAN0)));
+    }
+    hipLaunchKernelGGL((k_apply_f<Op, In, Out>), dim3((u32)nblk), dim3(T_), 0, ctx->stream, in, out, n, nblk > 1 ? (const T *)sums : (const T *)nullptr);
+    return IVX_OK;
+}
+
 // in-place scans; scratch slots WS_SCAN0.. are used for the block partials
 template <class Op>
 ivx_status inclusive(ivx_ctx *ctx, typename Op::T *data, u64 n) { return scan_rec<Op, true>(ctx, data, n, 0, WS_SCAN0); }

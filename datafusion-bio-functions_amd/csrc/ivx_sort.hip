@@ -25,9 +25,9 @@ constexpr int RS_T = 1024;
 constexpr int RS_WAVES = RS_T / IVX_WAVE;       // 16
 constexpr int RS_HT = 256;                      // histogram kernel: threads (= digits)
 constexpr int RS_HWAVES = RS_HT / IVX_WAVE;
-constexpr u64 RS_CHUNK = 32768;                 // records per workgroup (histogram and scatter agree on it)
+constexpr u64 RS_CHUNK = 65536;                 // records per workgroup (histogram and scatter agree on it)
 template <int NW> struct Tile {
-    static constexpr int I = NW == 3 ? 4 : 8;   // records per thread per tile: 8192-record tiles, 4096 for 24-byte records (LDS)
+    static constexpr int I = NW == 3 ? 4 : NW == 1 ? 8 : 8;   // records per thread per tile: 8192-record tiles, 4096 for 24-byte records, 16384 for 8-byte ones (LDS)
     static constexpr int N = RS_T * I;
     static constexpr int WT = N / RS_WAVES;     // consecutive records per wavefront
 };
@@ -129,23 +129,60 @@ __global__ __launch_bounds__(RS_T) void k_scatter(CPtrs<NW> in, Ptrs<NW> out, u6
     const u64 lo = (u64)blockIdx.x * RS_CHUNK;
     const u64 hi = lo + RS_CHUNK < n ? lo + RS_CHUNK : n;
 
+    // 8-byte records: the next tile's records are loaded while this one goes through LDS (registers allow it)
+    constexpr bool PREFETCH = NW == 1;
+    u64 nxt[PREFETCH ? RS_I : 1][NW];
+    auto load_tile = [&](u64 t0, u64 (&dst)[PREFETCH ? RS_I : 1][NW]) {
+        if (!PREFETCH) return;
+        const u32 tn = (u32)(hi - t0 < RS_TILE ? hi - t0 : RS_TILE);
+        if (tn == RS_TILE) {
+#pragma unroll
+            for (int k = 0; k < RS_I; k++)
+#pragma unroll
+                for (int q = 0; q < NW; q++) dst[PREFETCH ? k : 0][q] = in.w[q][t0 + wv * RS_WTILE + k * IVX_WAVE + ln];
+        } else {
+#pragma unroll
+            for (int k = 0; k < RS_I; k++) {
+                const u32 j = wv * RS_WTILE + k * IVX_WAVE + ln;
+#pragma unroll
+                for (int q = 0; q < NW; q++) dst[PREFETCH ? k : 0][q] = j < tn ? in.w[q][t0 + j] : 0;
+            }
+        }
+    };
+    if (PREFETCH && lo < hi) load_tile(lo, nxt);
     for (u64 t0 = lo; t0 < hi; t0 += RS_TILE) {
         for (int i = tid; i < RS_WAVES * 256; i += RS_T) (&wcnt[0][0])[i] = 0;
         __syncthreads();
         const u32 tile_n = (u32)(hi - t0 < RS_TILE ? hi - t0 : RS_TILE);
         u64 r[RS_I][NW];
         u32 dig[RS_I], lrank[RS_I];
-        // ---- stable rank inside the wave's 512-record slice (index order = round, lane)
+        // ---- the wave's records of this tile: every load is issued before the first one is used (a load inside the
+        //      ranking loop below would be a full memory round trip per record)
+        if (PREFETCH) {
+#pragma unroll
+            for (int k = 0; k < RS_I; k++)
+#pragma unroll
+                for (int q = 0; q < NW; q++) r[k][q] = nxt[PREFETCH ? k : 0][q];
+            if (t0 + RS_TILE < hi) load_tile(t0 + RS_TILE, nxt);
+        } else if (tile_n == RS_TILE) {
+#pragma unroll
+            for (int k = 0; k < RS_I; k++)
+#pragma unroll
+                for (int q = 0; q < NW; q++) r[k][q] = in.w[q][t0 + wv * RS_WTILE + k * IVX_WAVE + ln];
+        } else {
+#pragma unroll
+            for (int k = 0; k < RS_I; k++) {
+                const u32 j = wv * RS_WTILE + k * IVX_WAVE + ln;
+#pragma unroll
+                for (int q = 0; q < NW; q++) r[k][q] = j < tile_n ? in.w[q][t0 + j] : 0;
+            }
+        }
+        // ---- stable rank inside the wave's slice (index order = round, lane)
 #pragma unroll
         for (int k = 0; k < RS_I; k++) {
             const u32 j = wv * RS_WTILE + k * IVX_WAVE + ln;        // slot in tile
             const bool valid = j < tile_n;
-            u32 d = 0;
-            if (valid) {
-#pragma unroll
-                for (int q = 0; q < NW; q++) r[k][q] = in.w[q][t0 + j];
-                d = (u32)((pick_word<NW>(r[k], word) >> shift) & 0xFF);
-            }
+            const u32 d = valid ? (u32)((pick_word<NW>(r[k], word) >> shift) & 0xFF) : 0u;
             const u64 peers = match_digit(d, valid);
             u32 base = 0;
             if (valid) base = wcnt[wv][d];
@@ -200,19 +237,24 @@ __global__ __launch_bounds__(RS_T) void k_scatter(CPtrs<NW> in, Ptrs<NW> out, u6
 }
 
 template <int NW>
-ivx_status sort_impl(ivx_ctx *ctx, u64 *const *a, u64 *const *b, u64 n, const ivx_sort_field *fields, int nfields, int *in_b)
+ivx_status sort_impl(ivx_ctx *ctx, u64 *const *a, u64 *const *b, u64 n, const ivx_sort_field *fields, int nfields, int *in_b, bool tight)
 {
     *in_b = 0;
     if (n <= 1) return IVX_OK;
     if (n >= 0xFFFFFFFFull) return ctx->fail(IVX_ERR_INVALID, "sort: more than 2^32-1 records");
     hipStream_t st = ctx->stream;
     // which bits vary at all (per sorted word)
+    // (tight: the caller packed the fields from the columns' value ranges, every digit varies -- no need to look)
     unsigned long long *d_var = (unsigned long long *)(ctx->d_scalars + 16);
-    IVX_HIP(ctx, hipMemsetAsync(d_var, 0, 8 * sizeof(u64), st));
-    for (int f = 0; f < nfields; f++)
-        hipLaunchKernelGGL(k_varbits, dim3(ivx_stream_grid(n, RS_HT * 16, 1024)), dim3(RS_HT), 0, st, (const u64 *)a[fields[f].word], n, d_var + f);
-    IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 16, d_var, 8 * sizeof(u64), hipMemcpyDeviceToHost, st));
-    IVX_HIP(ctx, hipStreamSynchronize(st));
+    if (tight) {
+        for (int f = 0; f < nfields; f++) ctx->h_scalars[16 + f] = ~0ull;
+    } else {
+        IVX_HIP(ctx, hipMemsetAsync(d_var, 0, 8 * sizeof(u64), st));
+        for (int f = 0; f < nfields; f++)
+            hipLaunchKernelGGL(k_varbits, dim3(ivx_stream_grid(n, RS_HT * 16, 1024)), dim3(RS_HT), 0, st, (const u64 *)a[fields[f].word], n, d_var + f);
+        IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 16, d_var, 8 * sizeof(u64), hipMemcpyDeviceToHost, st));
+        IVX_HIP(ctx, hipStreamSynchronize(st));
+    }
 
     const u32 nblk = (u32)((n + RS_CHUNK - 1) / RS_CHUNK);
     u32 *hist;
@@ -242,12 +284,12 @@ ivx_status sort_impl(ivx_ctx *ctx, u64 *const *a, u64 *const *b, u64 n, const iv
 }  // namespace
 
 ivx_status ivx_radix_sort(ivx_ctx *ctx, int nw, u64 *const *a, u64 *const *b, u64 n,
-                          const ivx_sort_field *fields, int nfields, int *in_b)
+                          const ivx_sort_field *fields, int nfields, int *in_b, bool tight)
 {
     switch (nw) {
-    case 1: return sort_impl<1>(ctx, a, b, n, fields, nfields, in_b);
-    case 2: return sort_impl<2>(ctx, a, b, n, fields, nfields, in_b);
-    case 3: return sort_impl<3>(ctx, a, b, n, fields, nfields, in_b);
+    case 1: return sort_impl<1>(ctx, a, b, n, fields, nfields, in_b, tight);
+    case 2: return sort_impl<2>(ctx, a, b, n, fields, nfields, in_b, tight);
+    case 3: return sort_impl<3>(ctx, a, b, n, fields, nfields, in_b, tight);
     default: return ctx->fail(IVX_ERR_INVALID, "sort: unsupported record width");
     }
 }

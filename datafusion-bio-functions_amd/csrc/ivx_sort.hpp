@@ -8,5 +8,7 @@ struct ivx_sort_field { int word, lo, hi; };
 
 // a[0..nw) hold the input arrays, b[0..nw) same-sized scratch; *in_b tells where
 // the sorted records ended up (1 = in b).  Uses scratch WS_SORTHIST and WS_SCAN*.
+// tight: the fields were packed from the value ranges of the data, so every digit varies (skips the pass that looks
+// for constant digits).
 ivx_status ivx_radix_sort(ivx_ctx *ctx, int nw, u64 *const *a, u64 *const *b, u64 n,
-                          const ivx_sort_field *fields, int nfields, int *in_b);
+                          const ivx_sort_field *fields, int nfields, int *in_b, bool tight = false);
