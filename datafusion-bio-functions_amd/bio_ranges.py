@@ -63,7 +63,7 @@ def lib():
     global _lib
     if _lib is None:
         pyivx.lib()                                   # loads libivx_hip.so (and the HIP runtime) first
-        _lib = C.CDLL(_LIB_PATH)
+        _lib = C.CDLL(os.environ.get("BRH_LIB") or _LIB_PATH)     # BRH_LIB: another build of the host library (the sanitizer build)
         _lib.brh_last_error.restype = C.c_char_p
     return _lib
 
@@ -116,6 +116,17 @@ class Session:
     def _chk(self, rc):
         if rc != 0:
             raise BioRangesError(lib().brh_last_error(self.h).decode())
+
+    def metrics(self):
+        """BuildProbeJoinMetrics of the session (joins/utils.rs:399-453): build_time, join_time [ms], build_input_batches,
+        build_input_rows, build_mem_used, input_batches, input_rows, output_batches, output_rows."""
+        m = pyivx.Metrics()
+        self._chk(lib().brh_session_metrics(self.h, C.byref(m)))
+        return {f: getattr(m, f) for f, _ in pyivx.Metrics._fields_}
+
+    def set_memory_limit(self, nbytes):
+        """device bytes the session may reserve (MemoryReservation, interval_join.rs:614-639); 0 = no limit"""
+        self._chk(lib().brh_session_set_memory_limit(self.h, C.c_uint64(int(nbytes))))
 
     # ---- count_overlaps / coverage: RangeTableFunction (table_function.rs:521-560)
     def _count(self, left, right, cols_left, cols_right, strict, coverage):
@@ -234,7 +245,7 @@ class Session:
     # ---- f3: compute::take of payload columns on the device (interval_join.rs:1655-1667, nearest.rs:469-482)
     def take(self, column, idx):
         """column: pyarrow Array / ChunkedArray; idx: UInt32 array (nulls -> null rows).  Raises for layouts the
-        device gather does not cover (bool, nested, dictionary, views): those stay with the caller's own take."""
+        device gather does not cover (nested types): those stay with the caller's own take."""
         if isinstance(column, pa.ChunkedArray):
             column = column.combine_chunks() if column.num_chunks != 1 else column.chunk(0)
         if isinstance(idx, pa.ChunkedArray):
@@ -348,6 +359,17 @@ def check_position_column(table, column, as_i64=False):
     buf = C.create_string_buffer(512)
     try:
         rc = lib().brh_check_position_column(None, T.c, column.encode(), C.c_int(int(as_i64)), buf, C.c_int(512))
+    finally:
+        T.close()
+    return None if rc == 0 else buf.value.decode()
+
+
+def check_contig_column(table, column):
+    """ContigArray checks alone (no GPU): Utf8 / LargeUtf8 / Utf8View, no NULL contigs; returns None or the error text."""
+    T = _Exported(table)
+    buf = C.create_string_buffer(512)
+    try:
+        rc = lib().brh_check_contig_column(None, T.c, column.encode(), buf, C.c_int(512))
     finally:
         T.close()
     return None if rc == 0 else buf.value.decode()

@@ -4,6 +4,7 @@
 #include "ivx_internal.hpp"
 #include <cstdlib>
 #include <atomic>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -17,12 +18,19 @@ ivx_status ivx_ctx::get_scratch(int slot, size_t bytes, void **out)
     if (join_plan.valid && ((join_plan.slots >> slot) & 1)) join_plan.valid = false;
     if (bytes < 256) bytes = 256;
     if (b.cap < bytes) {
-        if (b.p) { (void)hipStreamSynchronize(stream); (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
         size_t want = bytes + bytes / 8;
+        if (mem_limit) {
+            const u64 others = scratch_bytes - b.cap + building_bytes;
+            if (others + bytes > mem_limit)
+                return fail(IVX_ERR_OOM, "Resources exhausted: failed to reserve " + std::to_string(bytes) + " bytes of device scratch (" +
+                                         std::to_string(others) + " bytes reserved, limit " + std::to_string(mem_limit) + ")");
+            if (others + want > mem_limit) want = bytes;
+        }
+        if (b.p) { (void)hipStreamSynchronize(stream); (void)hipFree(b.p); b.p = nullptr; scratch_bytes -= b.cap; b.cap = 0; }
         hipError_t e = hipMalloc(&b.p, want);
         if (e != hipSuccess) { want = bytes; e = hipMalloc(&b.p, want); }
         if (e != hipSuccess) { b.p = nullptr; return fail_hip("hipMalloc(scratch)", e); }
-        b.cap = want;
+        b.cap = want; scratch_bytes += want;
     }
     *out = b.p;
     return IVX_OK;
@@ -81,6 +89,10 @@ void pool_give(int device, void *p, size_t cap)
 ivx_status ivx_index_alloc(ivx_ctx *ctx, ivx_index *ix, size_t bytes, void **out)
 {
     if (bytes < 256) bytes = 256;
+    if (ctx->mem_limit && ctx->scratch_bytes + ctx->building_bytes + bytes > ctx->mem_limit)
+        return ctx->fail(IVX_ERR_OOM, "Resources exhausted: failed to reserve " + std::to_string(bytes) + " bytes for the index (" +
+                                      std::to_string(ctx->scratch_bytes + ctx->building_bytes) + " bytes reserved, limit " + std::to_string(ctx->mem_limit) + ")");
+    ctx->building_bytes += bytes;
     size_t cap = bytes;
     void *p = pool_take(ctx->device, bytes, &cap);
     if (!p) {
@@ -149,6 +161,22 @@ ivx_status check_probe_args(ivx_ctx *ctx, const ivx_index *ix, int kind, int mem
     IVX_HIP(ctx, hipSetDevice(ctx->device));
     return IVX_OK;
 }
+
+// BuildProbeJoinMetrics bookkeeping of one call (host wall time, as the reference's timers)
+struct CallMetrics {
+    ivx_ctx *c; bool build; std::chrono::steady_clock::time_point t0;
+    CallMetrics(ivx_ctx *ctx, bool is_build, u64 rows) : c(ctx), build(is_build), t0(std::chrono::steady_clock::now())
+    {
+        if (build) { c->metrics.build_input_batches++; c->metrics.build_input_rows += rows; }
+        else { c->metrics.input_batches++; c->metrics.input_rows += rows; }
+    }
+    void out(u64 rows) { if (rows) { c->metrics.output_batches++; c->metrics.output_rows += rows; } }
+    ~CallMetrics()
+    {
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        (build ? c->metrics.build_time : c->metrics.join_time) += ms;
+    }
+};
 
 struct KernelTimer {
     ivx_ctx *c;
@@ -224,6 +252,22 @@ extern "C" ivx_status ivx_ctx_synchronize(ivx_ctx *c)
     return IVX_OK;
 }
 
+extern "C" ivx_status ivx_ctx_metrics(const ivx_ctx *c, ivx_metrics *out)
+{
+    if (!c || !out) return IVX_ERR_INVALID;
+    *out = c->metrics;
+    return IVX_OK;
+}
+
+extern "C" void ivx_ctx_reset_metrics(ivx_ctx *c) { if (c) c->metrics = ivx_metrics{}; }
+
+extern "C" ivx_status ivx_ctx_set_memory_limit(ivx_ctx *c, uint64_t bytes)
+{
+    if (!c) return IVX_ERR_INVALID;
+    c->mem_limit = bytes;
+    return IVX_OK;
+}
+
 extern "C" double ivx_ctx_last_kernel_ms(const ivx_ctx *cc)
 {
     ivx_ctx *c = const_cast<ivx_ctx *>(cc);
@@ -260,6 +304,8 @@ extern "C" ivx_status ivx_index_build(ivx_ctx *ctx, int kind, int mem, const uin
     if (ix) ix->serial = next_serial.fetch_add(1);
     if (!ix) return ctx->fail(IVX_ERR_OOM, "host allocation failed");
     ix->kind = kind; ix->device = ctx->device; ix->n = n; ix->nkeys = n_keys;
+    CallMetrics cm(ctx, true, n);
+    ctx->building_bytes = 0;
     const u32 *dk; const i32 *ds, *de;
     ivx_status st = stage_in(ctx, mem, WS_IN_KEY, key, n, &dk);
     if (st == IVX_OK) st = stage_in(ctx, mem, WS_IN_START, start, n, &ds);
@@ -274,7 +320,9 @@ extern "C" ivx_status ivx_index_build(ivx_ctx *ctx, int kind, int mem, const uin
         }
     }
     if (st == IVX_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = ctx->fail(IVX_ERR_HIP, "index build failed on device");
+    ctx->building_bytes = 0;                                     // (the index is the caller's now; the limit covers scratch + a build in progress)
     if (st != IVX_OK) { ivx_index_free(ix); return st; }
+    ctx->metrics.build_mem_used += ix->bytes;
     *out = ix;
     return IVX_OK;
 }
@@ -304,6 +352,7 @@ static ivx_status overlap_common(ivx_ctx *ctx, const ivx_index *ix, int mem, int
                                  u32 *per_row, u8 *exists, u32 *bidx, u32 *pidx, u64 cap, u64 *total)
 {
     IVX_TRY(check_probe_args(ctx, ix, IVX_KIND_OVERLAP, mem, start, end, n));
+    CallMetrics cm(ctx, false, n);
     const u32 *dk = nullptr; const i32 *ds = nullptr, *de = nullptr;
     // large COUNT/FILL batches: partition the probe rows by index region and probe from LDS;
     // small batches and the per-row modes gather straight from the index
@@ -352,6 +401,7 @@ static ivx_status overlap_common(ivx_ctx *ctx, const ivx_index *ix, int mem, int
     if (mode == JP_COUNT && regions && pl.valid) pl.total = tot;
     if (total) *total = tot;
     if (mode == JP_FILL && tot > cap) return ctx->fail(IVX_ERR_CAPACITY, "pair buffers too small");   // (a plan survives this: the retry with bigger buffers reuses it)
+    cm.out(mode == JP_FILL ? tot : (mode == JP_COUNT ? 0 : n));
     if (planned) pl.valid = false;                          // a plan serves ONE successful fill: a caller that refills the same buffers with its next batch must not get this batch's rows
     IVX_TRY(copy_out(ctx, mem, per_row, d_row, n));
     IVX_TRY(copy_out(ctx, mem, exists, d_ex, n));
@@ -413,6 +463,8 @@ static ivx_status per_row_i64(ivx_ctx *ctx, const ivx_index *ix, int kind, int m
 {
     IVX_TRY(check_probe_args(ctx, ix, kind, mem, start, end, n));
     if (n && !out) return ctx->fail(IVX_ERR_INVALID, "null output column");
+    CallMetrics cm(ctx, false, n);
+    cm.out(n);
     const u32 *dk; const i32 *ds, *de; i64 *dout;
     IVX_TRY(stage_in(ctx, mem, WS_IN_KEY, key, n, &dk));
     IVX_TRY(stage_in(ctx, mem, WS_IN_START, start, n, &ds));
@@ -448,6 +500,7 @@ extern "C" ivx_status ivx_probe_nearest(ivx_ctx *ctx, const ivx_index *ix, int m
     if (!rows) return ctx->fail(IVX_ERR_INVALID, "null rows");
     if (n && (!build_idx || !probe_idx)) return ctx->fail(IVX_ERR_INVALID, "null output column");
     if ((u64)k * n > 0xFFFFFFFFFFull) return ctx->fail(IVX_ERR_INVALID, "nearest: k * rows too large");
+    CallMetrics cm(ctx, false, n);
     const u32 *dk; const i32 *ds, *de; u32 *db, *dp; i64 *dd;
     IVX_TRY(stage_in(ctx, mem, WS_IN_KEY, key, n, &dk));
     IVX_TRY(stage_in(ctx, mem, WS_IN_START, start, n, &ds));
@@ -462,6 +515,7 @@ extern "C" ivx_status ivx_probe_nearest(ivx_ctx *ctx, const ivx_index *ix, int m
         *rows = r;
         if (st != IVX_OK) return st;
     }
+    cm.out(r);
     IVX_TRY(copy_out(ctx, mem, build_idx, db, r));
     IVX_TRY(copy_out(ctx, mem, probe_idx, dp, r));
     IVX_TRY(copy_out(ctx, mem, distance, dd, r));

@@ -71,6 +71,9 @@ struct ivx_ctx {
     u64 *h_scalars = nullptr;           // pinned mirror
     ivx_sub_plan sub_plan;
     ivx_join_plan join_plan;
+    ivx_metrics metrics{};              // BuildProbeJoinMetrics, see ivx.h
+    u64 mem_limit = 0;                  // device bytes of scratch + the index being built (0 = unlimited)
+    u64 scratch_bytes = 0, building_bytes = 0;
 
     ivx_status fail(ivx_status st, const std::string &msg) { err = msg; return st; }
     ivx_status fail_hip(const char *what, hipError_t e)

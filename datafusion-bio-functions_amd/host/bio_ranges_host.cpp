@@ -82,6 +82,15 @@ int get_contig(brh_session *s, brh_batch t, const char *name, StrCol *out)
     else if (!std::strcmp(f, "U")) out->kind = 1;
     else if (!std::strcmp(f, "vu")) out->kind = 2;
     else return fail(s, "unsupported data type " + std::string(f) + " for contig column '" + name + "'; expected Utf8, LargeUtf8, or Utf8View");
+    // A NULL contig has no defined bytes (Arrow lets its offsets span anything): the reference hashes it as a key of its
+    // own in the join and reads whatever value(i) holds in the table functions; here it is refused outright rather than
+    // silently keyed as "" (parity with the reference on NULL contigs is not pinned by any of its tests).
+    if (null_count(out->a) > 0) {
+        const uint8_t *v = (const uint8_t *)out->a->buffers[0];
+        int64_t row = 0;
+        for (int64_t i = 0; i < out->a->length; i++) { const int64_t j = i + out->a->offset; if (!((v[j >> 3] >> (j & 7)) & 1)) { row = i; break; } }
+        return fail(s, "contig column '" + std::string(name) + "' contains a NULL at row " + std::to_string(row) + "; NULL contigs are not supported");
+    }
     return 0;
 }
 
@@ -216,13 +225,14 @@ int build_keys(brh_session *s, const std::vector<std::pair<brh_batch, brh_column
 }
 
 // ---- Arrow output helpers
-struct OutPriv { std::vector<void *> bufs; const void *ptrs[4] = {nullptr, nullptr, nullptr, nullptr}; char *fmt = nullptr; };
+struct OutPriv { std::vector<void *> bufs; const void *ptrs[4] = {nullptr, nullptr, nullptr, nullptr}; char *fmt = nullptr; ArrowArray *dict = nullptr; };
 
 void release_array(ArrowArray *a)
 {
     if (!a || !a->release) return;
     OutPriv *p = (OutPriv *)a->private_data;
     for (void *b : p->bufs) std::free(b);
+    if (p->dict) { if (p->dict->release) p->dict->release(p->dict); std::free(p->dict); }
     delete p;
     a->release = nullptr;
 }
@@ -230,6 +240,7 @@ void release_schema(ArrowSchema *sc)
 {
     if (!sc || !sc->release) return;
     std::free((void *)sc->format); std::free((void *)sc->name);
+    if (sc->dictionary) { if (sc->dictionary->release) sc->dictionary->release(sc->dictionary); std::free(sc->dictionary); }
     sc->release = nullptr;
 }
 
@@ -317,6 +328,28 @@ extern "C" int brh_check_position_column(brh_session *s, brh_batch table, const 
     }
     if (rc && errbuf && errbuf_len > 0) std::snprintf(errbuf, (size_t)errbuf_len, "%s", u->err.c_str());
     return rc;
+}
+
+extern "C" int brh_check_contig_column(brh_session *s, brh_batch table, const char *column, char *errbuf, int errbuf_len)
+{
+    brh_session tmp;
+    brh_session *u = s ? s : &tmp;
+    StrCol c;
+    const int rc = get_contig(u, table, column, &c);
+    if (rc && errbuf && errbuf_len > 0) std::snprintf(errbuf, (size_t)errbuf_len, "%s", u->err.c_str());
+    return rc;
+}
+
+extern "C" int brh_session_metrics(brh_session *s, ivx_metrics *out)
+{
+    if (!s || !out) return 1;
+    return ivx_ctx_metrics(s->ctx, out) == IVX_OK ? 0 : 1;
+}
+
+extern "C" int brh_session_set_memory_limit(brh_session *s, uint64_t bytes)
+{
+    if (!s) return 1;
+    return ivx_ctx_set_memory_limit(s->ctx, bytes) == IVX_OK ? 0 : 1;
 }
 
 extern "C" int brh_count_overlaps(brh_session *s, brh_batch left, brh_columns lcols, brh_batch right, brh_columns rcols,
@@ -563,6 +596,50 @@ const uint8_t *rebased_validity(const ArrowArray *a, std::vector<uint8_t> *store
     return store->data();
 }
 
+// an owned copy (offset 0) of a flat array: fixed-width primitives, Boolean, Utf8 / LargeUtf8 / Binary / LargeBinary --
+// the value types a dictionary-encoded payload column keeps its values in; false for anything else
+bool copy_flat_array(const ArrowArray *src, const char *f, ArrowArray *dst)
+{
+    std::memset(dst, 0, sizeof *dst);
+    const int64_t n = src->length, o = src->offset;
+    OutPriv *p = new OutPriv();
+    int nb = 2;
+    const bool s32 = !std::strcmp(f, "u") || !std::strcmp(f, "z"), s64 = !std::strcmp(f, "U") || !std::strcmp(f, "Z");
+    if (s32 || s64) {
+        const size_t ow = s64 ? 8 : 4;
+        const uint8_t *off = (const uint8_t *)src->buffers[1] + (size_t)o * ow;
+        const int64_t base = s64 ? ((const int64_t *)off)[0] : (int64_t)((const int32_t *)off)[0];
+        const int64_t end = s64 ? ((const int64_t *)off)[n] : (int64_t)((const int32_t *)off)[n];
+        void *oo = std::malloc((size_t)(n + 1) * ow);
+        for (int64_t i = 0; i <= n; i++) {
+            if (s64) ((int64_t *)oo)[i] = ((const int64_t *)off)[i] - base; else ((int32_t *)oo)[i] = ((const int32_t *)off)[i] - (int32_t)base;
+        }
+        void *od = std::malloc((size_t)(end - base > 0 ? end - base : 1));
+        if (end > base) std::memcpy(od, (const uint8_t *)src->buffers[2] + base, (size_t)(end - base));
+        p->bufs.push_back(oo); p->bufs.push_back(od); p->ptrs[1] = oo; p->ptrs[2] = od; nb = 3;
+    } else if (!std::strcmp(f, "b")) {
+        uint8_t *ob = (uint8_t *)std::calloc((size_t)(n + 7) / 8 + 1, 1);
+        const uint8_t *v = (const uint8_t *)src->buffers[1];
+        for (int64_t i = 0; i < n; i++) { const int64_t j = i + o; if ((v[j >> 3] >> (j & 7)) & 1) ob[i >> 3] |= (uint8_t)(1u << (i & 7)); }
+        p->bufs.push_back(ob); p->ptrs[1] = ob;
+    } else {
+        const uint32_t w = fixed_width(f);
+        if (!w) { delete p; return false; }
+        void *ov = std::malloc((size_t)(n ? n : 1) * w);
+        if (n) std::memcpy(ov, (const uint8_t *)src->buffers[1] + (size_t)o * w, (size_t)n * w);
+        p->bufs.push_back(ov); p->ptrs[1] = ov;
+    }
+    int64_t nulls = 0;
+    if (src->n_buffers > 0 && src->buffers[0] && null_count(src) > 0) {
+        uint8_t *bm = (uint8_t *)std::calloc((size_t)(n + 7) / 8 + 1, 1);
+        const uint8_t *v = (const uint8_t *)src->buffers[0];
+        for (int64_t i = 0; i < n; i++) { const int64_t j = i + o; if ((v[j >> 3] >> (j & 7)) & 1) bm[i >> 3] |= (uint8_t)(1u << (i & 7)); else nulls++; }
+        p->bufs.push_back(bm); p->ptrs[0] = bm;
+    }
+    dst->length = n; dst->null_count = nulls; dst->n_buffers = nb; dst->buffers = p->ptrs; dst->private_data = p; dst->release = release_array;
+    return true;
+}
+
 void finish_array(ArrowArray *a, OutPriv *p, int64_t n, const uint8_t *valid_bytes, int n_buffers)
 {
     uint8_t *bm = (uint8_t *)std::calloc((size_t)(n + 7) / 8 + 1, 1);
@@ -598,6 +675,33 @@ extern "C" int brh_take(brh_session *s, const ArrowArray *column, const ArrowSch
     const uint64_t n_src = (uint64_t)column->length;
     std::memset(out, 0, sizeof *out);
     const bool str32 = !std::strcmp(f, "u") || !std::strcmp(f, "z"), str64 = !std::strcmp(f, "U") || !std::strcmp(f, "Z");
+    if (column_schema->dictionary) {
+        // dictionary-encoded column (arrow's take gathers the keys and keeps the dictionary): the keys are a fixed-width
+        // gather on the device, the output carries an owned copy of the dictionary values
+        const uint32_t w = fixed_width(f);
+        if (!w || !column->dictionary) return fail(s, "take: malformed dictionary column");
+        ArrowArray *dict = (ArrowArray *)std::malloc(sizeof(ArrowArray));
+        if (!copy_flat_array(column->dictionary, column_schema->dictionary->format, dict)) {
+            std::free(dict);
+            return fail(s, "take: unsupported dictionary value type " + std::string(column_schema->dictionary->format) + " (flat value types only)");
+        }
+        const uint8_t *src = (const uint8_t *)column->buffers[1] + (size_t)column->offset * w;
+        void *o = std::malloc((size_t)(n ? n : 1) * w);
+        const ivx_status st = ivx_take_fixed(s->ctx, IVX_MEM_HOST, src, w, n_src, svb, ix.data(), (uint64_t)n, o, valid.data());
+        if (st != IVX_OK) { std::free(o); dict->release(dict); std::free(dict); return fail_ivx(s, st); }
+        OutPriv *p = new OutPriv();
+        p->bufs.push_back(o);
+        p->ptrs[1] = o;
+        p->dict = dict;
+        finish_array(out, p, n, valid.data(), 2);
+        out->dictionary = dict;
+        make_schema(out_schema, f, column_schema->name ? column_schema->name : "", true);
+        out_schema->flags |= column_schema->flags & 1;              // ARROW_FLAG_DICTIONARY_ORDERED
+        out_schema->dictionary = (ArrowSchema *)std::malloc(sizeof(ArrowSchema));
+        make_schema(out_schema->dictionary, column_schema->dictionary->format, column_schema->dictionary->name ? column_schema->dictionary->name : "",
+                    (column_schema->dictionary->flags & 2) != 0);
+        return 0;
+    }
     if (str32 || str64) {
         const size_t ow = str64 ? 8 : 4;
         const uint8_t *off = (const uint8_t *)column->buffers[1] + (size_t)column->offset * ow;

@@ -26,7 +26,14 @@ SYMBOLS = [
     "ivx_index_device_bytes", "ivx_probe_overlap_count", "ivx_probe_overlap_fill", "ivx_probe_exists",
     "ivx_probe_count", "ivx_probe_coverage", "ivx_probe_nearest", "ivx_merge", "ivx_subtract",
     "ivx_cluster", "ivx_complement", "ivx_take_fixed", "ivx_take_utf8", "ivx_take_bits", "ivx_take_view",
+    "ivx_ctx_metrics", "ivx_ctx_reset_metrics", "ivx_ctx_set_memory_limit",
 ]
+
+
+class Metrics(C.Structure):
+    _fields_ = [("build_time", C.c_double), ("join_time", C.c_double), ("build_input_batches", C.c_uint64),
+                ("build_input_rows", C.c_uint64), ("build_mem_used", C.c_uint64), ("input_batches", C.c_uint64),
+                ("input_rows", C.c_uint64), ("output_batches", C.c_uint64), ("output_rows", C.c_uint64)]
 
 
 class IvxError(RuntimeError):
@@ -160,6 +167,18 @@ class Ctx:
 
     def last_kernel_ms(self):
         return lib().ivx_ctx_last_kernel_ms(self.h)
+
+    def metrics(self):
+        """BuildProbeJoinMetrics under the reference's names (joins/utils.rs:399-453)."""
+        m = Metrics()
+        self._chk(lib().ivx_ctx_metrics(self.h, C.byref(m)))
+        return {f: getattr(m, f) for f, _ in Metrics._fields_}
+
+    def reset_metrics(self):
+        lib().ivx_ctx_reset_metrics(self.h)
+
+    def set_memory_limit(self, nbytes):
+        self._chk(lib().ivx_ctx_set_memory_limit(self.h, C.c_uint64(int(nbytes))))
 
     # ---- index ----
     def build(self, kind, key, start, end, n_keys=None):

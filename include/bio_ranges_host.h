@@ -23,6 +23,7 @@
 #ifndef BIO_RANGES_HOST_H
 #define BIO_RANGES_HOST_H
 #include <stdint.h>
+#include "ivx.h"   /* ivx_metrics */
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -129,9 +130,10 @@ int brh_complement(brh_session *s, brh_batch table, brh_columns cols, brh_batch 
  * (interval_join.rs:1655-1667, nearest.rs:469-482), on the device.  column: any fixed-width primitive
  * (ints, floats, date/time/timestamp/duration, decimal128/256, fixed-size binary of 1/2/4/8/16/32 bytes),
  * Boolean, Utf8 / LargeUtf8 / Binary / LargeBinary, or Utf8View / BinaryView (the output is compacted
- * into one data buffer); idx: UInt32, nulls allowed (-> null output slots).
- * Other layouts (nested, dictionary) return an error: the caller keeps them on
- * its own take.  The output has the column's type and is nullable. */
+ * into one data buffer), or a dictionary-encoded column over any of the flat value types (the keys are gathered, the
+ * output carries its own copy of the dictionary); idx: UInt32, nulls allowed (-> null output slots).
+ * Nested layouts (struct, list, ...) return an error: the caller keeps them on its own take.  The output has the
+ * column's type and is nullable. */
 int brh_take(brh_session *s, const struct ArrowArray *column, const struct ArrowSchema *column_schema,
              const struct ArrowArray *idx, const struct ArrowSchema *idx_schema,
              struct ArrowArray *out, struct ArrowSchema *out_schema);
@@ -169,6 +171,15 @@ void brh_join_stream_close(brh_join_stream *js);
  * 0 = fine, else the error text is set.  Used by the CPU-only tests. */
 int brh_check_position_column(brh_session *s_or_null, brh_batch table, const char *column, int as_i64,
                               char *errbuf, int errbuf_len);
+/* ... and a contig column like ContigArray (array_utils.rs:10-24, :178-229): Utf8 / LargeUtf8 / Utf8View; NULL contigs are
+ * refused (the reference's behaviour on them is not pinned by its tests; keying them as "" would be a silent guess). */
+int brh_check_contig_column(brh_session *s_or_null, brh_batch table, const char *column, char *errbuf, int errbuf_len);
+
+/* BuildProbeJoinMetrics of the session's context under the reference's names (joins/utils.rs:399-453), and the device
+ * memory the session may reserve (MemoryReservation::try_grow, interval_join.rs:614-639): ivx.h ivx_ctx_metrics /
+ * ivx_ctx_set_memory_limit. */
+int brh_session_metrics(brh_session *s, ivx_metrics *out);
+int brh_session_set_memory_limit(brh_session *s, uint64_t bytes);
 
 #ifdef __cplusplus
 }

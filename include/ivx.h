@@ -97,6 +97,22 @@ ivx_status ivx_ctx_synchronize(ivx_ctx *ctx);
 double     ivx_ctx_last_kernel_ms(const ivx_ctx *ctx);
 const char *ivx_version(void);
 
+/* BuildProbeJoinMetrics (joins/utils.rs:399-453) under the reference's names, accumulated over the calls made on this
+ * context since creation / the last reset: build_* by ivx_index_build, the rest by the probe and sweep calls (one
+ * call = one input batch and, if it returns rows, one output batch).  Times are host wall time of the calls in ms
+ * (what the reference's timers bracket); build_mem_used = device bytes of the indexes built. */
+typedef struct ivx_metrics {
+    double build_time, join_time;
+    uint64_t build_input_batches, build_input_rows, build_mem_used;
+    uint64_t input_batches, input_rows, output_batches, output_rows;
+} ivx_metrics;
+ivx_status ivx_ctx_metrics(const ivx_ctx *ctx, ivx_metrics *out);
+void       ivx_ctx_reset_metrics(ivx_ctx *ctx);
+/* Device memory this context may hold at once in its scratch buffers plus any ONE index it is building (0 = no limit):
+ * the reference reserves build-side memory against DataFusion's pool and fails with ResourcesExhausted
+ * (interval_join.rs:614-639); a call that would go over the limit returns IVX_ERR_OOM and allocates nothing. */
+ivx_status ivx_ctx_set_memory_limit(ivx_ctx *ctx, uint64_t bytes);
+
 /* ---- index build: replaces collect_left_input's update_hashmap +
  *      IntervalJoinAlgorithm::new (interval_join.rs:584-668, :745-847, :903-931),
  *      build_count_index_from_batches / build_coitree_from_batches

@@ -218,6 +218,11 @@ def test_device_take_matches_arrow_take(ctx):
         "flag": pa.array([None if i % 7 == 0 else (i % 3 == 0) for i in range(n)], pa.bool_()),
         "view": pa.array([None if i % 10 == 0 else ("v%d-" % i) * (i % 7) for i in range(n)], pa.string_view()),
         "bview": pa.array([bytes([65 + i % 26]) * (i % 40) for i in range(n)], pa.binary_view()),
+        # dictionary-encoded payload columns (arrow's take gathers the keys, interval_join.rs:1655-1667 takes any type)
+        "dict_s": pa.array([None if i % 17 == 0 else "chr%d" % (i % 24) for i in range(n)], pa.string()).dictionary_encode(),
+        "dict_i": pa.DictionaryArray.from_arrays(pa.array([None if i % 19 == 0 else i % 5 for i in range(n)], pa.int8()),
+                                                 pa.array([10, 20, None, 40, 50], pa.int64())),
+        "dict_ls": pa.DictionaryArray.from_arrays(pa.array([i % 3 for i in range(n)], pa.uint16()), pa.array(["+", "-", "."], pa.large_string())),
     }
     t = pa.table(cols).slice(3)                                       # non-zero offsets into every buffer, bitmaps included
     idx = pa.array([None if i % 13 == 0 else (i * 7) % t.num_rows for i in range(1000)], pa.uint32())
@@ -232,6 +237,9 @@ def test_device_take_matches_arrow_take(ctx):
             continue
         want = pc.take(col, idx)
         assert got.type == want.type and got.to_pylist() == want.combine_chunks().to_pylist(), name
+        if name.startswith("dict"):
+            got.validate(full=True)
+            assert got.dictionary.to_pylist() == col.chunk(0).dictionary.to_pylist()      # the dictionary rides along unchanged
     with pytest.raises(br.BioRangesError, match="unsupported column type"):
         ctx.take(pa.array([[1], [2]]), pa.array([0], pa.uint32()))             # nested: stays with the caller
     with pytest.raises(br.BioRangesError, match="out of bounds"):
@@ -445,3 +453,36 @@ def test_join_stream_errors(ctx, golden):
         js.push(pa.table({"contig": ["chr1"], "pos_start": pa.array([2**31], pa.int64()), "pos_end": pa.array([2**31 + 5], pa.int64())}))
     assert js.finish() == []                                     # nothing was accepted
     js.close()
+
+
+def test_null_contig_is_refused_by_the_operators(ctx, golden):
+    reads, targets = table(golden.tables["reads"]), table(golden.tables["targets"])
+    bad = pa.table({"contig": pa.array(["chr1", None]), "pos_start": pa.array([1, 5], pa.int64()), "pos_end": pa.array([9, 8], pa.int64())})
+    for call in (lambda: ctx.count_overlaps(bad, targets), lambda: ctx.count_overlaps(reads, bad), lambda: ctx.interval_join(reads, bad),
+                 lambda: ctx.merge(bad), lambda: ctx.nearest(bad, targets)):
+        with pytest.raises(br.BioRangesError, match=r"contains a NULL at row 1; NULL contigs are not supported"):
+            call()
+
+
+def test_session_metrics_and_memory_limit(golden):
+    """BuildProbeJoinMetrics under the reference's names (joins/utils.rs:399-453) and the device-memory reservation
+    (interval_join.rs:614-639: over the limit -> ResourcesExhausted, nothing allocated, the session stays usable)."""
+    import numpy as np
+    s = br.Session(0)
+    build, probe = _rand_tables(21, 50_000, 400_000)
+    wb, wp = s.interval_join(build, probe)
+    m = s.metrics()
+    assert m["build_input_batches"] == 1 and m["build_input_rows"] == 50_000 and m["build_mem_used"] > 50_000 * 12
+    assert m["input_batches"] == 2 and m["input_rows"] == 2 * 400_000          # the sizing call and the fill call
+    assert m["output_batches"] == 1 and m["output_rows"] == len(wb)
+    assert m["build_time"] > 0 and m["join_time"] > 0
+    s.close()
+    s = br.Session(0)
+    s.set_memory_limit(1 << 20)                                                # 1 MiB: the build needs more
+    with pytest.raises(br.BioRangesError, match=r"Resources exhausted: failed to reserve \d+ bytes"):
+        s.interval_join(build, probe)
+    s.set_memory_limit(0)
+    wb2, wp2 = s.interval_join(build, probe)                                   # the same session, no limit: fine
+    key = lambda b, p: np.sort((b.to_numpy().astype(np.uint64) << np.uint64(32)) | p.to_numpy().astype(np.uint64))
+    assert (key(wb2, wp2) == key(wb, wp)).all()
+    s.close()

@@ -53,3 +53,40 @@ def test_missing_and_unsupported_columns():
 def test_sliced_batches_respect_offsets():
     t = _t(p=pa.array([2**40, 1, 2, 3], pa.int64())).slice(1)
     assert br.check_position_column(t, "p") is None
+
+
+def test_contig_column_types_and_null_contigs():
+    # ContigArray (array_utils.rs:10-24, :196-229): Utf8 / LargeUtf8 / Utf8View
+    for ty in (pa.string(), pa.large_string(), pa.string_view()):
+        assert br.check_contig_column(_t(c=pa.array(["chr1", "", "chrX"], ty)), "c") is None
+    assert "expected Utf8, LargeUtf8, or Utf8View" in br.check_contig_column(_t(c=pa.array([1, 2])), "c")
+    assert "contig column 'q' not found in batch with columns" in br.check_contig_column(_t(c=pa.array(["a"])), "q")
+    # a NULL contig is refused, not silently keyed as "" (sliced batches: the row is counted in the slice)
+    t = _t(c=pa.array(["chr1", "chr2", None, "chr3"]))
+    assert br.check_contig_column(t, "c") == "contig column 'c' contains a NULL at row 2; NULL contigs are not supported"
+    assert br.check_contig_column(t.slice(1), "c") == "contig column 'c' contains a NULL at row 1; NULL contigs are not supported"
+    assert br.check_contig_column(t.slice(3), "c") is None
+
+
+def test_host_checks_under_address_and_ub_sanitizers():
+    """The host library's column checks (offset arithmetic on sliced Arrow buffers, error formatting) once more against an
+    ASan + UBSan build of host/bio_ranges_host.cpp, in a child process with the sanitizer runtimes preloaded (sanitizers
+    run on CPU code only; the GPU tiers use the normal build)."""
+    import shutil
+    import subprocess
+    if os.environ.get("BRH_LIB"):
+        pytest.skip("already inside the sanitizer child")
+    gxx = shutil.which("g++")
+    if not gxx:
+        pytest.skip("no g++")
+    rts = [subprocess.run([gxx, f"-print-file-name={n}"], capture_output=True, text=True).stdout.strip() for n in ("libasan.so", "libubsan.so")]
+    if not all(os.path.isabs(r) and os.path.exists(r) for r in rts):
+        pytest.skip("sanitizer runtimes not installed")
+    pkg = os.path.join(ROOT, "datafusion-bio-functions_amd")
+    subprocess.check_call(["make", "-s", "-C", pkg, "asan"])
+    env = dict(os.environ, LD_PRELOAD=":".join(rts), BRH_LIB=os.path.join(pkg, "lib", "asan", "libbio_ranges_hip.so"),
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    p = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", os.path.abspath(__file__)],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    assert " passed" in p.stdout and "1 skipped" in p.stdout
