@@ -54,8 +54,8 @@ struct ivx_join_plan {
     u32 chunk = 0, nblk = 0;
     // one-pass routing (ivx_join_regions.hip): the rows sit in pages; hist = first routed row of every region,
     // ptab = [region][page slot] -> page + 1
-    bool paged = false;
-    const u32 *ptab = nullptr; u32 pstride = 0, lgpg = 0;
+    bool paged = false, packed = false;   // packed: 8-byte routed rows (start in region | length | row), else (start,end) + row id
+    const u32 *ptab = nullptr; u32 pstride = 0, lgpg = 0, rowbits = 32;
 };
 
 struct ivx_ctx {
@@ -122,7 +122,8 @@ struct ivx_ent { i32 s, e; u32 row; };          // 12-byte AoS entry of the over
 // header words written by the layout kernel (device resident, read by probes)
 enum { HDR_SH0 = 0, HDR_NLEV = 1, HDR_NBINS = 2, HDR_CS = 3 /* log2(cells per region) or ~0u */, HDR_NREG = 4,
        HDR_RCELLS = 5 /* cells per region */, HDR_RMUL_LO = 6, HDR_RMUL_HI = 7 /* ceil(2^40 / cells per region) */, HDR_LEVCNT = 8 /* .. +IVX_MAXL */,
-       HDR_FG = 8 + IVX_MAXL /* log2(block width) of the occupancy bitmap, or ~0u: no bitmap */, HDR_FBITS = 9 + IVX_MAXL /* its size in bits */, HDR_WORDS = 10 + IVX_MAXL };
+       HDR_FG = 8 + IVX_MAXL /* log2(block width) of the occupancy bitmap, or ~0u: no bitmap */, HDR_FBITS = 9 + IVX_MAXL /* its size in bits */,
+       HDR_PK24 = 10 + IVX_MAXL /* 1: a region spans at most 2^24 coordinates (routed rows pack into 8 bytes) */, HDR_WORDS = 11 + IVX_MAXL };
 // Occupancy bitmap of the build side ("can a probe row match anything at all"): per key one bit per 2^g-wide block of
 // [origin, origin + span] plus one overflow block behind it; a bit is set when some build row touches the block.  Sized to
 // stay resident in an XCD's 4 MiB L2 next to the streamed probe rows.
@@ -138,7 +139,7 @@ enum { HDR_SH0 = 0, HDR_NLEV = 1, HDR_NBINS = 2, HDR_CS = 3 /* log2(cells per re
 #define IVX_RP_ECAP 6144          // level-0 entries a region's LDS slice holds (ivx_join_regions.hip)
 #endif
 #define IVX_RP_HALO 8u      // slice cells past the region's last cell
-struct ivx_regdesc { u32 k; i32 origin; u32 span, lb, slo, shi, e0, ne; };
+struct ivx_regdesc { u32 k; i32 origin; u32 span, lb, slo, shi, e0, ne; i32 rbase; /* coordinate of the region's first cell */ };
 
 struct JoinIndexView {
     const i32 *origin;      // [nkeys] smallest start of the key
@@ -199,6 +200,7 @@ struct ivx_index {
     JoinIndexView jv{};
     u32 jv_nreg = 0;            // >0: the region-partitioned probe is available
     bool jv_filter = false;     // jv carries an occupancy bitmap (hdr[HDR_FG] != ~0u)
+    bool jv_pk24 = false;       // hdr[HDR_PK24]
     RankGridView gs{}, ge{};
     CoverageView cv{};
     NearestView nv{};
@@ -227,7 +229,7 @@ enum { JP_COUNT = 0, JP_PER_ROW = 1, JP_EXISTS = 2, JP_FILL = 3 };
 // join_regions.hip: partition the probe rows by index region, probe each region from LDS
 ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nreg, int mode,
                                   const u32 *key, const i32 *s, const i32 *e, u64 n,
-                                  u32 *ob, u32 *op, u64 cap, u64 *d_cursor, bool planned = false, bool has_filter = false);
+                                  u32 *ob, u32 *op, u64 cap, u64 *d_cursor, bool planned = false, bool has_filter = false, bool pk24 = false);
 
 // per-row-output operators through the same partition (count_overlaps: jv over the build rows, no row with
 // end < start; coverage: jv over the merged nodes)

@@ -249,6 +249,7 @@ __global__ __launch_bounds__(1024) void k_join_layout(const i32 *kmin, const i32
         hdr[HDR_RCELLS] = (u32)(R > 0xFFFFFFFFull ? 0xFFFFFFFFull : R);
         const u64 M = R ? ((1ull << 40) + R - 1) / R : 0;
         hdr[HDR_RMUL_LO] = (u32)M; hdr[HDR_RMUL_HI] = (u32)(M >> 32);
+        hdr[HDR_PK24] = (R && sh0 < 24 && R <= (1ull << (24 - sh0))) ? 1u : 0u;
     }
 }
 
@@ -271,6 +272,7 @@ __global__ __launch_bounds__(256) void k_join_regdesc(const i32 *origin, const u
     d.shi = rc1 + IVX_RP_HALO < cells0 ? rc1 + IVX_RP_HALO : cells0;
     d.e0 = binstart[d.lb + d.slo];
     d.ne = binstart[d.lb + d.shi] - d.e0;
+    d.rbase = (i32)((i64)d.origin + (i64)(rc0w << sh0));           // (rc0 < cells0: at most the key's largest start)
     rdesc[r] = d;
 }
 
@@ -586,6 +588,7 @@ ivx_status ivx_join_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32
     if (*(u32 *)(ctx->h_scalars + 8)) return ctx->fail(IVX_ERR_INVALID, "build key id >= n_keys");
     ix->jv_nreg = ((const u32 *)(ctx->h_scalars + 32))[HDR_NREG];
     ix->jv_filter = ((const u32 *)(ctx->h_scalars + 32))[HDR_FG] != 0xFFFFFFFFu;
+    ix->jv_pk24 = ((const u32 *)(ctx->h_scalars + 32))[HDR_PK24] != 0;
     if (want_route) ivx_route_view_ready(ctx, ix);
 
     ix->jv.origin = origin; ix->jv.span = span; ix->jv.kcnt = kcnt; ix->jv.lbase = lbase;

@@ -290,7 +290,7 @@ __global__ __launch_bounds__(PA_T) void k_part_scatter(JoinIndexView ix, const u
 struct KeyTab2 {
     const i32 *s_origin; const u32 *s_span, *s_kreg, *s_fbase;      // LDS; kreg = 0xFFFFFFFF: key has no build rows
     const u32 *fbits;
-    u32 nkeys, sh0, cs, fg;
+    u32 nkeys, sh0, cs, fg, rcells;
     u64 rmul;
 };
 
@@ -299,6 +299,7 @@ __device__ __forceinline__ void keytab2_load(const JoinIndexView &ix, i32 *s_ori
 {
     kt.nkeys = ix.nkeys; kt.sh0 = ix.hdr[HDR_SH0]; kt.cs = ix.hdr[HDR_CS]; kt.fg = use_filter ? ix.hdr[HDR_FG] : 0xFFFFFFFFu;
     kt.rmul = (u64)ix.hdr[HDR_RMUL_LO] | ((u64)ix.hdr[HDR_RMUL_HI] << 32);
+    kt.rcells = ix.hdr[HDR_RCELLS];
     kt.fbits = ix.fbits;
     if (KLDS) {
         for (u32 k = threadIdx.x; k < ix.nkeys; k += blockDim.x) {
@@ -317,8 +318,19 @@ __device__ __forceinline__ void keytab2_load(const JoinIndexView &ix, i32 *s_ori
 //                (0x3F blocks-1 = more than 32 blocks: not tested)
 //   route_test   whether any block of the window is set, given the 8 bytes that start at the 4-byte word holding the
 //                window's first bit (up to 32 blocks always fit)
-template <bool KLDS, bool FILT>
-__device__ __forceinline__ u32 route_prep(const JoinIndexView &ix, const KeyTab2 &kt, u32 k, i32 qs, i32 qe, u32 &fpos)
+// PK (8-byte routed rows, hdr[HDR_PK24]): a routed row is ONE word,
+//     bits  0..23  start inside its region          bits 24..31  length (end - start), low 8 bits
+//     bits 32..    row id (rowbits bits)             bits 32+rowbits..63  length, the bits above the low 8
+// so the fewer rows a batch has, the longer a row may be (100 M rows: 27 bits of row id, lengths up to 8190).  A length
+// field of all ones marks a row that does not fit -- it starts outside its region's coordinates (before the key's first
+// or behind its last start), is too long, or has end < start: the probe reads such a row's coordinates from the input
+// columns by its row id.  `packed` = start | length << 24 as a 64-bit value, or PK_ESCAPE.
+constexpr u64 PK_ESCAPE = ~0ull;
+// the length field's all-ones value: 8 bits plus the row id's spare bits, at most 16 (the host passes rowbits = 32, i.e. no
+// spare bits, when the occupancy bitmap is in use: the partition kernel then has no register to carry the upper bits in)
+__host__ __device__ __forceinline__ u32 pk_maxlen(u32 rowbits) { const u32 spare = rowbits >= 32 ? 0u : 32u - rowbits; return (1u << (8u + (spare > 8u ? 8u : spare))) - 1u; }
+template <bool KLDS, bool FILT, bool PK>
+__device__ __forceinline__ u32 route_prep(const JoinIndexView &ix, const KeyTab2 &kt, u32 k, i32 qs, i32 qe, u32 &fpos, u64 &packed, u32 maxlen)
 {
     const bool kok = k < kt.nkeys;
     const u32 kk = kok ? k : 0u;
@@ -341,8 +353,16 @@ __device__ __forceinline__ u32 route_prep(const JoinIndexView &ix, const KeyTab2
     const u32 last = span >> kt.sh0;
     const i64 c64 = d <= 0 ? 0 : (d >> kt.sh0);
     const u32 c = c64 > (i64)last ? last : (u32)c64;
-    const u32 reg = kreg + (kt.cs != 0xFFFFFFFFu ? c >> kt.cs : (u32)(((u64)c * kt.rmul) >> 40));
-    return ok ? reg : NO_REGION;
+    const u32 rin = kt.cs != 0xFFFFFFFFu ? c >> kt.cs : (u32)(((u64)c * kt.rmul) >> 40);    // region inside the key
+    packed = PK_ESCAPE;
+    if (PK) {
+        // 32-bit arithmetic is exact here: for d >= 0 the region's first coordinate (rin * R << sh0 <= span) is at most d,
+        // and for end >= start the length is below 2^32
+        const u32 rel = (u32)d - ((rin * kt.rcells) << kt.sh0);
+        const u32 len = (u32)qe - (u32)qs;
+        if (d >= 0 && rel < (1u << 24) && qe >= qs && len < maxlen) packed = (u64)rel | ((u64)len << 24);
+    }
+    return ok ? kreg + rin : NO_REGION;
 }
 
 __device__ __forceinline__ bool route_test(u32 fpos, u64 win)
@@ -386,19 +406,24 @@ __device__ __forceinline__ void load4nt(const u32 *__restrict__ pkey, const i32 
     }
 }
 
-// ND digits (256 / 1024), I rows per thread and tile (tile = 1024 * I rows <= one page)
-template <bool VEC, int ND, int I, bool KLDS, bool FILT>
-__global__ __launch_bounds__(PA_T) void k_part_onepass(JoinIndexView ix, const u32 *__restrict__ pkey, const i32 *__restrict__ ps,
+// ND digits (256 / 1024), T threads, I rows per thread and tile (tile = T * I rows <= one page).  Packed rows need no
+// slot array in LDS: two 512-thread workgroups with 8192-row tiles then share a CU, and one's loads overlap the other's
+// LDS phases (the kernel is bound by those phases, not by HBM: 8-byte instead of 12-byte rows alone changed nothing)
+// PK: a routed row is ONE 8-byte word, (start inside its region | length) and the row id (route_prep), instead of
+// (start, end) in one array and the row id in another: a third fewer bytes written here and read by the probe
+template <bool VEC, int ND, int I, bool KLDS, bool FILT, bool PK, int T = PA_T>
+__global__ __launch_bounds__(T, 4) void k_part_onepass(JoinIndexView ix, const u32 *__restrict__ pkey, const i32 *__restrict__ ps,
                                                        const i32 *__restrict__ pe, u64 n, u32 chunk, u32 *__restrict__ rcur, PageTab pt,
-                                                       u32 *pool_next, u64 *__restrict__ out_se, u32 *__restrict__ out_row)
+                                                       u32 *pool_next, u64 *__restrict__ out_se, u32 *__restrict__ out_row, u32 rowbits)
 {
-    constexpr int TILE = PA_T * I;
+    constexpr int TILE = T * I;
+    static_assert(ND <= T, "one thread per region");
     __shared__ u64 r_se[TILE];
-    __shared__ unsigned short r_slot[TILE];
+    __shared__ unsigned short r_slot[PK ? 1 : TILE];            // (packed rows carry their row id with them)
     using DigT = typename std::conditional<(ND > 256), unsigned short, unsigned char>::type;
     __shared__ DigT r_dig[TILE];
     __shared__ u32 dstart[ND], vbase[ND], pg0[ND];
-    __shared__ u32 scan_lds[PA_T / IVX_WAVE + 1];
+    __shared__ u32 scan_lds[T / IVX_WAVE + 1];
     __shared__ i32 s_origin[KT_MAX];
     __shared__ u32 s_span[KT_MAX], s_kreg[KT_MAX], s_fbase[KT_MAX];
 
@@ -411,17 +436,21 @@ __global__ __launch_bounds__(PA_T) void k_part_onepass(JoinIndexView ix, const u
     for (u64 t0 = lo; t0 < hi; t0 += TILE) {
         if (tid < ND) dstart[tid] = 0;
         __syncthreads();
-        u64 se[I]; u32 dig[I], lrank[I];
-        {
-            // all of the tile's row loads first, then all of its bitmap gathers: straight-line code (no per-row branches),
-            // so that the loads of a stage are in flight together
-            u32 kk[I]; i32 qs[I], qe[I];
+        u64 se[PK ? 1 : I]; u32 plo[PK ? I : 1], dig[I];     // PK: low word of the packed row (the length's bits above its low 8 ride in dig)
+        // the tile's rows in chunks of CH per thread (all of them, or eight at a time when a thread holds sixteen: the raw
+        // columns of sixteen rows plus their routed form do not fit the registers)
+        constexpr int CH = (I % 8 == 0 && I > 8) ? 8 : I;
+#pragma unroll
+        for (int c0 = 0; c0 < I; c0 += CH) {
+            // a chunk's row loads first, then all of its bitmap gathers: straight-line code (no per-row branches), so that
+            // the loads of a stage are in flight together
+            u32 kk[CH]; i32 qs[CH], qe[CH];
             if (VEC && t0 + TILE <= hi) {
                 typedef u32 __attribute__((ext_vector_type(4))) v4u;
                 typedef i32 __attribute__((ext_vector_type(4))) v4i;
 #pragma unroll
-                for (int v = 0; v < I / 4; v++) {
-                    const u64 i = t0 + ((u64)v * PA_T + tid) * 4;
+                for (int v = 0; v < CH / 4; v++) {
+                    const u64 i = t0 + ((u64)(c0 / 4 + v) * T + tid) * 4;
                     const v4u kv = pkey ? __builtin_nontemporal_load(reinterpret_cast<const v4u *>(pkey + i)) : v4u{0u, 0u, 0u, 0u};
                     const v4i sv = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(ps + i));
                     const v4i ev = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(pe + i));
@@ -431,46 +460,63 @@ __global__ __launch_bounds__(PA_T) void k_part_onepass(JoinIndexView ix, const u
                 }
             } else {
 #pragma unroll
-                for (int v = 0; v < I / 4; v++) {
+                for (int v = 0; v < CH / 4; v++) {
                     u32 k4[4]; i32 s4[4], e4[4];
-                    load4nt<false>(pkey, ps, pe, t0 + ((u64)v * PA_T + tid) * 4, hi, k4, s4, e4);
+                    load4nt<false>(pkey, ps, pe, t0 + ((u64)(c0 / 4 + v) * T + tid) * 4, hi, k4, s4, e4);
 #pragma unroll
                     for (int j = 0; j < 4; j++) { kk[v * 4 + j] = k4[j]; qs[v * 4 + j] = s4[j]; qe[v * 4 + j] = e4[j]; }
                 }
             }
-            u32 fpos[I];
+            u32 fpos[CH];
 #pragma unroll
-            for (int k = 0; k < I; k++) {
-                se[k] = (u64)(u32)qs[k] | ((u64)(u32)qe[k] << 32);
-                dig[k] = route_prep<KLDS, FILT>(ix, kt, kk[k], qs[k], qe[k], fpos[k]);
+            for (int k = 0; k < CH; k++) {
+                u64 packed;
+                const u32 maxlen = pk_maxlen(rowbits);
+                dig[c0 + k] = route_prep<KLDS, FILT, PK>(ix, kt, kk[k], qs[k], qe[k], fpos[k], packed, maxlen);
+                if (PK) {
+                    const u32 lenf = packed == PK_ESCAPE ? maxlen : (u32)(packed >> 24);
+                    plo[PK ? c0 + k : 0] = (packed == PK_ESCAPE ? 0u : (u32)packed & 0xFFFFFFu) | (lenf << 24);
+                    fpos[k] = FILT ? fpos[k] : (lenf >> 8);       // (parked until the row's rank is known; with the bitmap in use lengths keep to 8 bits)
+                } else se[PK ? 0 : c0 + k] = (u64)(u32)qs[k] | ((u64)(u32)qe[k] << 32);
             }
             if (FILT) {
-                u64 win[I];
+                u64 win[CH];
 #pragma unroll
-                for (int k = 0; k < I; k++) __builtin_memcpy(&win[k], kt.fbits + ((fpos[k] & 0x3FFFFFFu) >> 5), sizeof(u64));
+                for (int k = 0; k < CH; k++) __builtin_memcpy(&win[k], kt.fbits + ((fpos[k] & 0x3FFFFFFu) >> 5), sizeof(u64));
 #pragma unroll
-                for (int k = 0; k < I; k++) dig[k] = route_test(fpos[k], win[k]) ? dig[k] : NO_REGION;
+                for (int k = 0; k < CH; k++) dig[c0 + k] = route_test(fpos[k], win[k]) ? dig[c0 + k] : NO_REGION;
             }
-        }
 #pragma unroll
-        for (int k = 0; k < I; k++) lrank[k] = lds_count_up(dstart, dig[k], dig[k] != NO_REGION);
+            for (int k = 0; k < CH; k++) {                      // region and rank share a register from here on (10 + 14 bits)
+                const u32 lr = lds_count_up(dstart, dig[c0 + k], dig[c0 + k] != NO_REGION);
+                const u32 lhi = (PK && !FILT) ? fpos[k] << 24 : 0u;
+                dig[c0 + k] = dig[c0 + k] == NO_REGION ? NO_REGION : (dig[c0 + k] | (lr << 10) | lhi);
+            }
+            if (CH != I) asm volatile("" ::: "memory");         // (keeps the next chunk's loads from being hoisted above this chunk's work)
+        }
         __syncthreads();
         // ---- reserve the tile's run in every region's row stream; take / look up the pages it touches
         const u32 mine = tid < ND ? dstart[tid] : 0u;
         u32 v = 0;
         if (mine) v = atomicAdd(&rcur[tid], mine);
         u32 tot;
-        const u32 ds = block_excl_scan<u32, PA_T>(mine, scan_lds, &tot);     // (barriers inside: every counter is read before any is overwritten)
+        const u32 ds = block_excl_scan<u32, T>(mine, scan_lds, &tot);     // (barriers inside: every counter is read before any is overwritten)
         if (tid < ND) dstart[tid] = ds;
         __syncthreads();
         // (the returned v is first needed after the LDS re-order below, which runs while the atomics are in flight)
 #pragma unroll
         for (int k = 0; k < I; k++) {
             if (dig[k] != NO_REGION) {
-                const u32 pos = dstart[dig[k]] + lrank[k];
-                r_se[pos] = se[k];
-                r_slot[pos] = (unsigned short)(((k / 4) * PA_T + tid) * 4 + (k % 4));
-                r_dig[pos] = (DigT)dig[k];
+                const u32 d = dig[k] & 1023u;
+                const u32 pos = dstart[d] + ((dig[k] >> 10) & 0x3FFFu);
+                if (PK) {
+                    const u32 row = (u32)(t0 + (u32)(((k / 4) * T + tid) * 4 + (k % 4)));
+                    r_se[pos] = (u64)plo[PK ? k : 0] | ((u64)(row | (rowbits < 32 ? (dig[k] >> 24) << rowbits : 0u)) << 32);
+                } else {
+                    r_se[pos] = se[PK ? 0 : k];
+                    r_slot[pos] = (unsigned short)(((k / 4) * T + tid) * 4 + (k % 4));
+                }
+                r_dig[pos] = (DigT)d;
             }
         }
         if (mine) {
@@ -489,7 +535,7 @@ __global__ __launch_bounds__(PA_T) void k_part_onepass(JoinIndexView ix, const u
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < I; k++) {
-            const u32 j = k * PA_T + tid;
+            const u32 j = k * T + tid;
             if (j < tot) {
                 const u32 d = r_dig[j];
                 const u32 x = vbase[d] + (j - dstart[d]);                       // virtual row number in region d
@@ -497,7 +543,7 @@ __global__ __launch_bounds__(PA_T) void k_part_onepass(JoinIndexView ix, const u
                 if ((x >> pt.lgpg) != (vbase[d] >> pt.lgpg)) pg = page_wait(pt.ptab + (u64)d * pt.pstride + (x >> pt.lgpg));   // the run's second page
                 const u64 g = ((u64)pg << pt.lgpg) + (x & pmask);
                 out_se[g] = r_se[j];
-                out_row[g] = (u32)(t0 + r_slot[j]);
+                if (!PK) out_row[g] = (u32)(t0 + r_slot[j]);
             }
         }
         __syncthreads();
@@ -547,6 +593,7 @@ struct Slice {
     const unsigned short *s_off; const u64 *s_ent; const u32 *s_row;
     u32 sh0, nlev, k, lb, slo, shi, e0, ncell0; bool inlds, upper, lev0;
     i32 origin; u32 span;
+    i32 rbase;                  // coordinate of the region's first cell (packed rows hold their start relative to it)
 };
 
 // every match of one probe row: f(v, is_slot, start, end) -- v is a slot of the staged slice (build row =
@@ -636,7 +683,7 @@ __device__ __forceinline__ void slice_load(const JoinIndexView &ix, Slice &S, co
     const ivx_regdesc d = ix.rdesc[r];                                  // built by k_join_regdesc
     S.k = d.k; S.origin = d.origin; S.span = d.span; S.lb = d.lb;
     S.ncell0 = (S.span >> S.sh0) + 1u;
-    S.slo = d.slo; S.shi = d.shi; S.e0 = d.e0;
+    S.slo = d.slo; S.shi = d.shi; S.e0 = d.e0; S.rbase = d.rbase;
     const u32 ne = d.ne;
     const u32 nc = S.shi - S.slo + 1u;
     S.inlds = ne <= RP_ECAP && nc <= RP_CCAP;
@@ -838,15 +885,21 @@ __global__ void k_pick_rows(const u32 *__restrict__ rfirst, u32 nreg, u64 hint, 
     *bsel = force ? force : per_row <= 0.45f ? 8u : per_row <= 0.9f ? 4u : per_row <= 1.8f ? 2u : 1u;
 }
 
-template <int MODE, int B, bool IDENT, bool PAGED = false>
+template <int MODE, int B, bool IDENT, bool PAGED = false, bool PK = false>
 __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const void *__restrict__ rows_a, const void *__restrict__ rows_b,
                                                         const u32 *__restrict__ offs, u32 nblk, u32 vpb,
                                                         u32 *__restrict__ ob, u32 *__restrict__ op, u64 cap,
                                                         unsigned long long *cursor, u32 prow_stride, u32 adj,
                                                         const u32 *unsorted, int dbg, PageTab pt = PageTab{nullptr, 0u, 0u},
-                                                        const u32 *bsel = nullptr)
+                                                        const u32 *bsel = nullptr, const i32 *__restrict__ ps_in = nullptr, const i32 *__restrict__ pe_in = nullptr,
+                                                        u32 rowbits = 32)
 {
     constexpr bool FILL = MODE == 1;
+    const u32 rowmask = rowbits >= 32 ? 0xFFFFFFFFu : (1u << rowbits) - 1u;
+    const u32 maxlen = pk_maxlen(rowbits);
+    static_assert(!PK || PAGED, "packed rows come from the one-pass partition");
+    // PK: rows_a holds 8-byte words (start inside the region | length << 24, row id << 32; PK_ESCAPE: the coordinates are
+    // read from the input columns ps_in / pe_in by the row id); rows_b is not used
     if (bsel != nullptr && *bsel != (u32)B) return;                   // (every B is launched; k_pick_rows chose one)
     // IDENT: the input already is in region order (k_part_hist left `unsorted` at 0): the partitioned arrays
     // were never written and row i IS input row i.  Both instantiations are launched; the one whose case
@@ -929,7 +982,7 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
                     const u64 i = b0 + (u64)q * (RP_W * IVX_WAVE) + ln;
                     const u64 at = i < c_hi ? row_at(i, r, rf) : 0;
                     nx[q] = i < c_hi ? row_se(at) : 0;
-                    nxr[q] = (FILL && i < c_hi) ? row_id(i, at) : 0u;
+                    nxr[q] = (FILL && !PK && i < c_hi) ? row_id(i, at) : 0u;
                 }
                 slice_load(ix, S, L, r, r != loaded_r);
                 loaded_r = r;
@@ -938,8 +991,25 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
                     u32 okmask = 0;
 #pragma unroll
                     for (int q = 0; q < B; q++) {
-                        qs[q] = (i32)(u32)nx[q]; qe[q] = (i32)(u32)(nx[q] >> 32); rowv[q] = nxr[q];
+                        if (PK) {
+                            const u32 lo32 = (u32)nx[q], hi32 = (u32)(nx[q] >> 32);
+                            const u32 len = (lo32 >> 24) | ((rowbits < 32 ? (hi32 >> rowbits) & 0xFFu : 0u) << 8);
+                            qs[q] = (i32)((u32)S.rbase + (lo32 & 0xFFFFFFu)); qe[q] = (i32)((u32)qs[q] + len); rowv[q] = hi32 & rowmask;
+                            nxr[q] = len;                               // (kept for the escape test below; the row id prefetch slot is free here)
+                        } else { qs[q] = (i32)(u32)nx[q]; qe[q] = (i32)(u32)(nx[q] >> 32); rowv[q] = nxr[q]; }
                         if (b0 + (u64)q * (RP_W * IVX_WAVE) + ln < c_hi) okmask |= 1u << q;
+                    }
+                    if (PK) {                                           // rows that did not fit the packed form (rare)
+                        u32 esc = 0;
+#pragma unroll
+                        for (int q = 0; q < B; q++) if (((okmask >> q) & 1u) && nxr[q] == maxlen) esc |= 1u << q;
+                        if (__any(esc != 0)) {                          // all the gathers first, then their uses: one round trip, not 2 * B
+                            i32 ts[B], te[B];
+#pragma unroll
+                            for (int q = 0; q < B; q++) { const u32 rr = ((esc >> q) & 1u) ? rowv[q] : 0u; ts[q] = ps_in[rr]; te[q] = pe_in[rr]; }
+#pragma unroll
+                            for (int q = 0; q < B; q++) if ((esc >> q) & 1u) { qs[q] = (i32)((u32)ts[q] + adj); qe[q] = (i32)((u32)te[q] - adj); }
+                        }
                     }
                     {
                         const u64 b1 = b0 + (u64)RP_W * WB;
@@ -948,7 +1018,7 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
                             const u64 i = b1 + (u64)q * (RP_W * IVX_WAVE) + ln;
                             const u64 at = i < c_hi ? row_at(i, r, rf) : 0;
                             nx[q] = i < c_hi ? row_se(at) : 0;
-                            nxr[q] = (FILL && i < c_hi) ? row_id(i, at) : 0u;
+                            nxr[q] = (FILL && !PK && i < c_hi) ? row_id(i, at) : 0u;
                         }
                     }
                     if (MODE >= RV_COUNT) {
@@ -998,12 +1068,15 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
 //   PASS 1  the piece is walked again in lock step (every lane steps through its candidates together); the lanes
 //           that match in a step take consecutive positions after the piece's running offset by ballot rank, so
 //           the stores of a step are contiguous.  Order inside a piece is arbitrary, like everywhere else.
-template <int PASS, bool IDENT, bool PAGED = false>
+template <int PASS, bool IDENT, bool PAGED = false, bool PK = false>
 __global__ __launch_bounds__(RP_T) void k_probe_dense(JoinIndexView ix, const void *__restrict__ rows_a, const void *__restrict__ rows_b,
                                                       const u32 *__restrict__ offs, u32 nblk, u32 prow_stride, const u32 *unsorted,
                                                       u64 *__restrict__ pcount, u32 *__restrict__ ob, u32 *__restrict__ op, u64 cap,
-                                                      PageTab pt = PageTab{nullptr, 0u, 0u})
+                                                      PageTab pt = PageTab{nullptr, 0u, 0u}, const i32 *__restrict__ ps_in = nullptr, const i32 *__restrict__ pe_in = nullptr,
+                                                      u32 rowbits = 32)
 {
+    const u32 rowmask = rowbits >= 32 ? 0xFFFFFFFFu : (1u << rowbits) - 1u;
+    const u32 maxlen = pk_maxlen(rowbits);
     if ((unsorted != nullptr && *unsorted == 0) != IDENT) return;
     static_assert(!(IDENT && PAGED), "paged rows are never read in place");
     __shared__ u32 s_pg[RP_NPG];
@@ -1063,14 +1136,21 @@ __global__ __launch_bounds__(RP_T) void k_probe_dense(JoinIndexView ix, const vo
         const u64 rf = PAGED ? rfirst(r) : 0;
         pages_load(lo, c_hi, r, rf);
         const u64 g1 = (c_hi + 63) >> 6;
-        { const u64 i = g * 64 + ln; const bool ok = g < g1 && i >= lo && i < c_hi; const u64 at = ok ? row_at(i, r, rf) : 0; nx = ok ? row_se(at) : 0; nxr = (PASS == 1 && ok) ? row_id(i, at) : 0u; }
+        { const u64 i = g * 64 + ln; const bool ok = g < g1 && i >= lo && i < c_hi; const u64 at = ok ? row_at(i, r, rf) : 0; nx = ok ? row_se(at) : 0; nxr = (PASS == 1 && !PK && ok) ? row_id(i, at) : 0u; }
         slice_load(ix, S, L, r, true);
         for (; g < g1; g += RP_W) {
             const u64 i = g * 64 + ln;
             const bool ok = i >= lo && i < c_hi;
-            const i32 qs = (i32)(u32)nx, qe = (i32)(u32)(nx >> 32);
-            const u32 rowv = nxr;
-            { const u64 g2 = g + RP_W; const u64 i2 = g2 * 64 + ln; const bool ok2 = g2 < g1 && i2 >= lo && i2 < c_hi; const u64 at = ok2 ? row_at(i2, r, rf) : 0; nx = ok2 ? row_se(at) : 0; nxr = (PASS == 1 && ok2) ? row_id(i2, at) : 0u; }
+            i32 qs = (i32)(u32)nx, qe = (i32)(u32)(nx >> 32);
+            u32 rowv = nxr;
+            if (PK) {
+                const u32 lo32 = (u32)nx, hi32 = (u32)(nx >> 32);
+                const u32 len = (lo32 >> 24) | ((rowbits < 32 ? (hi32 >> rowbits) & 0xFFu : 0u) << 8);
+                rowv = hi32 & rowmask;
+                qs = (i32)((u32)S.rbase + (lo32 & 0xFFFFFFu)); qe = (i32)((u32)qs + len);
+                if (ok && len == maxlen) { qs = ps_in[rowv]; qe = pe_in[rowv]; }
+            }
+            { const u64 g2 = g + RP_W; const u64 i2 = g2 * 64 + ln; const bool ok2 = g2 < g1 && i2 >= lo && i2 < c_hi; const u64 at = ok2 ? row_at(i2, r, rf) : 0; nx = ok2 ? row_se(at) : 0; nxr = (PASS == 1 && !PK && ok2) ? row_id(i2, at) : 0u; }
             const u64 slot = g + r;
             if (PASS == 0) {
                 u32 c = 0;
@@ -1499,7 +1579,7 @@ static bool dense_fill_wanted(u64 cap, u64 n)
 
 ivx_status dense_fill(ivx_ctx *ctx, const JoinIndexView &jv, u32 nreg, const void *rows_se, const void *rows_id, u32 prow_stride,
                       const i32 *s, const i32 *e, const u32 *offs, u32 nblk, const u32 *unsorted, u64 n,
-                      u32 *ob, u32 *op, u64 cap, u64 *d_cursor, const PageTab *pt = nullptr)
+                      u32 *ob, u32 *op, u64 cap, u64 *d_cursor, const PageTab *pt = nullptr, bool packed = false, u32 rowbits = 32)
 {
     hipStream_t st = ctx->stream;
     const u64 slots = (n >> 6) + nreg + 3;
@@ -1507,6 +1587,7 @@ ivx_status dense_fill(ivx_ctx *ctx, const JoinIndexView &jv, u32 nreg, const voi
     IVX_TRY(ctx->get_scratch(WS_T3, slots * sizeof(u64), (void **)&pcount));
     IVX_HIP(ctx, hipMemsetAsync(pcount, 0, slots * sizeof(u64), st));
 #define IVX_DENSE_PASS(P_) do { \
+        if (pt && packed) { hipLaunchKernelGGL((k_probe_dense<P_, false, true, true>), dim3(RP_VGRID), dim3(RP_T), 0, st, jv, rows_se, rows_id, offs, nblk, prow_stride, unsorted, pcount, ob, op, cap, *pt, s, e, rowbits); break; } \
         if (pt) { hipLaunchKernelGGL((k_probe_dense<P_, false, true>), dim3(RP_VGRID), dim3(RP_T), 0, st, jv, rows_se, rows_id, offs, nblk, prow_stride, unsorted, pcount, ob, op, cap, *pt); break; } \
         hipLaunchKernelGGL((k_probe_dense<P_, false>), dim3(RP_VGRID), dim3(RP_T), 0, st, jv, rows_se, rows_id, offs, nblk, prow_stride, unsorted, pcount, ob, op, cap); \
         if (unsorted) hipLaunchKernelGGL((k_probe_dense<P_, true>), dim3(RP_VGRID), dim3(RP_T), 0, st, jv, (const void *)s, (const void *)e, offs, nblk, 1u, unsorted, pcount, ob, op, cap); } while (0)
@@ -1600,7 +1681,7 @@ ivx_status probe_two_level(ivx_ctx *ctx, const JoinIndexView &jv, int mode, u32 
 
 ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nreg, int mode,
                                   const u32 *key, const i32 *s, const i32 *e, u64 n,
-                                  u32 *ob, u32 *op, u64 cap, u64 *d_cursor, bool planned, bool has_filter)
+                                  u32 *ob, u32 *op, u64 cap, u64 *d_cursor, bool planned, bool has_filter, bool pk24)
 {
     if (n == 0) return IVX_OK;
     ivx_join_plan &pl = ctx->join_plan;
@@ -1617,43 +1698,56 @@ ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nre
     if ((planned && pl.paged) || (!planned && !two_pass)) {
         const bool wide = nreg > IVX_MAXREG;
         PageTab pt; const u32 *rfirst; const u64 *pool_se; const u32 *pool_row;
+        // 8-byte routed rows whenever a region's coordinates fit 24 bits (IVX_PACK=0: the 12-byte form, for A/B runs and tests)
+        const bool pack_off = getenv("IVX_PACK") && !strcmp(getenv("IVX_PACK"), "0");
+        bool packed = pk24 && !pack_off;
+        u32 rowbits = 1;
+        while (rowbits < 32 && (n - 1) >> rowbits) rowbits++;          // bits of the largest row id (the rest of the word's upper half extends the length)
         if (planned) {
+            rowbits = pl.rowbits;
             pt = PageTab{const_cast<u32 *>(pl.ptab), pl.pstride, pl.lgpg};
-            rfirst = pl.hist; pool_se = pl.pse; pool_row = pl.prow;
+            rfirst = pl.hist; pool_se = pl.pse; pool_row = pl.prow; packed = pl.packed;
+            s = pl.ds; e = pl.de;                                       // (the columns the count call read: packed rows refer to them)
         } else {
             u32 lgpg = 14;                                              // a page holds at least a tile; at most ~4096 pages per region
             while (lgpg < 31 && (n >> lgpg) > 4096) lgpg++;
             const u64 pstride = (n >> lgpg) + 2;
             const u64 npages = (n >> lgpg) + nreg + 1;
-            u32 *ctl, *ptab; u64 *pse; u32 *prow;
+            u32 *ctl, *ptab; u64 *pse; u32 *prow = nullptr;
             IVX_TRY(ctx->get_scratch(WS_SORTHIST, (1024 + 8 + 1032) * sizeof(u32), (void **)&ctl));   // rcur[1024] | pool_next | .. | rfirst[<= 1025]
             IVX_TRY(ctx->get_scratch(WS_T2, (size_t)nreg * pstride * sizeof(u32), (void **)&ptab));
             IVX_TRY(ctx->get_scratch(WS_T0, (size_t)(npages << lgpg) * sizeof(u64), (void **)&pse));
-            IVX_TRY(ctx->get_scratch(WS_T1, (size_t)(npages << lgpg) * sizeof(u32), (void **)&prow));
+            if (!packed) IVX_TRY(ctx->get_scratch(WS_T1, (size_t)(npages << lgpg) * sizeof(u32), (void **)&prow));
             IVX_HIP(ctx, hipMemsetAsync(ctl, 0, (1024 + 8) * sizeof(u32), st));
             IVX_HIP(ctx, hipMemsetAsync(ptab, 0, (size_t)nreg * pstride * sizeof(u32), st));
             pt = PageTab{ptab, (u32)pstride, lgpg};
             u32 *rcur = ctl, *pool_next = ctl + 1024, *rf = ctl + 1032;
             const bool vec = (((uintptr_t)key | (uintptr_t)s | (uintptr_t)e) & 15) == 0;
-            const u32 tile = wide ? PA_T * 8u : PA_T * 12u;
+            const bool half = packed && !wide;                          // two 512-thread workgroups per CU, 8192-row tiles
+            const u32 tile = wide ? PA_T * 8u : half ? 512u * 16u : PA_T * 12u;
             const u32 tiles = n >= (16u << 20) ? 4u : n >= (4u << 20) ? 2u : 1u;
             const u32 chunk1 = tile * tiles;
             const u32 nblk1 = (u32)((n + chunk1 - 1) / chunk1);
-#define IVX_ONEPASS3(V_, ND_, I_, K_, F_) hipLaunchKernelGGL((k_part_onepass<V_, ND_, I_, K_, F_>), dim3(nblk1), dim3(PA_T), 0, st, jv, key, s, e, n, chunk1, rcur, pt, pool_next, pse, prow)
+#define IVX_ONEPASS4(V_, ND_, I_, K_, F_, P_) hipLaunchKernelGGL((k_part_onepass<V_, ND_, I_, K_, F_, P_>), dim3(nblk1), dim3(PA_T), 0, st, jv, key, s, e, n, chunk1, rcur, pt, pool_next, pse, prow, rowbits)
+#define IVX_ONEPASS3(V_, ND_, I_, K_, F_) do { \
+        if (half) hipLaunchKernelGGL((k_part_onepass<V_, 256, 16, K_, F_, true, 512>), dim3(nblk1), dim3(512), 0, st, jv, key, s, e, n, chunk1, rcur, pt, pool_next, pse, prow, rowbits); \
+        else if (packed) IVX_ONEPASS4(V_, ND_, I_, K_, F_, true); else IVX_ONEPASS4(V_, ND_, I_, K_, F_, false); } while (0)
 #define IVX_ONEPASS2(V_, ND_, I_, K_) do { if (use_filter) IVX_ONEPASS3(V_, ND_, I_, K_, true); else IVX_ONEPASS3(V_, ND_, I_, K_, false); } while (0)
 #define IVX_ONEPASS(V_, ND_, I_) do { if (jv.nkeys <= KT_MAX) IVX_ONEPASS2(V_, ND_, I_, true); else IVX_ONEPASS2(V_, ND_, I_, false); } while (0)
             const bool filter_off = getenv("IVX_FILTER") && !strcmp(getenv("IVX_FILTER"), "0");   // experiments: IVX_FILTER=0 routes every row
             const bool use_filter = has_filter && !filter_off;
+            if (use_filter) rowbits = 32;                               // (see pk_maxlen)
             if (wide) { if (vec) IVX_ONEPASS(true, 1024, 8); else IVX_ONEPASS(false, 1024, 8); }
             else { if (vec) IVX_ONEPASS(true, 256, 12); else IVX_ONEPASS(false, 256, 12); }
 #undef IVX_ONEPASS2
 #undef IVX_ONEPASS3
+#undef IVX_ONEPASS4
 #undef IVX_ONEPASS
             hipLaunchKernelGGL(k_page_bounds, dim3(1), dim3(1024), 0, st, (const u32 *)rcur, nreg, rf);
             rfirst = rf; pool_se = pse; pool_row = prow;
             if (mode == JP_COUNT) {
                 pl.hist = rf; pl.pse = pse; pl.prow = prow; pl.ds = s; pl.de = e; pl.chunk = 0; pl.nblk = 1;
-                pl.paged = true; pl.ptab = ptab; pl.pstride = (u32)pstride; pl.lgpg = lgpg;
+                pl.paged = true; pl.packed = packed; pl.rowbits = rowbits; pl.ptab = ptab; pl.pstride = (u32)pstride; pl.lgpg = lgpg;
                 pl.slots = (1ull << WS_SORTHIST) | (1ull << WS_T0) | (1ull << WS_T1) | (1ull << WS_T2) | (1ull << WS_IN_START) | (1ull << WS_IN_END);
                 pl.valid = true;
             }
@@ -1662,14 +1756,18 @@ ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nre
         // the rows the probe walks are the routed ones: the density hint is pairs per INPUT row, as the caller sized it
         const u64 hint = planned && pl.total < cap ? pl.total : cap;
         if (mode == JP_FILL && dense_fill_wanted(hint, n))
-            return dense_fill(ctx, jv, nreg, (const void *)pool_se, (const void *)pool_row, 1u, nullptr, nullptr, rfirst, 1u, nullptr, n, ob, op, cap, d_cursor, &pt);
+            return dense_fill(ctx, jv, nreg, (const void *)pool_se, (const void *)pool_row, 1u, s, e, rfirst, 1u, nullptr, n, ob, op, cap, d_cursor, &pt, packed, rowbits);
         if (mode == JP_FILL) {
             u32 *bsel = (u32 *)(ctx->d_scalars + 11);
             const u32 force = getenv("IVX_RP_ROWS") ? (u32)atoi(getenv("IVX_RP_ROWS")) : 0u;
             hipLaunchKernelGGL(k_pick_rows, dim3(1), dim3(1), 0, st, rfirst, nreg, hint, force, bsel);
-#define IVX_FILLP(B_) hipLaunchKernelGGL((k_probe_regions<1, B_, false, true>), dim3(RP_GRID), dim3(RP_T), 0, st, jv, (const void *)pool_se, (const void *)pool_row, rfirst, 1u, RP_VGRID / RP_GRID, ob, op, cap, cur, 1u, 0u, (const u32 *)nullptr, 0, pt, (const u32 *)bsel)
+#define IVX_FILLP2(B_, P_) hipLaunchKernelGGL((k_probe_regions<1, B_, false, true, P_>), dim3(RP_GRID), dim3(RP_T), 0, st, jv, (const void *)pool_se, (const void *)pool_row, rfirst, 1u, RP_VGRID / RP_GRID, ob, op, cap, cur, 1u, 0u, (const u32 *)nullptr, 0, pt, (const u32 *)bsel, s, e, rowbits)
+#define IVX_FILLP(B_) do { if (packed) IVX_FILLP2(B_, true); else IVX_FILLP2(B_, false); } while (0)
             IVX_FILLP(8); IVX_FILLP(4); IVX_FILLP(2); IVX_FILLP(1);
 #undef IVX_FILLP
+#undef IVX_FILLP2
+        } else if (packed) {
+            hipLaunchKernelGGL((k_probe_regions<0, RP_B, false, true, true>), dim3(RP_VGRID), dim3(RP_T), 0, st, jv, (const void *)pool_se, (const void *)pool_row, rfirst, 1u, 1u, ob, op, cap, cur, 1u, 0u, (const u32 *)nullptr, 0, pt, (const u32 *)nullptr, s, e, rowbits);
         } else {
             hipLaunchKernelGGL((k_probe_regions<0, RP_B, false, true>), dim3(RP_VGRID), dim3(RP_T), 0, st, jv, (const void *)pool_se, (const void *)pool_row, rfirst, 1u, 1u, ob, op, cap, cur, 1u, 0u, (const u32 *)nullptr, 0, pt);
         }

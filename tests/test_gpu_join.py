@@ -36,12 +36,16 @@ def _check_join(ctx, bk, bs, be, pk, ps, pe, nkeys):
     # ... for the latter both ways of writing the pairs: staging ring (IVX_DENSE=0) and count-scan-write (1),
     # both partitions (one pass into region pages, "two": histogram + scatter) and the bitmap-filtered routing
     # "routed": rle_right / exists over probe rows routed by coordinate region, gathers from the index (big build sides)
-    for path in ("direct", "regions", "regions-dense", "regions-two", "regions-two-dense", "regions-filter", "regions-filter-dense", "routed"):
+    # "nopack": the 12-byte routed rows ((start,end) + row id) instead of the packed 8-byte ones
+    for path in ("direct", "regions", "regions-dense", "regions-nopack", "regions-nopack-dense", "regions-two", "regions-two-dense",
+                 "regions-filter", "regions-filter-dense", "routed"):
         os.environ["IVX_JOIN_PATH"] = path.split("-")[0]
         if path.startswith("regions"):
             os.environ["IVX_DENSE"] = "1" if path.endswith("dense") else "0"
             if "-two" in path:
                 os.environ["IVX_PART"] = "two"
+            if "-nopack" in path:
+                os.environ["IVX_PACK"] = "0"
         x = ixf if "-filter" in path else ix
         try:
             assert ctx.overlap_count(x, pk, ps, pe) == total, path
@@ -53,6 +57,7 @@ def _check_join(ctx, bk, bs, be, pk, ps, pe, nkeys):
             del os.environ["IVX_JOIN_PATH"]
             os.environ.pop("IVX_DENSE", None)
             os.environ.pop("IVX_PART", None)
+            os.environ.pop("IVX_PACK", None)
         assert len(ob) == total and len(ob2) == total, path
         assert (pair_set(ob, op) == pair_set(want_b, want_p)).all(), path
         assert (pair_set(ob2, op2) == pair_set(want_b, want_p)).all(), path
