@@ -35,6 +35,7 @@ struct ivx_sub_plan {
     const i64 *lsv, *lev, *rsv, *hrs, *hpm;
     const void *sm;
     const u64 *offs;
+    const u32 *plan_hlo; const i64 *plan_tail;      // per left row: its first gap head, where its tail fragment starts
 };
 
 // What a region-partitioned overlap COUNT call leaves behind for the fill call that follows it: the probe
