@@ -46,9 +46,11 @@ constexpr int PA_TILE = PA_T * PA_I;              // 12288 rows: ~63 rows per re
 constexpr u32 NO_REGION = 0xFFFFFFFFu;
 constexpr u32 KT_MAX = 256;                       // per-key tables cached in LDS up to this many keys
 
-// per-key lookup for "which region does a probe row start in", cached in LDS
+// per-key lookup for "which region does a probe row start in", cached in LDS (up to KT_MAX keys; lastcell = 0xFFFFFFFF: key
+// has no build rows).  The LDS tables are passed to region_of as the kernel's own arrays, never through a pointer that may
+// also be null / global: such a pointer makes every lookup a flat load with full waits.
 struct KeyTab {
-    const i32 *origin; const u32 *lastcell; const u32 *kreg;   // lastcell = 0xFFFFFFFF: key has no build rows
+    bool lds;
     u32 nkeys, sh0, cs;          // cs = log2(cells per region), or ~0u: divide by multiplying with rmul
     u64 rmul;
 };
@@ -57,24 +59,27 @@ __device__ __forceinline__ void keytab_load(const JoinIndexView &ix, i32 *s_orig
 {
     kt.nkeys = ix.nkeys; kt.sh0 = ix.hdr[HDR_SH0]; kt.cs = ix.hdr[HDR_CS];
     kt.rmul = (u64)ix.hdr[HDR_RMUL_LO] | ((u64)ix.hdr[HDR_RMUL_HI] << 32);
-    if (ix.nkeys <= KT_MAX) {
+    kt.lds = ix.nkeys <= KT_MAX;
+    if (kt.lds) {
         for (u32 k = threadIdx.x; k < ix.nkeys; k += blockDim.x) {
             s_origin[k] = ix.origin[k];
             s_last[k] = ix.kcnt[k] ? (ix.span[k] >> kt.sh0) : 0xFFFFFFFFu;
             s_kreg[k] = ix.kreg[k];
         }
-        kt.origin = s_origin; kt.lastcell = s_last; kt.kreg = s_kreg;
-    } else {
-        kt.origin = nullptr; kt.lastcell = nullptr; kt.kreg = nullptr;
     }
 }
 
-// region of a probe row = region of the level-0 cell its START falls in (clamped into the key)
-__device__ __forceinline__ u32 region_of(const JoinIndexView &ix, const KeyTab &kt, u32 k, i32 qs)
+#define KEYTAB_DISPATCH(kt_, body_) do { if ((kt_).lds) body_(std::true_type{}); else body_(std::false_type{}); } while (0)
+
+// region of a probe row = region of the level-0 cell its START falls in (clamped into the key).  KLDS is a template
+// parameter, not a run-time choice next to the loads: "LDS table or index column" in one expression compiles to flat loads.
+// The kernels run their main loop once per case (KEYTAB_DISPATCH).
+template <bool KLDS>
+__device__ __forceinline__ u32 region_of(const JoinIndexView &ix, const KeyTab &kt, const i32 *s_origin, const u32 *s_last, const u32 *s_kreg, u32 k, i32 qs)
 {
     if (k >= kt.nkeys) return NO_REGION;
     i32 origin; u32 last, kreg;
-    if (kt.origin) { origin = kt.origin[k]; last = kt.lastcell[k]; kreg = kt.kreg[k]; }
+    if (KLDS) { origin = s_origin[k]; last = s_last[k]; kreg = s_kreg[k]; }
     else { origin = ix.origin[k]; last = ix.kcnt[k] ? (ix.span[k] >> kt.sh0) : 0xFFFFFFFFu; kreg = ix.kreg[k]; }
     if (last == 0xFFFFFFFFu) return NO_REGION;                    // cannot match anything
     const i64 d = (i64)qs - (i64)origin;
@@ -151,6 +156,8 @@ __global__ __launch_bounds__(PA_T) void k_part_hist(JoinIndexView ix, const u32 
     __syncthreads();
     const u64 lo = (u64)blockIdx.x * chunk;
     const u64 hi = lo + chunk < n ? lo + chunk : n;
+    auto body = [&](auto klds_tag) {
+    constexpr bool KLDS = decltype(klds_tag)::value;
     for (u64 i0 = lo; i0 < hi; i0 += (u64)PA_T * 4) {
         u32 k[4]; i32 q[4], unused[4];
         const u64 i = i0 + (u64)threadIdx.x * 4;
@@ -159,7 +166,7 @@ __global__ __launch_bounds__(PA_T) void k_part_hist(JoinIndexView ix, const u32 
         u32 d[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            d[u] = region_of(ix, kt, k[u], (i32)((u32)q[u] + adj));
+            d[u] = region_of<KLDS>(ix, kt, s_origin, s_last, s_kreg, k[u], (i32)((u32)q[u] + adj));
             lds_count_up(cnt, SPLIT ? (u32)(((u64)d[u] * split.y) >> 32) : d[u], d[u] != NO_REGION);
         }
         if (!s_unsorted) {                                  // (once raised nobody needs to look any further)
@@ -170,12 +177,14 @@ __global__ __launch_bounds__(PA_T) void k_part_hist(JoinIndexView ix, const u32 
                 bad |= d[u] == NO_REGION || (u && d[u] < d[u - 1]);
             }
             if (i + 3 < hi && i + 4 < n) {                  // the row after this thread's four: next thread, wavefront, loop step or workgroup
-                const u32 dn = region_of(ix, kt, pkey ? pkey[i + 4] : 0u, (i32)((u32)ps[i + 4] + adj));
+                const u32 dn = region_of<KLDS>(ix, kt, s_origin, s_last, s_kreg, pkey ? pkey[i + 4] : 0u, (i32)((u32)ps[i + 4] + adj));
                 bad |= dn < d[3];
             }
             if (bad) s_unsorted = 1;
         }
     }
+    };
+    KEYTAB_DISPATCH(kt, body);
     __syncthreads();
     if (threadIdx.x < ND) hist[(u64)threadIdx.x * nblk + blockIdx.x] = cnt[threadIdx.x];
     if (threadIdx.x == 0 && s_unsorted) *unsorted = 1;
@@ -209,6 +218,8 @@ __global__ __launch_bounds__(PA_T) void k_part_scatter(JoinIndexView ix, const u
     if (tid < ND) gbase[tid] = offs[(u64)tid * nblk + blockIdx.x];
     const u64 lo = (u64)blockIdx.x * chunk;
     const u64 hi = lo + chunk < n ? lo + chunk : n;
+    auto body = [&](auto klds_tag) {
+    constexpr bool KLDS = decltype(klds_tag)::value;
     for (u64 t0 = lo; t0 < hi; t0 += PA_TILE) {
         if (tid < ND) dstart[tid] = 0;
         __syncthreads();
@@ -226,7 +237,7 @@ __global__ __launch_bounds__(PA_T) void k_part_scatter(JoinIndexView ix, const u
         for (int k = 0; k < PA_I; k++) {
             qs[k] = (i32)((u32)qs[k] + adj); qe[k] = (i32)((u32)qe[k] - adj);
             se[k] = (u64)(u32)qs[k] | ((u64)(u32)qe[k] << 32);
-            u32 d = region_of(ix, kt, kk[k], qs[k]);
+            u32 d = region_of<KLDS>(ix, kt, s_origin, s_last, s_kreg, kk[k], qs[k]);
             if (SPLIT && d != NO_REGION) {                       // digit = super-region; region % G rides along in the bits above it
                 const u32 sup = (u32)(((u64)d * split.y) >> 32);
                 d = sup | ((d - sup * split.x) << 10);
@@ -268,6 +279,8 @@ __global__ __launch_bounds__(PA_T) void k_part_scatter(JoinIndexView ix, const u
         __syncthreads();
         if (tid < ND) gbase[tid] += mine;
     }
+    };
+    KEYTAB_DISPATCH(kt, body);
 }
 
 // ------------------------------------------------------------------ one-pass partition into region pages
@@ -1565,7 +1578,11 @@ __global__ __launch_bounds__(WR_T) void k_sorted_bounds(JoinIndexView ix, const 
     const u32 r = blockIdx.x * WR_T + threadIdx.x;
     if (r > nreg) return;
     u64 lo = 0, hi = n;                                             // first row whose region is >= r (every row is routable here)
-    while (lo < hi) { const u64 mid = lo + ((hi - lo) >> 1); if (region_of(ix, kt, pkey ? pkey[mid] : 0u, ps[mid]) < r) lo = mid + 1; else hi = mid; }
+    auto body = [&](auto klds_tag) {
+        constexpr bool KLDS = decltype(klds_tag)::value;
+        while (lo < hi) { const u64 mid = lo + ((hi - lo) >> 1); if (region_of<KLDS>(ix, kt, s_origin, s_last, s_kreg, pkey ? pkey[mid] : 0u, ps[mid]) < r) lo = mid + 1; else hi = mid; }
+    };
+    KEYTAB_DISPATCH(kt, body);
     rfirst[r] = (u32)lo;
 }
 
