@@ -427,8 +427,11 @@ __device__ __forceinline__ void load4nt(const u32 *__restrict__ pkey, const i32 
 template <bool VEC, int ND, int I, bool KLDS, bool FILT, bool PK, int T = PA_T>
 __global__ __launch_bounds__(T, 4) void k_part_onepass(JoinIndexView ix, const u32 *__restrict__ pkey, const i32 *__restrict__ ps,
                                                        const i32 *__restrict__ pe, u64 n, u32 chunk, u32 *__restrict__ rcur, PageTab pt,
-                                                       u32 *pool_next, u64 *__restrict__ out_se, u32 *__restrict__ out_row, u32 rowbits)
+                                                       u32 *pool_next, u64 *__restrict__ out_se, u32 *__restrict__ out_row, u32 rowbits,
+                                                       u32 adj = 0, uint2 *__restrict__ vtab = nullptr)
 {
+    // adj = 1: the UDTFs' strict mode shrinks the query to [start+1, end-1] before anything else (interval_tree.rs:185-188)
+    // vtab (per-row-value operators): [tile][region] -> (virtual start, rows) of the tile's run, for the un-permute
     constexpr int TILE = T * I;
     static_assert(ND <= T, "one thread per region");
     __shared__ u64 r_se[TILE];
@@ -485,6 +488,7 @@ __global__ __launch_bounds__(T, 4) void k_part_onepass(JoinIndexView ix, const u
             for (int k = 0; k < CH; k++) {
                 u64 packed;
                 const u32 maxlen = pk_maxlen(rowbits);
+                qs[k] = (i32)((u32)qs[k] + adj); qe[k] = (i32)((u32)qe[k] - adj);
                 dig[c0 + k] = route_prep<KLDS, FILT, PK>(ix, kt, kk[k], qs[k], qe[k], fpos[k], packed, maxlen);
                 if (PK) {
                     const u32 lenf = packed == PK_ESCAPE ? maxlen : (u32)(packed >> 24);
@@ -512,6 +516,7 @@ __global__ __launch_bounds__(T, 4) void k_part_onepass(JoinIndexView ix, const u
         const u32 mine = tid < ND ? dstart[tid] : 0u;
         u32 v = 0;
         if (mine) v = atomicAdd(&rcur[tid], mine);
+        if (vtab && tid < ND) vtab[(u64)(t0 / TILE) * ND + tid] = make_uint2(v, mine);
         u32 tot;
         const u32 ds = block_excl_scan<u32, T>(mine, scan_lds, &tot);     // (barriers inside: every counter is read before any is overwritten)
         if (tid < ND) dstart[tid] = ds;
@@ -1038,8 +1043,14 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
                         u32 val[B];
                         batch_rowval<MODE, B>(S, qs, qe, okmask, val);
 #pragma unroll
-                        for (int q = 0; q < B; q++)
-                            if ((okmask >> q) & 1u) ob[b0 + (u64)q * (RP_W * IVX_WAVE) + ln] = val[q];
+                        for (int q = 0; q < B; q++) {
+                            if (!((okmask >> q) & 1u)) continue;
+                            const u64 i = b0 + (u64)q * (RP_W * IVX_WAVE) + ln;
+                            if (PAGED) {    // in place: the value takes the low half of the row's packed word, the row id stays above it
+                                const u64 at = row_at(i, r, rf);
+                                ((u64 *)ob)[at] = (u64)val[q] | ((u64)rowv[q] << 32);      // (ob = the page pool itself)
+                            } else ob[i] = val[q];
+                        }
                         continue;
                     }
                     u32 start = 0;
@@ -1331,17 +1342,116 @@ __global__ __launch_bounds__(PA_T) void k_unpermute(const u32 *__restrict__ val,
     if (OUT == UP_U32 && total) { const u64 b = block_sum<u64, PA_T>(mysum, s_sum); if (tid == 0 && b) atomicAdd(total, (unsigned long long)b); }
 }
 
+// The same for rows routed by the one-pass partition (packed rows in region pages): the probe left every row's value in the
+// low half of its packed word, the row id above it.  One workgroup per partition tile: vtab[tile][region] says where the
+// tile's run of every region went (virtual start, rows); the words are read back run by run (each wavefront a contiguous
+// share of the tile's words), dropped at row - tile start in LDS and written out in input order.
+template <int OUT, int TILE>
+__global__ __launch_bounds__(512) void k_unpermute_paged(const u64 *__restrict__ pool, const uint2 *__restrict__ vtab, PageTab pt, u32 nreg, u32 rowbits,
+                                                         u64 n, void *__restrict__ out, unsigned long long *total)
+{
+    constexpr int T = 512, ND = 256;
+    __shared__ u32 s_val[TILE];
+    __shared__ u32 s_pre[ND + 1], s_v[ND], s_pg0[ND];
+    __shared__ u32 scan_lds[T / IVX_WAVE + 1];
+    __shared__ u64 s_sum[T / IVX_WAVE];
+    const u32 tid = threadIdx.x;
+    const u64 t0 = (u64)blockIdx.x * TILE;
+    const u32 len = (u32)(t0 + TILE < n ? (u64)TILE : n - t0);
+    const u32 rowmask = rowbits >= 32 ? 0xFFFFFFFFu : (1u << rowbits) - 1u;
+    const u32 pmask = (1u << pt.lgpg) - 1u;
+    u32 v = 0, c = 0;
+    if (tid < nreg) { const uint2 vc = vtab[(u64)blockIdx.x * ND + tid]; v = vc.x; c = vc.y; }
+    u32 tot;
+    const u32 ex = block_excl_scan<u32, T>(c, scan_lds, &tot);
+    if (tid < ND) { s_pre[tid] = ex; s_v[tid] = v; s_pg0[tid] = c ? pt.ptab[(u64)tid * pt.pstride + (v >> pt.lgpg)] - 1u : 0u; }
+    if (tid == 0) s_pre[ND] = tot;
+    for (u32 t = tid; t < TILE; t += T) s_val[t] = 0;           // rows that were never routed keep 0: the reference's answer for them
+    __syncthreads();
+    const u32 wv = tid / IVX_WAVE, ln = lane_id();
+    const u32 per = (tot + T / IVX_WAVE - 1) / (T / IVX_WAVE);
+    const u32 j_lo = wv * per, j_hi = j_lo + per < tot ? j_lo + per : tot;
+    u32 r = 0;
+    if (j_lo < j_hi) { u32 a = 0, b = ND; while (a < b) { const u32 m = (a + b + 1) >> 1; if (m < ND && s_pre[m] <= j_lo + ln) a = m; else b = m - 1; } r = a; }
+    for (u32 j = j_lo + ln; j < j_hi; j += IVX_WAVE) {
+        while (r + 1 < ND && s_pre[r + 1] <= j) r++;
+        const u32 x = s_v[r] + (j - s_pre[r]);                  // virtual row number in region r
+        u32 pg = s_pg0[r];
+        if ((x >> pt.lgpg) != (s_v[r] >> pt.lgpg)) pg = pt.ptab[(u64)r * pt.pstride + (x >> pt.lgpg)] - 1u;   // the run's second page
+        const u64 w = pool[((u64)pg << pt.lgpg) + (x & pmask)];
+        const u32 slot = ((u32)(w >> 32) & rowmask) - (u32)t0;
+        if (slot < (u32)TILE) s_val[slot] = (u32)w;
+    }
+    __syncthreads();
+    u64 mysum = 0;
+    for (u32 t = tid; t < len; t += T) { const u32 val = s_val[t]; up_store<OUT>(out, t0 + t, val); mysum += val; }
+    if (OUT == UP_U32 && total) { const u64 b = block_sum<u64, T>(mysum, s_sum); if (tid == 0 && b) atomicAdd(total, (unsigned long long)b); }
+}
+
 }  // namespace
 
 // One value per probe row, in input order, through the region partition.  kind: IVX_RV_COUNT (count_overlaps,
 // jv over the build rows, i64 out), IVX_RV_COVERAGE (jv over the merged nodes, i64 out), IVX_RV_PER_ROW (the
 // join's rle_right: u32 out, *d_total += all matches), IVX_RV_EXISTS (semi / anti join: u8 out).
 ivx_status ivx_rowval_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nreg, int kind,
-                                    const u32 *key, const i32 *s, const i32 *e, u64 n, int strict, void *out, u64 *d_total)
+                                    const u32 *key, const i32 *s, const i32 *e, u64 n, int strict, void *out, u64 *d_total,
+                                    bool has_filter, bool pk24)
 {
     if (n == 0) return IVX_OK;
     if (nreg == 0 || nreg > IVX_MAXREG_WIDE) return ctx->fail(IVX_ERR_INVALID, "per-row region probe: one partition pass only");
     hipStream_t st = ctx->stream;
+    // Packed rows in region pages (the join's one-pass partition, two 512-thread workgroups per CU) when the index allows
+    // them and one 256-digit pass routes the rows: no histogram pass, the probe leaves each value in the row's own word,
+    // the un-permute reads the words back through vtab.  (IVX_PART=two / IVX_PACK=0: the two-pass form below.)
+    const bool two_pass = (getenv("IVX_PART") && !strcmp(getenv("IVX_PART"), "two")) || (getenv("IVX_PACK") && !strcmp(getenv("IVX_PACK"), "0"));
+    if (pk24 && nreg <= IVX_MAXREG && !two_pass) {
+        constexpr u32 TILE = 512u * 16u;
+        u32 rowbits = 1;
+        while (rowbits < 32 && (n - 1) >> rowbits) rowbits++;
+        const bool filter_off = getenv("IVX_FILTER") && !strcmp(getenv("IVX_FILTER"), "0");
+        const bool use_filter = has_filter && !filter_off;
+        if (use_filter) rowbits = 32;
+        u32 lgpg = 14;
+        while (lgpg < 31 && (n >> lgpg) > 4096) lgpg++;
+        const u64 pstride = (n >> lgpg) + 2;
+        const u64 npages = (n >> lgpg) + nreg + 1;
+        const u64 ntiles = (n + TILE - 1) / TILE;
+        u32 *ctl, *ptab; u64 *pool; uint2 *vtab;
+        IVX_TRY(ctx->get_scratch(WS_SORTHIST, (1024 + 8 + 1032) * sizeof(u32), (void **)&ctl));
+        IVX_TRY(ctx->get_scratch(WS_T2, (size_t)nreg * pstride * sizeof(u32), (void **)&ptab));
+        IVX_TRY(ctx->get_scratch(WS_T0, (size_t)(npages << lgpg) * sizeof(u64), (void **)&pool));
+        IVX_TRY(ctx->get_scratch(WS_T1, (size_t)ntiles * 256 * sizeof(uint2), (void **)&vtab));
+        IVX_HIP(ctx, hipMemsetAsync(ctl, 0, (1024 + 8) * sizeof(u32), st));
+        IVX_HIP(ctx, hipMemsetAsync(ptab, 0, (size_t)nreg * pstride * sizeof(u32), st));
+        const PageTab pt{ptab, (u32)pstride, lgpg};
+        u32 *rcur = ctl, *pool_next = ctl + 1024, *rf = ctl + 1032;
+        const bool vec = (((uintptr_t)key | (uintptr_t)s | (uintptr_t)e) & 15) == 0;
+        const u32 adj = strict ? 1u : 0u;
+        const u32 tiles = n >= (16u << 20) ? 4u : n >= (4u << 20) ? 2u : 1u;
+        const u32 chunk1 = TILE * tiles;
+        const u32 nblk1 = (u32)((n + chunk1 - 1) / chunk1);
+#define IVX_RVPART(V_, K_, F_) hipLaunchKernelGGL((k_part_onepass<V_, 256, 16, K_, F_, true, 512>), dim3(nblk1), dim3(512), 0, st, jv, key, s, e, n, chunk1, rcur, pt, pool_next, pool, (u32 *)nullptr, rowbits, adj, vtab)
+#define IVX_RVPART2(V_, K_) do { if (use_filter) IVX_RVPART(V_, K_, true); else IVX_RVPART(V_, K_, false); } while (0)
+#define IVX_RVPART3(V_) do { if (jv.nkeys <= KT_MAX) IVX_RVPART2(V_, true); else IVX_RVPART2(V_, false); } while (0)
+        if (vec) IVX_RVPART3(true); else IVX_RVPART3(false);
+#undef IVX_RVPART3
+#undef IVX_RVPART2
+#undef IVX_RVPART
+        hipLaunchKernelGGL(k_page_bounds, dim3(1), dim3(1024), 0, st, (const u32 *)rcur, nreg, rf);
+#define IVX_RVP(M_) hipLaunchKernelGGL((k_probe_regions<M_, RP_B, false, true, true>), dim3(RP_VGRID), dim3(RP_T), 0, st, jv, (const void *)pool, (const void *)nullptr, (const u32 *)rf, 1u, 1u, (u32 *)pool, (u32 *)nullptr, (u64)0, (unsigned long long *)nullptr, 1u, adj, (const u32 *)nullptr, 0, pt, (const u32 *)nullptr, s, e, rowbits)
+        if (kind == IVX_RV_COVERAGE) IVX_RVP(RV_COVERAGE); else if (kind == IVX_RV_COUNT) IVX_RVP(RV_COUNT); else IVX_RVP(RV_MATCHES);
+#undef IVX_RVP
+#define IVX_UPP(O_) hipLaunchKernelGGL((k_unpermute_paged<O_, (int)TILE>), dim3((u32)ntiles), dim3(512), 0, st, (const u64 *)pool, (const uint2 *)vtab, pt, nreg, rowbits, n, out, (unsigned long long *)d_total)
+        switch (kind) {
+        case IVX_RV_COVERAGE: IVX_UPP(UP_I64S); break;
+        case IVX_RV_COUNT: IVX_UPP(UP_I64); break;
+        case IVX_RV_PER_ROW: IVX_UPP(UP_U32); break;
+        default: IVX_UPP(UP_U8); break;
+        }
+#undef IVX_UPP
+        IVX_HIP(ctx, hipGetLastError());
+        return IVX_OK;
+    }
     const bool wide = nreg > IVX_MAXREG;                                // 1024 digits instead of 256
     const u32 chunk = part_chunk(n, 2);
     const u32 nblk = (u32)((n + chunk - 1) / chunk);
