@@ -32,17 +32,30 @@ __global__ __launch_bounds__(GT) void k_keystats(const u32 *__restrict__ key, co
         for (u32 k = threadIdx.x; k < nkeys; k += GT) { smin[k] = INT32_MAX; smax[k] = INT32_MIN; scnt[k] = 0; }
         __syncthreads();
     }
+    // a thread keeps the statistics of its current key in registers and hands them over when the key changes: rows
+    // that come grouped by key (sorted tables) cost no atomics at all, random keys what they cost before
+    u32 ck = 0xFFFFFFFFu, ccnt = 0; i32 cmin = INT32_MAX, cmax = INT32_MIN;
+    u32 cl = 0xFFFFFFFFu, clcnt = 0;
+    auto flush = [&]() {
+        if (!ccnt) return;
+        if (priv) { atomicMin(&smin[ck], cmin); atomicMax(&smax[ck], cmax); atomicAdd(&scnt[ck], ccnt); }
+        else { atomicMin(&kmin[ck], cmin); atomicMax(&kmax[ck], cmax); atomicAdd(&kcnt[ck], ccnt); }
+    };
     for (u64 i = (u64)blockIdx.x * GT + threadIdx.x; i < n; i += (u64)gridDim.x * GT) {
         const u32 k = key ? key[i] : 0u;
         if (k >= nkeys) { *errflag = 1; continue; }
         const i32 x = v[i * vs];
         if (lenhist) {
             const i64 len = (i64)vend[i] - (i64)x;
-            atomicAdd(&s_len[len <= 0 ? 0u : 64u - (u32)__clzll((u64)len)], 1u);
+            const u32 c = len <= 0 ? 0u : 64u - (u32)__clzll((u64)len);
+            if (c != cl) { if (clcnt) atomicAdd(&s_len[cl], clcnt); cl = c; clcnt = 0; }
+            clcnt++;
         }
-        if (priv) { atomicMin(&smin[k], x); atomicMax(&smax[k], x); atomicAdd(&scnt[k], 1u); }
-        else { atomicMin(&kmin[k], x); atomicMax(&kmax[k], x); atomicAdd(&kcnt[k], 1u); }
+        if (k != ck) { flush(); ck = k; ccnt = 0; cmin = INT32_MAX; cmax = INT32_MIN; }
+        cmin = x < cmin ? x : cmin; cmax = x > cmax ? x : cmax; ccnt++;
     }
+    flush();
+    if (lenhist && clcnt) atomicAdd(&s_len[cl], clcnt);
     if (priv) {
         __syncthreads();
         for (u32 k = threadIdx.x; k < nkeys; k += GT)
@@ -52,6 +65,24 @@ __global__ __launch_bounds__(GT) void k_keystats(const u32 *__restrict__ key, co
         __syncthreads();
         if (threadIdx.x < 33 && s_len[threadIdx.x]) atomicAdd(&lenhist[threadIdx.x], s_len[threadIdx.x]);
     }
+}
+
+// rows grouped by ascending key with non-decreasing v inside a key: a key's rows are found by bisecting the key
+// column, its min / max are its first / last value (one thread per key)
+__global__ __launch_bounds__(GT) void k_keystats_sorted(const u32 *__restrict__ key, const i32 *__restrict__ v, u64 n, u32 nkeys,
+                                                        i32 *kmin, i32 *kmax, u32 *kcnt, u32 vs)
+{
+    const u32 k = blockIdx.x * GT + threadIdx.x;
+    if (k >= nkeys) return;
+    auto lower = [&](u32 x) {                       // first row whose key is >= x
+        u64 a = 0, b = n;
+        while (a < b) { const u64 m = (a + b) >> 1; if ((key ? key[m] : 0u) < x) a = m + 1; else b = m; }
+        return a;
+    };
+    const u64 lo = lower(k), hi = k + 1 == 0u ? n : lower(k + 1);
+    kcnt[k] = (u32)(hi - lo);
+    kmin[k] = hi > lo ? v[lo * vs] : INT32_MAX;
+    kmax[k] = hi > lo ? v[(hi - 1) * vs] : INT32_MIN;
 }
 
 __device__ __forceinline__ u32 gcells(u32 cnt, u32 span, u32 sh) { return cnt ? (span >> sh) + 1u : 0u; }
@@ -199,7 +230,8 @@ ivx_status ivx_grid_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32
     u32 *errflag = (u32 *)(ctx->d_scalars + 8);
     IVX_HIP(ctx, hipMemsetAsync(binstart, 0, (maxcells + 1) * sizeof(u32), st));
     if (!sorted) IVX_HIP(ctx, hipMemsetAsync(cursor, 0, (maxcells + 1) * sizeof(u32), st));
-    IVX_TRY(ivx_keystats(ctx, key, v, n, nkeys, kmin, kmax, kcnt, errflag, vstride));
+    if (sorted && n) hipLaunchKernelGGL(k_keystats_sorted, dim3((nkeys + GT - 1) / GT), dim3(GT), 0, st, key, v, n, nkeys, kmin, kmax, kcnt, vstride);
+    else IVX_TRY(ivx_keystats(ctx, key, v, n, nkeys, kmin, kmax, kcnt, errflag, vstride));
     hipLaunchKernelGGL(k_grid_layout, dim3(1), dim3(1024), 0, st, kmin, kmax, kcnt, nkeys, n, origin, span, koff, kbase, hdr);
     if (n && sorted) {
         const u32 grid = ivx_stream_grid(n, GT * 8, 2048);

@@ -233,18 +233,18 @@ struct SegMaxOp {
     }
 };
 
-__global__ __launch_bounds__(OT) void k_segmax_in(const u32 *__restrict__ ks, const ivx_nrec *__restrict__ rs, u64 n, SegMax *sm)
-{
-    const u64 i = (u64)blockIdx.x * OT + threadIdx.x;
-    if (i >= n) return;
-    SegMax t; t.v = rs[i].b; t.head = (i == 0 || ks[i] != ks[i - 1]) ? 1u : 0u;
-    sm[i] = t;
-}
-__global__ __launch_bounds__(OT) void k_segmax_out(const SegMax *__restrict__ sm, u64 n, ivx_nrec *rs)
-{
-    const u64 i = (u64)blockIdx.x * OT + threadIdx.x;
-    if (i < n) rs[i].pmax = sm[i].v;
-}
+// the scan's elements come straight from the records and the key column, its results go into the records
+struct SegMaxIn {
+    const u32 *ks; const ivx_nrec *rs;
+    __device__ SegMax operator()(u64 i) const
+    {
+        SegMax t; t.v = rs[i].b; t.head = (i == 0 || ks[i] != ks[i - 1]) ? 1u : 0u; return t;
+    }
+};
+struct SegMaxOut {
+    ivx_nrec *rs;
+    __device__ void operator()(u64 i, const SegMax &v) const { rs[i].pmax = v.v; }
+};
 
 struct Cand { i32 s, e; u32 row; };
 
@@ -459,6 +459,202 @@ __global__ __launch_bounds__(OT) void k_fix_runs_se(u64 *__restrict__ w0, u64 *_
     }
 }
 
+// ---- the same two orders through ONE 64-bit sort word per row (the usual case: genomic coordinates)
+// Per key the coordinates of both columns span [origin, origin + span]; `lin = base[key] + (v - origin[key])` with
+// base = running sum of (span + 1) numbers every (key, coordinate) in key-major order.  If lin's bits and a row
+// number's bits fit 64 together, `lin(start) ‖ row` sorts as 8-byte records over ceil(linbits / 8) digit passes
+// (4 for a human genome, where the packed (key, start) of the two-word form takes 5), the end is fetched by row
+// afterwards, and the end-major order is the same sort of `lin(end) ‖ position in start order`.
+constexpr u32 NLIN_KEYS_LDS = 2048;
+
+__global__ void k_init_minmax(i32 *kmin, i32 *kmax, u32 nkeys)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nkeys) { kmin[i] = INT32_MAX; kmax[i] = INT32_MIN; }
+}
+
+__global__ __launch_bounds__(OT) void k_nstats(const u32 *__restrict__ key, const i32 *__restrict__ s, const i32 *__restrict__ e, u64 n,
+                                               u32 nkeys, i32 *kmin, i32 *kmax, u32 *kcnt, u32 *flags)
+{
+    extern __shared__ i32 sh[];
+    const bool priv = nkeys <= NLIN_KEYS_LDS;
+    i32 *smin = sh, *smax = sh + nkeys;
+    u32 *scnt = (u32 *)(sh + 2 * nkeys);
+    if (priv) {
+        for (u32 k = threadIdx.x; k < nkeys; k += OT) { smin[k] = INT32_MAX; smax[k] = INT32_MIN; scnt[k] = 0; }
+        __syncthreads();
+    }
+    u32 ck = 0xFFFFFFFFu, ccnt = 0; i32 cmin = INT32_MAX, cmax = INT32_MIN;
+    auto flush = [&]() {
+        if (!ccnt) return;
+        if (priv) { atomicMin(&smin[ck], cmin); atomicMax(&smax[ck], cmax); atomicAdd(&scnt[ck], ccnt); }
+        else { atomicMin(&kmin[ck], cmin); atomicMax(&kmax[ck], cmax); atomicAdd(&kcnt[ck], ccnt); }
+    };
+    bool bad = false, unsorted = false;
+    for (u64 i = (u64)blockIdx.x * OT + threadIdx.x; i < n; i += (u64)gridDim.x * OT) {
+        const u32 k = key ? key[i] : 0u;
+        if (k >= nkeys) { bad = true; continue; }
+        const i32 a = s[i], b = e[i];
+        if (i) {                                                        // below the row before it? (flags[1]: input not sorted)
+            const u32 pk = key ? key[i - 1] : 0u;
+            const i32 pa = s[i - 1], pb = e[i - 1];
+            if (k != pk ? k < pk : (a != pa ? a < pa : b < pb)) unsorted = true;
+        }
+        if (k != ck) { flush(); ck = k; ccnt = 0; cmin = INT32_MAX; cmax = INT32_MIN; }
+        const i32 lo = a < b ? a : b, hi = a < b ? b : a;
+        cmin = lo < cmin ? lo : cmin; cmax = hi > cmax ? hi : cmax; ccnt++;
+    }
+    flush();
+    if (bad) flags[0] = 1;
+    if (unsorted) flags[1] = 1;
+    if (priv) {
+        __syncthreads();
+        for (u32 k = threadIdx.x; k < nkeys; k += OT)
+            if (scnt[k]) { atomicMin(&kmin[k], smin[k]); atomicMax(&kmax[k], smax[k]); atomicAdd(&kcnt[k], scnt[k]); }
+    }
+}
+
+// one workgroup: origin, base (nkeys + 1 entries), and hdr = {linbits, rowbits, fits}
+__global__ __launch_bounds__(1024) void k_nlin_layout(const i32 *kmin, const i32 *kmax, const u32 *kcnt, u32 nkeys, u64 n,
+                                                      i32 *origin, u64 *base, u32 *hdr)
+{
+    __shared__ u64 red[1024 / IVX_WAVE + 1];
+    const u32 t = threadIdx.x;
+    u64 run = 0;
+    for (u32 k0 = 0; k0 < nkeys; k0 += 1024) {
+        const u32 k = k0 + t;
+        const u64 w = (k < nkeys && kcnt[k]) ? (u64)((i64)kmax[k] - (i64)kmin[k]) + 1 : 0;
+        u64 tot;
+        const u64 ex = block_excl_scan<u64, 1024>(w, red, &tot);
+        if (k < nkeys) { base[k] = run + ex; origin[k] = kcnt[k] ? kmin[k] : 0; }
+        run += tot;
+    }
+    if (t == 0) {
+        base[nkeys] = run;
+        const u32 linbits = run > 1 ? 64u - (u32)__clzll(run - 1) : 1u;
+        const u32 rowbits = n > 1 ? 64u - (u32)__clzll(n - 1) : 1u;
+        hdr[0] = linbits; hdr[1] = rowbits; hdr[2] = linbits + rowbits <= 64 ? 1u : 0u;
+    }
+}
+
+__global__ __launch_bounds__(OT) void k_pack_lin(const u32 *__restrict__ key, const i32 *__restrict__ v, u64 n, const i32 *__restrict__ origin,
+                                                 const u64 *__restrict__ base, u32 rowbits, u32 vs, u64 *w)
+{
+    const u64 i = (u64)blockIdx.x * OT + threadIdx.x;
+    if (i >= n) return;
+    const u32 k = key ? key[i] : 0u;
+    w[i] = ((base[k] + (u64)((i64)v[i * vs] - (i64)origin[k])) << rowbits) | i;
+}
+
+// key of a linearised coordinate: last k with base[k] <= lin (keys without rows share their successor's base and are
+// skipped by taking the LAST such k among those with rows: base[k + 1] > lin)
+__device__ __forceinline__ u32 lin_key(const u64 *base, u32 nkeys, u64 lin)
+{
+    u32 a = 0, b = nkeys;                                              // first k with base[k + 1] > lin
+    while (a < b) { const u32 m = (a + b) >> 1; if (base[m + 1] > lin) b = m; else a = m + 1; }
+    return a;
+}
+
+// sorted start words -> records in (key, start, end, row) order + the key column + the end-major sort words.
+// Rows of equal (key, start) arrive in row order; each finds its place among them by (end, row).
+constexpr u32 NLIN_MAXRUN = 64;
+__global__ __launch_bounds__(OT) void k_unpack_lin(const u64 *__restrict__ w, u64 n, u32 nkeys, const i32 *__restrict__ origin,
+                                                   const u64 *__restrict__ base_g, const i32 *__restrict__ e, u32 rowbits,
+                                                   u32 *ks, ivx_nrec *rs, u64 *y, u32 *toolong)
+{
+    __shared__ u64 s_base[NLIN_KEYS_LDS + 1];
+    const bool lds = nkeys <= NLIN_KEYS_LDS;
+    if (lds) { for (u32 k = threadIdx.x; k <= nkeys; k += OT) s_base[k] = base_g[k]; __syncthreads(); }
+    const u64 i = (u64)blockIdx.x * OT + threadIdx.x;
+    if (i >= n) return;
+    const u64 rowmask = (1ull << rowbits) - 1;                          // (rowbits <= 32)
+    const u64 x = w[i], lin = x >> rowbits;
+    const u32 row = (u32)(x & rowmask);
+    const i32 end = e[row];
+    u64 h = i, t = i + 1;                                               // the run of equal lin around i
+    while (h > 0 && i - h < NLIN_MAXRUN && (w[h - 1] >> rowbits) == lin) h--;
+    while (t < n && t - i < NLIN_MAXRUN && (w[t] >> rowbits) == lin) t++;
+    u64 pos = i;
+    if (t - h > 1) {
+        if (t - h > NLIN_MAXRUN) { *toolong = 1; return; }
+        u32 below = 0;
+        for (u64 j = h; j < t; j++) {
+            if (j == i) continue;
+            const i32 ej = e[(u32)(w[j] & rowmask)];
+            below += (ej < end || (ej == end && j < i)) ? 1u : 0u;
+        }
+        pos = h + below;
+    }
+    const u32 k = lds ? lin_key(s_base, nkeys, lin) : lin_key(base_g, nkeys, lin);
+    const u64 kb = lds ? s_base[k] : base_g[k];
+    const i32 org = origin[k];
+    ivx_nrec r;
+    r.a = (i32)((i64)org + (i64)(lin - kb)); r.b = end; r.row = row; r.pmax = 0;
+    rs[pos] = r;
+    ks[pos] = k;
+    y[pos] = ((kb + (u64)((i64)end - (i64)org)) << rowbits) | pos;
+}
+
+// sorted end words -> records in (key, end, start, row) order: the payload is the row's place in the start order
+__global__ __launch_bounds__(OT) void k_unpack_lin_end(const u64 *__restrict__ y, u64 n, u32 rowbits, const ivx_nrec *__restrict__ rs, ivx_nrec *re)
+{
+    const u64 i = (u64)blockIdx.x * OT + threadIdx.x;
+    if (i >= n) return;
+    const ivx_nrec r = rs[(u32)(y[i] & ((1ull << rowbits) - 1))];
+    ivx_nrec o; o.a = r.b; o.b = r.a; o.row = r.row; o.pmax = 0;
+    re[i] = o;
+}
+
+// IVX_OK with *done = false: the input does not fit the one-word form (coordinate spans, or a long run of equal
+// (key, start)) -- the caller takes the two-word sorts
+ivx_status nearest_sorted_records_lin(ivx_ctx *ctx, const u32 *key, const i32 *s, const i32 *e, u64 n, u32 nkeys,
+                                      u32 *ks, ivx_nrec *rs, ivx_nrec *re, bool *done)
+{
+    *done = false;
+    if (n < 4096 || n > 0xFFFFFFFFull || getenv("IVX_NEAREST_SORT2")) return IVX_OK;
+    hipStream_t st = ctx->stream;
+    i32 *kmin, *kmax, *origin; u32 *kcnt; u64 *base;
+    IVX_TRY(ctx->get_scratch(WS_GRID0, nkeys * sizeof(i32), (void **)&kmin));
+    IVX_TRY(ctx->get_scratch(WS_GRID1, nkeys * sizeof(i32), (void **)&kmax));
+    IVX_TRY(ctx->get_scratch(WS_GRID2, nkeys * sizeof(u32), (void **)&kcnt));
+    IVX_TRY(ctx->get_scratch(WS_T3, nkeys * sizeof(i32), (void **)&origin));
+    IVX_TRY(ctx->get_scratch(WS_T4, ((size_t)nkeys + 1) * sizeof(u64), (void **)&base));
+    u32 *flags = (u32 *)(ctx->d_scalars + 8);                           // [0] bad key, [1] unsorted / run too long
+    u32 *hdr = (u32 *)(ctx->d_scalars + 10);
+    IVX_HIP(ctx, hipMemsetAsync(kcnt, 0, nkeys * sizeof(u32), st));
+    hipLaunchKernelGGL(k_init_minmax, dim3((nkeys + OT - 1) / OT), dim3(OT), 0, st, kmin, kmax, nkeys);
+    const size_t shm = nkeys <= NLIN_KEYS_LDS ? (size_t)nkeys * 12 : 0;
+    hipLaunchKernelGGL(k_nstats, dim3(ivx_stream_grid(n, OT * 8, 1024)), dim3(OT), shm, st, key, s, e, n, nkeys, kmin, kmax, kcnt, flags);
+    hipLaunchKernelGGL(k_nlin_layout, dim3(1), dim3(1024), 0, st, (const i32 *)kmin, (const i32 *)kmax, (const u32 *)kcnt, nkeys, n, origin, base, hdr);
+    IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 8, ctx->d_scalars + 8, 4 * sizeof(u64), hipMemcpyDeviceToHost, st));
+    IVX_HIP(ctx, hipStreamSynchronize(st));
+    const u32 *hf = (const u32 *)(ctx->h_scalars + 8), *hh = (const u32 *)(ctx->h_scalars + 10);
+    if (hf[0]) return ctx->fail(IVX_ERR_INVALID, "build key id >= n_keys");
+    const bool presorted = hf[1] == 0 && !getenv("IVX_FORCE_SORT");
+    const u32 linbits = hh[0], rowbits = hh[1];
+    if (!hh[2]) return IVX_OK;
+    u64 *a[1], *b[1];
+    IVX_TRY(ctx->get_scratch(WS_SA0, n * sizeof(u64), (void **)&a[0]));
+    IVX_TRY(ctx->get_scratch(WS_SB0, n * sizeof(u64), (void **)&b[0]));
+    const ivx_sort_field f[1] = {{0, (int)rowbits, (int)(rowbits + linbits)}};
+    int in_b = 0;
+    hipLaunchKernelGGL(k_pack_lin, dim3(grid1(n)), dim3(OT), 0, st, key, s, n, (const i32 *)origin, (const u64 *)base, rowbits, 1u, a[0]);
+    if (!presorted) IVX_TRY(ivx_radix_sort(ctx, 1, a, b, n, f, 1, &in_b, true));
+    u64 *w = in_b ? b[0] : a[0], *y = in_b ? a[0] : b[0];
+    IVX_HIP(ctx, hipMemsetAsync(flags + 1, 0, sizeof(u32), st));
+    hipLaunchKernelGGL(k_unpack_lin, dim3(grid1(n)), dim3(OT), 0, st, (const u64 *)w, n, nkeys, (const i32 *)origin, (const u64 *)base, e, rowbits,
+                       ks, rs, y, flags + 1);
+    a[0] = y; b[0] = w;
+    IVX_TRY(ivx_radix_sort(ctx, 1, a, b, n, f, 1, &in_b, true));
+    hipLaunchKernelGGL(k_unpack_lin_end, dim3(grid1(n)), dim3(OT), 0, st, (const u64 *)(in_b ? b[0] : a[0]), n, rowbits, (const ivx_nrec *)rs, re);
+    IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 8, ctx->d_scalars + 8, sizeof(u64), hipMemcpyDeviceToHost, st));
+    IVX_HIP(ctx, hipStreamSynchronize(st));
+    if (hf[1]) return IVX_OK;                                           // a run of equal (key, start) beyond NLIN_MAXRUN rows
+    IVX_HIP(ctx, hipGetLastError());
+    *done = true;
+    return IVX_OK;
+}
+
 // The two orders of the nearest index as records: rs by (key,start,end,row) (nearest_index.rs:50-55), re by
 // (key,end,start,row) (:77-82), ks = the key column (the same in both orders).  The second order is a STABLE
 // sort of the first by (key,end) alone -- ties keep their (start,row) order -- which is 5 digit passes
@@ -467,6 +663,12 @@ ivx_status nearest_sorted_records(ivx_ctx *ctx, const u32 *key, const i32 *s, co
                                   u32 *ks, ivx_nrec *rs, ivx_nrec *re)
 {
     if (n == 0) return IVX_OK;
+    {
+        bool done = false;
+        IVX_TRY(nearest_sorted_records_lin(ctx, key, s, e, n, nkeys, ks, rs, re, &done));
+        if (done) return IVX_OK;
+        IVX_HIP(ctx, hipMemsetAsync(ctx->d_scalars + 8, 0, sizeof(u64), ctx->stream));
+    }
     u64 *a[2], *b[2];
     IVX_TRY(ctx->get_scratch(WS_SA0, n * sizeof(u64), (void **)&a[0]));
     IVX_TRY(ctx->get_scratch(WS_SA1, n * sizeof(u64), (void **)&a[1]));
@@ -607,11 +809,8 @@ ivx_status ivx_nearest_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const 
     IVX_TRY(ctx->get_scratch(WS_T0, na * 4, (void **)&ks));
     IVX_TRY(nearest_sorted_records(ctx, key, s, e, n, nkeys, ks, rs, re));
     if (n) {
-        SegMax *sm;
-        IVX_TRY(ctx->get_scratch(WS_T2, n * sizeof(SegMax), (void **)&sm));
-        hipLaunchKernelGGL(k_segmax_in, dim3(grid1(n)), dim3(OT), 0, st, (const u32 *)ks, (const ivx_nrec *)rs, n, sm);
-        IVX_TRY(ivxscan::inclusive<SegMaxOp>(ctx, sm, n));                               // prefix_max_end :58-63
-        hipLaunchKernelGGL(k_segmax_out, dim3(grid1(n)), dim3(OT), 0, st, (const SegMax *)sm, n, rs);
+        SegMaxIn in{ks, rs}; SegMaxOut out{rs};
+        IVX_TRY((ivxscan::inclusive_f<SegMaxOp>(ctx, in, out, n)));                      // prefix_max_end :58-63
     }
     // the records' fields are the grids' value arrays (stride 4 words): sorted columns, prefix max: all ascending per key
     IVX_TRY(ivx_grid_build(ctx, ix, ks, &rs->a, n, nkeys, &ix->nv.by_start, true, 4));

@@ -283,6 +283,41 @@ def test_nearest_build_long_runs_of_equal_starts(ctx):
     ix.free()
 
 
+@pytest.mark.parametrize("variant", ["many_keys", "i32_extremes", "two_word_sorts"])
+def test_nearest_build_sort_forms(ctx, variant):
+    # the index build sorts one 64-bit word per row (linearised (key, coordinate) ‖ row) when that fits, else two words
+    rng = np.random.default_rng(77)
+    nb, nk = 40_000, 5
+    if variant == "many_keys":                              # more keys than the LDS copy of the key table takes
+        nk = 3000
+        bk, bs, be = synth(nb, 601, nkeys=nk, mean_len=300, span=200_000)
+        pk, ps, pe = synth(30_000, 602, nkeys=nk, mean_len=100, span=200_000)
+    elif variant == "i32_extremes":
+        bk = rng.integers(0, nk, nb).astype(np.uint32)
+        bs = rng.integers(-2**31, 2**31 - 1, nb, dtype=np.int64)
+        be = np.minimum(bs + rng.integers(0, 2**24, nb), 2**31 - 1)
+        bs[:4] = [-2**31, 2**31 - 1, -2**31, 0]; be[:4] = [-2**31, 2**31 - 1, 2**31 - 1, 0]
+        bs, be = bs.astype(np.int32), be.astype(np.int32)
+        pk = rng.integers(0, nk, 30_000).astype(np.uint32)
+        ps = rng.integers(-2**31, 2**31 - 1, 30_000, dtype=np.int64)
+        pe = np.minimum(ps + rng.integers(0, 2**20, 30_000), 2**31 - 1)
+        ps, pe = ps.astype(np.int32), pe.astype(np.int32)
+    else:
+        bk, bs, be = synth(nb, 603, nkeys=nk, mean_len=300, span=2_000_000)
+        bs[::17] = bs[1::17][: len(bs[::17])]; be[::17] = np.maximum(be[::17], bs[::17])
+        pk, ps, pe = synth(30_000, 604, nkeys=nk, mean_len=100, span=2_000_000)
+        os.environ["IVX_NEAREST_SORT2"] = "1"
+    try:
+        ix = ctx.build(pyivx.KIND_NEAREST, bk, bs, be, n_keys=nk)
+    finally:
+        os.environ.pop("IVX_NEAREST_SORT2", None)
+    for k, ovl in [(1, True), (1, False), (3, True)]:
+        gb, gp, gd = ctx.nearest(ix, pk, ps, pe, k=k, overlap=ovl)
+        wb, wp, wd = orc.nearest(bk, bs, be, pk, ps, pe, k=k, overlap=ovl)
+        assert len(gb) == len(wb) and (gb == wb).all() and (gp == wp).all() and (gd == wd).all(), (variant, k, ovl)
+    ix.free()
+
+
 def test_nearest_empty_build_and_k0(ctx):
     e = np.empty(0, np.int32)
     ix = ctx.build(pyivx.KIND_NEAREST, np.empty(0, np.uint32), e, e, n_keys=3)
