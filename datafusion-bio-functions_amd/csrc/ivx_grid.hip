@@ -152,32 +152,40 @@ __global__ __launch_bounds__(GT) void k_grid_scatter(const u32 *__restrict__ key
     }
 }
 
-// input already sorted by (key, value): the cell table needs no atomics and the values no copy.  The last
-// element of every non-empty cell c leaves its end index at E[c+1]; an inclusive max-scan turns E into
-// binstart (an empty cell inherits the end of the last non-empty cell before it).
+// input already sorted by (key, value): the cell table needs no atomics, no scan and the values no copy.
+// binstart[c] = rows in cells below c = (index of the last row of the nearest non-empty cell below c) + 1, so the row
+// that ends its cell writes that number into every cell up to and including the next row's (cells ascend with the
+// rows: keys ascend and their cell ranges are laid out in key order); the first row also writes the zeros before it,
+// the last one the n's after it.  Gaps are a cell or two on average; a long one (an empty stretch of a contig) is
+// filled by the whole wavefront.
 __global__ __launch_bounds__(GT) void k_grid_bounds(const u32 *__restrict__ key, const i32 *__restrict__ v, u64 n, u32 nkeys,
-                                                    const i32 *origin, const u32 *kbase, const u32 *hdr, u32 *E, u32 vs)
+                                                    const i32 *origin, const u32 *kbase, const u32 *hdr, u32 *binstart, u32 vs)
 {
-    const u32 sh = hdr[0];
-    for (u64 i = (u64)blockIdx.x * GT + threadIdx.x; i < n; i += (u64)gridDim.x * GT) {
-        const u32 k = key ? key[i] : 0u;
-        if (k >= nkeys) continue;
-        const u32 c = kbase[k] + ((u32)((i64)v[i * vs] - (i64)origin[k]) >> sh);
-        bool last = i + 1 == n;
-        if (!last) {
-            const u32 k2 = key ? key[i + 1] : 0u;
-            last = k2 != k || k2 >= nkeys || kbase[k2] + ((u32)((i64)v[(i + 1) * vs] - (i64)origin[k2]) >> sh) != c;
+    const u32 sh = hdr[0], ncells = hdr[1];
+    const u64 nround = (n + GT - 1) / GT * GT;                          // whole wavefronts stay in the loop together
+    for (u64 i = (u64)blockIdx.x * GT + threadIdx.x; i < nround; i += (u64)gridDim.x * GT) {
+        u32 lo = 1, hi = 0, val = 0;                                    // cells [lo, hi] <- val
+        const u32 k = i < n ? (key ? key[i] : 0u) : 0xFFFFFFFFu;
+        if (k < nkeys) {
+            const u32 c = kbase[k] + ((u32)((i64)v[i * vs] - (i64)origin[k]) >> sh);
+            u32 cn = ncells;
+            if (i + 1 < n) {
+                const u32 k2 = key ? key[i + 1] : 0u;
+                if (k2 < nkeys) cn = kbase[k2] + ((u32)((i64)v[(i + 1) * vs] - (i64)origin[k2]) >> sh);
+            }
+            if (i == 0) { for (u32 x = 0; x <= c; x++) binstart[x] = 0; }       // (a key's first cell holds its first row: c is small)
+            lo = c + 1; hi = cn; val = (u32)(i + 1);
         }
-        if (last) E[c + 1] = (u32)(i + 1);
+        u64 big = __ballot(lo <= hi && hi - lo >= 64u);
+        if (lo <= hi && hi - lo < 64u) for (u32 x = lo; x <= hi; x++) binstart[x] = val;
+        while (big) {
+            const int src = __builtin_ctzll(big);
+            big &= big - 1;
+            const u32 a = __shfl(lo, src, IVX_WAVE), b = __shfl(hi, src, IVX_WAVE), w = __shfl(val, src, IVX_WAVE);
+            for (u64 x = (u64)a + lane_id(); x <= b; x += IVX_WAVE) binstart[x] = w;
+        }
     }
 }
-
-struct MaxU32Op {
-    using T = u32;
-    __host__ __device__ static T identity() { return 0u; }
-    __device__ static T combine(const T &a, const T &b) { return a > b ? a : b; }
-    __device__ static T shfl_up(const T &x, int d) { return __shfl_up(x, d, IVX_WAVE); }
-};
 
 }  // namespace
 
@@ -226,17 +234,17 @@ ivx_status ivx_grid_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32
     i32 *kmin, *kmax; u32 *cursor;
     IVX_TRY(ctx->get_scratch(WS_GRID0, nkeys * sizeof(i32), (void **)&kmin));
     IVX_TRY(ctx->get_scratch(WS_GRID1, nkeys * sizeof(i32), (void **)&kmax));
-    IVX_TRY(ctx->get_scratch(WS_GRID2, (maxcells + 1) * sizeof(u32), (void **)&cursor));
+    cursor = nullptr;
+    if (!sorted) IVX_TRY(ctx->get_scratch(WS_GRID2, (maxcells + 1) * sizeof(u32), (void **)&cursor));
     u32 *errflag = (u32 *)(ctx->d_scalars + 8);
-    IVX_HIP(ctx, hipMemsetAsync(binstart, 0, (maxcells + 1) * sizeof(u32), st));
+    if (!sorted || !n) IVX_HIP(ctx, hipMemsetAsync(binstart, 0, (maxcells + 1) * sizeof(u32), st));
     if (!sorted) IVX_HIP(ctx, hipMemsetAsync(cursor, 0, (maxcells + 1) * sizeof(u32), st));
     if (sorted && n) hipLaunchKernelGGL(k_keystats_sorted, dim3((nkeys + GT - 1) / GT), dim3(GT), 0, st, key, v, n, nkeys, kmin, kmax, kcnt, vstride);
     else IVX_TRY(ivx_keystats(ctx, key, v, n, nkeys, kmin, kmax, kcnt, errflag, vstride));
     hipLaunchKernelGGL(k_grid_layout, dim3(1), dim3(1024), 0, st, kmin, kmax, kcnt, nkeys, n, origin, span, koff, kbase, hdr);
     if (n && sorted) {
-        const u32 grid = ivx_stream_grid(n, GT * 8, 2048);
+        const u32 grid = ivx_stream_grid(n, GT * 2, 1u << 20);          // (a row's loads depend on nothing: many short threads hide their latency)
         hipLaunchKernelGGL(k_grid_bounds, dim3(grid), dim3(GT), 0, st, key, v, n, nkeys, origin, kbase, hdr, binstart, vstride);
-        IVX_TRY(ivxscan::inclusive<MaxU32Op>(ctx, binstart, maxcells + 1));
     } else if (n) {
         const u32 grid = ivx_stream_grid(n, GT * 8, 1024);
         hipLaunchKernelGGL(k_grid_count, dim3(grid), dim3(GT), 0, st, key, v, n, nkeys, origin, kbase, hdr, binstart);

@@ -323,7 +323,10 @@ __global__ __launch_bounds__(OT) void k_probe_nearest1(NearestView nv, const u32
         i32 qs = rs, qe = re;
         if (strict) { qs = wadd(qs, 1); qe = wsub(qe, 1); }              // nearest.rs:341-344
         Cand best{};
-        const bool found = nearest_one(x, k, qs, qe, include_overlaps, &best);
+        bool found;
+        const u32 k0 = (u32)__builtin_amdgcn_readfirstlane((int)k);       // sorted probe rows: one key per wavefront, its per-key tables (fifteen lookups per row) go through the scalar unit: 2.0 -> 1.5 ms per 50M rows
+        if (__ballot(k != k0) == 0) found = nearest_one(x, k0, qs, qe, include_overlaps, &best);
+        else found = nearest_one(x, k, qs, qe, include_overlaps, &best);
         ob[i] = found ? best.row : IVX_NULL_IDX;
         op[i] = (u32)i;
         if (od) od[i] = found ? cand_dist(rs, re, best.s, best.e) : -1;  // raw coordinates, nearest.rs:367-374
@@ -355,6 +358,9 @@ __global__ __launch_bounds__(NR_T) void k_nearest_routed(NearestView nv, const u
         const u64 w = pse[i];
         const i32 qs = (i32)(u32)w, qe = (i32)(u32)(w >> 32);
         Cand best{};
+        // (reading the per-key tables through the scalar unit when the wavefront shares its region, as k_probe_nearest1
+        // does, is slower here -- 2.6 -> 2.85 ms per 50M rows: the lanes' reads of one address are a single request already,
+        // and this kernel waits on the scattered index sectors of its unsorted rows, not on issuing loads)
         const bool found = nearest_one(x, k, qs, qe, include_overlaps, &best);
         vb[i] = found ? best.row : IVX_NULL_IDX;
         if (vd) vd[i] = found ? cand_dist(wsub(qs, (i32)adj), wadd(qe, (i32)adj), best.s, best.e) : -1;
@@ -474,48 +480,52 @@ __global__ void k_init_minmax(i32 *kmin, i32 *kmax, u32 nkeys)
 }
 
 __global__ __launch_bounds__(OT) void k_nstats(const u32 *__restrict__ key, const i32 *__restrict__ s, const i32 *__restrict__ e, u64 n,
-                                               u32 nkeys, i32 *kmin, i32 *kmax, u32 *kcnt, u32 *flags)
+                                               u32 nkeys, i32 *kmin, i32 *kmax, u32 *flags)
 {
     extern __shared__ i32 sh[];
     const bool priv = nkeys <= NLIN_KEYS_LDS;
     i32 *smin = sh, *smax = sh + nkeys;
-    u32 *scnt = (u32 *)(sh + 2 * nkeys);
     if (priv) {
-        for (u32 k = threadIdx.x; k < nkeys; k += OT) { smin[k] = INT32_MAX; smax[k] = INT32_MIN; scnt[k] = 0; }
+        for (u32 k = threadIdx.x; k < nkeys; k += OT) { smin[k] = INT32_MAX; smax[k] = INT32_MIN; }
         __syncthreads();
     }
-    u32 ck = 0xFFFFFFFFu, ccnt = 0; i32 cmin = INT32_MAX, cmax = INT32_MIN;
-    auto flush = [&]() {
-        if (!ccnt) return;
-        if (priv) { atomicMin(&smin[ck], cmin); atomicMax(&smax[ck], cmax); atomicAdd(&scnt[ck], ccnt); }
-        else { atomicMin(&kmin[ck], cmin); atomicMax(&kmax[ck], cmax); atomicAdd(&kcnt[ck], ccnt); }
-    };
+    // only "has rows" matters of a key's count; a bound is touched by an atomic only when this row moves it (a plain
+    // read comes first: after the first rows of a key almost none do)
     bool bad = false, unsorted = false;
-    for (u64 i = (u64)blockIdx.x * OT + threadIdx.x; i < n; i += (u64)gridDim.x * OT) {
-        const u32 k = key ? key[i] : 0u;
-        if (k >= nkeys) { bad = true; continue; }
-        const i32 a = s[i], b = e[i];
-        if (i) {                                                        // below the row before it? (flags[1]: input not sorted)
-            const u32 pk = key ? key[i - 1] : 0u;
-            const i32 pa = s[i - 1], pb = e[i - 1];
-            if (k != pk ? k < pk : (a != pa ? a < pa : b < pb)) unsorted = true;
+    constexpr int U = 4;                                                // rows per thread in flight
+    for (u64 i0 = (u64)blockIdx.x * (OT * U) + threadIdx.x; i0 < n; i0 += (u64)gridDim.x * (OT * U)) {
+        u32 k[U], pk[U]; i32 a[U], b[U], pa[U], pb[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const u64 i = i0 + (u64)u * OT;
+            const bool in = i < n;
+            k[u] = in ? (key ? key[i] : 0u) : 0u; a[u] = in ? s[i] : 0; b[u] = in ? e[i] : 0;
+            const bool hp = in && i > 0;
+            pk[u] = hp ? (key ? key[i - 1] : 0u) : 0u; pa[u] = hp ? s[i - 1] : INT32_MIN; pb[u] = hp ? e[i - 1] : INT32_MIN;
         }
-        if (k != ck) { flush(); ck = k; ccnt = 0; cmin = INT32_MAX; cmax = INT32_MIN; }
-        const i32 lo = a < b ? a : b, hi = a < b ? b : a;
-        cmin = lo < cmin ? lo : cmin; cmax = hi > cmax ? hi : cmax; ccnt++;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (i0 + (u64)u * OT >= n) continue;
+            if (k[u] >= nkeys) { bad = true; continue; }
+            // below the row before it? (flags[1]: input not sorted)
+            if (k[u] != pk[u] ? k[u] < pk[u] : (a[u] != pa[u] ? a[u] < pa[u] : b[u] < pb[u])) unsorted = true;
+            const i32 lo = a[u] < b[u] ? a[u] : b[u], hi = a[u] < b[u] ? b[u] : a[u];
+            i32 *pmin = priv ? &smin[k[u]] : &kmin[k[u]], *pmax = priv ? &smax[k[u]] : &kmax[k[u]];
+            if (lo < *(volatile i32 *)pmin) atomicMin(pmin, lo);
+            if (hi > *(volatile i32 *)pmax) atomicMax(pmax, hi);
+        }
     }
-    flush();
     if (bad) flags[0] = 1;
     if (unsorted) flags[1] = 1;
     if (priv) {
         __syncthreads();
         for (u32 k = threadIdx.x; k < nkeys; k += OT)
-            if (scnt[k]) { atomicMin(&kmin[k], smin[k]); atomicMax(&kmax[k], smax[k]); atomicAdd(&kcnt[k], scnt[k]); }
+            if (smin[k] <= smax[k]) { atomicMin(&kmin[k], smin[k]); atomicMax(&kmax[k], smax[k]); }
     }
 }
 
 // one workgroup: origin, base (nkeys + 1 entries), and hdr = {linbits, rowbits, fits}
-__global__ __launch_bounds__(1024) void k_nlin_layout(const i32 *kmin, const i32 *kmax, const u32 *kcnt, u32 nkeys, u64 n,
+__global__ __launch_bounds__(1024) void k_nlin_layout(const i32 *kmin, const i32 *kmax, u32 nkeys, u64 n,
                                                       i32 *origin, u64 *base, u32 *hdr)
 {
     __shared__ u64 red[1024 / IVX_WAVE + 1];
@@ -523,10 +533,11 @@ __global__ __launch_bounds__(1024) void k_nlin_layout(const i32 *kmin, const i32
     u64 run = 0;
     for (u32 k0 = 0; k0 < nkeys; k0 += 1024) {
         const u32 k = k0 + t;
-        const u64 w = (k < nkeys && kcnt[k]) ? (u64)((i64)kmax[k] - (i64)kmin[k]) + 1 : 0;
+        const bool has = k < nkeys && kmin[k] <= kmax[k];              // (a key without rows keeps its sentinels)
+        const u64 w = has ? (u64)((i64)kmax[k] - (i64)kmin[k]) + 1 : 0;
         u64 tot;
         const u64 ex = block_excl_scan<u64, 1024>(w, red, &tot);
-        if (k < nkeys) { base[k] = run + ex; origin[k] = kcnt[k] ? kmin[k] : 0; }
+        if (k < nkeys) { base[k] = run + ex; origin[k] = has ? kmin[k] : 0; }
         run += tot;
     }
     if (t == 0) {
@@ -537,13 +548,14 @@ __global__ __launch_bounds__(1024) void k_nlin_layout(const i32 *kmin, const i32
     }
 }
 
-__global__ __launch_bounds__(OT) void k_pack_lin(const u32 *__restrict__ key, const i32 *__restrict__ v, u64 n, const i32 *__restrict__ origin,
-                                                 const u64 *__restrict__ base, u32 rowbits, u32 vs, u64 *w)
+__global__ __launch_bounds__(OT) void k_pack_lin(const u32 *__restrict__ key, const i32 *__restrict__ v, const i32 *__restrict__ e, u64 n,
+                                                 const i32 *__restrict__ origin, const u64 *__restrict__ base, u32 rowbits, u64 *w, i32 *pay)
 {
     const u64 i = (u64)blockIdx.x * OT + threadIdx.x;
     if (i >= n) return;
     const u32 k = key ? key[i] : 0u;
-    w[i] = ((base[k] + (u64)((i64)v[i * vs] - (i64)origin[k])) << rowbits) | i;
+    w[i] = ((base[k] + (u64)((i64)v[i] - (i64)origin[k])) << rowbits) | i;
+    pay[i] = e[i];                                                      // the end rides along as the record's payload
 }
 
 // key of a linearised coordinate: last k with base[k] <= lin (keys without rows share their successor's base and are
@@ -570,7 +582,7 @@ __global__ __launch_bounds__(OT) void k_unpack_lin(const u64 *__restrict__ w, u6
     const u64 rowmask = (1ull << rowbits) - 1;                          // (rowbits <= 32)
     const u64 x = w[i], lin = x >> rowbits;
     const u32 row = (u32)(x & rowmask);
-    const i32 end = e[row];
+    const i32 end = e[i];                                               // (payloads, in sorted order)
     u64 h = i, t = i + 1;                                               // the run of equal lin around i
     while (h > 0 && i - h < NLIN_MAXRUN && (w[h - 1] >> rowbits) == lin) h--;
     while (t < n && t - i < NLIN_MAXRUN && (w[t] >> rowbits) == lin) t++;
@@ -580,7 +592,7 @@ __global__ __launch_bounds__(OT) void k_unpack_lin(const u64 *__restrict__ w, u6
         u32 below = 0;
         for (u64 j = h; j < t; j++) {
             if (j == i) continue;
-            const i32 ej = e[(u32)(w[j] & rowmask)];
+            const i32 ej = e[j];
             below += (ej < end || (ej == end && j < i)) ? 1u : 0u;
         }
         pos = h + below;
@@ -613,19 +625,17 @@ ivx_status nearest_sorted_records_lin(ivx_ctx *ctx, const u32 *key, const i32 *s
     *done = false;
     if (n < 4096 || n > 0xFFFFFFFFull || getenv("IVX_NEAREST_SORT2")) return IVX_OK;
     hipStream_t st = ctx->stream;
-    i32 *kmin, *kmax, *origin; u32 *kcnt; u64 *base;
+    i32 *kmin, *kmax, *origin; u64 *base;
     IVX_TRY(ctx->get_scratch(WS_GRID0, nkeys * sizeof(i32), (void **)&kmin));
     IVX_TRY(ctx->get_scratch(WS_GRID1, nkeys * sizeof(i32), (void **)&kmax));
-    IVX_TRY(ctx->get_scratch(WS_GRID2, nkeys * sizeof(u32), (void **)&kcnt));
     IVX_TRY(ctx->get_scratch(WS_T3, nkeys * sizeof(i32), (void **)&origin));
     IVX_TRY(ctx->get_scratch(WS_T4, ((size_t)nkeys + 1) * sizeof(u64), (void **)&base));
     u32 *flags = (u32 *)(ctx->d_scalars + 8);                           // [0] bad key, [1] unsorted / run too long
     u32 *hdr = (u32 *)(ctx->d_scalars + 10);
-    IVX_HIP(ctx, hipMemsetAsync(kcnt, 0, nkeys * sizeof(u32), st));
     hipLaunchKernelGGL(k_init_minmax, dim3((nkeys + OT - 1) / OT), dim3(OT), 0, st, kmin, kmax, nkeys);
-    const size_t shm = nkeys <= NLIN_KEYS_LDS ? (size_t)nkeys * 12 : 0;
-    hipLaunchKernelGGL(k_nstats, dim3(ivx_stream_grid(n, OT * 8, 1024)), dim3(OT), shm, st, key, s, e, n, nkeys, kmin, kmax, kcnt, flags);
-    hipLaunchKernelGGL(k_nlin_layout, dim3(1), dim3(1024), 0, st, (const i32 *)kmin, (const i32 *)kmax, (const u32 *)kcnt, nkeys, n, origin, base, hdr);
+    const size_t shm = nkeys <= NLIN_KEYS_LDS ? (size_t)nkeys * 8 : 0;
+    hipLaunchKernelGGL(k_nstats, dim3(ivx_stream_grid(n, OT * 16, 4096)), dim3(OT), shm, st, key, s, e, n, nkeys, kmin, kmax, flags);
+    hipLaunchKernelGGL(k_nlin_layout, dim3(1), dim3(1024), 0, st, (const i32 *)kmin, (const i32 *)kmax, nkeys, n, origin, base, hdr);
     IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 8, ctx->d_scalars + 8, 4 * sizeof(u64), hipMemcpyDeviceToHost, st));
     IVX_HIP(ctx, hipStreamSynchronize(st));
     const u32 *hf = (const u32 *)(ctx->h_scalars + 8), *hh = (const u32 *)(ctx->h_scalars + 10);
@@ -633,17 +643,19 @@ ivx_status nearest_sorted_records_lin(ivx_ctx *ctx, const u32 *key, const i32 *s
     const bool presorted = hf[1] == 0 && !getenv("IVX_FORCE_SORT");
     const u32 linbits = hh[0], rowbits = hh[1];
     if (!hh[2]) return IVX_OK;
-    u64 *a[1], *b[1];
+    u64 *a[1], *b[1]; u32 *pay[2];
     IVX_TRY(ctx->get_scratch(WS_SA0, n * sizeof(u64), (void **)&a[0]));
     IVX_TRY(ctx->get_scratch(WS_SB0, n * sizeof(u64), (void **)&b[0]));
+    IVX_TRY(ctx->get_scratch(WS_SA1, n * sizeof(u32), (void **)&pay[0]));
+    IVX_TRY(ctx->get_scratch(WS_SB1, n * sizeof(u32), (void **)&pay[1]));
     const ivx_sort_field f[1] = {{0, (int)rowbits, (int)(rowbits + linbits)}};
     int in_b = 0;
-    hipLaunchKernelGGL(k_pack_lin, dim3(grid1(n)), dim3(OT), 0, st, key, s, n, (const i32 *)origin, (const u64 *)base, rowbits, 1u, a[0]);
-    if (!presorted) IVX_TRY(ivx_radix_sort(ctx, 1, a, b, n, f, 1, &in_b, true));
+    hipLaunchKernelGGL(k_pack_lin, dim3(grid1(n)), dim3(OT), 0, st, key, s, e, n, (const i32 *)origin, (const u64 *)base, rowbits, a[0], (i32 *)pay[0]);
+    if (!presorted) IVX_TRY(ivx_radix_sort(ctx, 1, a, b, n, f, 1, &in_b, true, pay));
     u64 *w = in_b ? b[0] : a[0], *y = in_b ? a[0] : b[0];
     IVX_HIP(ctx, hipMemsetAsync(flags + 1, 0, sizeof(u32), st));
-    hipLaunchKernelGGL(k_unpack_lin, dim3(grid1(n)), dim3(OT), 0, st, (const u64 *)w, n, nkeys, (const i32 *)origin, (const u64 *)base, e, rowbits,
-                       ks, rs, y, flags + 1);
+    hipLaunchKernelGGL(k_unpack_lin, dim3(grid1(n)), dim3(OT), 0, st, (const u64 *)w, n, nkeys, (const i32 *)origin, (const u64 *)base,
+                       (const i32 *)pay[in_b], rowbits, ks, rs, y, flags + 1);
     a[0] = y; b[0] = w;
     IVX_TRY(ivx_radix_sort(ctx, 1, a, b, n, f, 1, &in_b, true));
     hipLaunchKernelGGL(k_unpack_lin_end, dim3(grid1(n)), dim3(OT), 0, st, (const u64 *)(in_b ? b[0] : a[0]), n, rowbits, (const ivx_nrec *)rs, re);

@@ -32,8 +32,8 @@ template <int NW> struct Tile {
     static constexpr int WT = N / RS_WAVES;     // consecutive records per wavefront
 };
 
-template <int NW> struct Ptrs { u64 *w[NW]; };
-template <int NW> struct CPtrs { const u64 *w[NW]; };
+template <int NW> struct Ptrs { u64 *w[NW]; u32 *p; };            // p: optional 32-bit payload riding along (12-byte records for NW = 1)
+template <int NW> struct CPtrs { const u64 *w[NW]; const u32 *p; };
 
 // word `word` of a record held in registers, without a runtime-indexed array
 // (a runtime index would send the record to scratch memory)
@@ -112,12 +112,13 @@ __global__ __launch_bounds__(RS_HT) void k_hist(const u64 *__restrict__ w, u64 n
     }
 }
 
-template <int NW>
+template <int NW, bool PAY>
 __global__ __launch_bounds__(RS_T) void k_scatter(CPtrs<NW> in, Ptrs<NW> out, u64 n, int word, int shift, u32 nblk,
                                                  const u32 *__restrict__ offs)
 {
     constexpr int RS_I = Tile<NW>::I, RS_TILE = Tile<NW>::N, RS_WTILE = Tile<NW>::WT;
     __shared__ u64 rec[NW][RS_TILE];
+    __shared__ u32 recp[PAY ? RS_TILE : 1];
     __shared__ u32 wcnt[RS_WAVES][256];          // per-wave digit counts -> exclusive offsets across waves
     __shared__ u32 dstart[256];                  // first local slot of the digit in this tile
     __shared__ u32 tcnt[256];                    // records of the digit in this tile
@@ -132,29 +133,34 @@ __global__ __launch_bounds__(RS_T) void k_scatter(CPtrs<NW> in, Ptrs<NW> out, u6
     // 8-byte records: the next tile's records are loaded while this one goes through LDS (registers allow it)
     constexpr bool PREFETCH = NW == 1;
     u64 nxt[PREFETCH ? RS_I : 1][NW];
-    auto load_tile = [&](u64 t0, u64 (&dst)[PREFETCH ? RS_I : 1][NW]) {
+    u32 nxp[PREFETCH && PAY ? RS_I : 1];
+    auto load_tile = [&](u64 t0, u64 (&dst)[PREFETCH ? RS_I : 1][NW], u32 (&dp)[PREFETCH && PAY ? RS_I : 1]) {
         if (!PREFETCH) return;
         const u32 tn = (u32)(hi - t0 < RS_TILE ? hi - t0 : RS_TILE);
         if (tn == RS_TILE) {
 #pragma unroll
-            for (int k = 0; k < RS_I; k++)
+            for (int k = 0; k < RS_I; k++) {
 #pragma unroll
                 for (int q = 0; q < NW; q++) dst[PREFETCH ? k : 0][q] = in.w[q][t0 + wv * RS_WTILE + k * IVX_WAVE + ln];
+                if (PAY) dp[PREFETCH && PAY ? k : 0] = in.p[t0 + wv * RS_WTILE + k * IVX_WAVE + ln];
+            }
         } else {
 #pragma unroll
             for (int k = 0; k < RS_I; k++) {
                 const u32 j = wv * RS_WTILE + k * IVX_WAVE + ln;
 #pragma unroll
                 for (int q = 0; q < NW; q++) dst[PREFETCH ? k : 0][q] = j < tn ? in.w[q][t0 + j] : 0;
+                if (PAY) dp[PREFETCH && PAY ? k : 0] = j < tn ? in.p[t0 + j] : 0u;
             }
         }
     };
-    if (PREFETCH && lo < hi) load_tile(lo, nxt);
+    if (PREFETCH && lo < hi) load_tile(lo, nxt, nxp);
     for (u64 t0 = lo; t0 < hi; t0 += RS_TILE) {
         for (int i = tid; i < RS_WAVES * 256; i += RS_T) (&wcnt[0][0])[i] = 0;
         __syncthreads();
         const u32 tile_n = (u32)(hi - t0 < RS_TILE ? hi - t0 : RS_TILE);
         u64 r[RS_I][NW];
+        u32 rp[PAY ? RS_I : 1];
         u32 dig[RS_I], lrank[RS_I];
         // ---- the wave's records of this tile: every load is issued before the first one is used (a load inside the
         //      ranking loop below would be a full memory round trip per record)
@@ -163,18 +169,25 @@ __global__ __launch_bounds__(RS_T) void k_scatter(CPtrs<NW> in, Ptrs<NW> out, u6
             for (int k = 0; k < RS_I; k++)
 #pragma unroll
                 for (int q = 0; q < NW; q++) r[k][q] = nxt[PREFETCH ? k : 0][q];
-            if (t0 + RS_TILE < hi) load_tile(t0 + RS_TILE, nxt);
+            if (PAY) {
+#pragma unroll
+                for (int k = 0; k < RS_I; k++) rp[PAY ? k : 0] = nxp[PREFETCH && PAY ? k : 0];
+            }
+            if (t0 + RS_TILE < hi) load_tile(t0 + RS_TILE, nxt, nxp);
         } else if (tile_n == RS_TILE) {
 #pragma unroll
-            for (int k = 0; k < RS_I; k++)
+            for (int k = 0; k < RS_I; k++) {
 #pragma unroll
                 for (int q = 0; q < NW; q++) r[k][q] = in.w[q][t0 + wv * RS_WTILE + k * IVX_WAVE + ln];
+                if (PAY) rp[PAY ? k : 0] = in.p[t0 + wv * RS_WTILE + k * IVX_WAVE + ln];
+            }
         } else {
 #pragma unroll
             for (int k = 0; k < RS_I; k++) {
                 const u32 j = wv * RS_WTILE + k * IVX_WAVE + ln;
 #pragma unroll
                 for (int q = 0; q < NW; q++) r[k][q] = j < tile_n ? in.w[q][t0 + j] : 0;
+                if (PAY) rp[PAY ? k : 0] = j < tile_n ? in.p[t0 + j] : 0u;
             }
         }
         // ---- stable rank inside the wave's slice (index order = round, lane)
@@ -213,6 +226,7 @@ __global__ __launch_bounds__(RS_T) void k_scatter(CPtrs<NW> in, Ptrs<NW> out, u6
                 const u32 pos = dstart[dig[k]] + wcnt[wv][dig[k]] + lrank[k];
 #pragma unroll
                 for (int q = 0; q < NW; q++) rec[q][pos] = r[k][q];
+                if (PAY) recp[PAY ? pos : 0] = rp[PAY ? k : 0];
             }
         }
         __syncthreads();
@@ -228,6 +242,7 @@ __global__ __launch_bounds__(RS_T) void k_scatter(CPtrs<NW> in, Ptrs<NW> out, u6
                 const u64 g = (u64)gbase[d] + (j - dstart[d]);
 #pragma unroll
                 for (int q = 0; q < NW; q++) out.w[q][g] = x[q];
+                if (PAY) out.p[g] = recp[PAY ? j : 0];
             }
         }
         __syncthreads();
@@ -236,8 +251,9 @@ __global__ __launch_bounds__(RS_T) void k_scatter(CPtrs<NW> in, Ptrs<NW> out, u6
     }
 }
 
-template <int NW>
-ivx_status sort_impl(ivx_ctx *ctx, u64 *const *a, u64 *const *b, u64 n, const ivx_sort_field *fields, int nfields, int *in_b, bool tight)
+template <int NW, bool PAY>
+ivx_status sort_impl(ivx_ctx *ctx, u64 *const *a, u64 *const *b, u64 n, const ivx_sort_field *fields, int nfields, int *in_b, bool tight,
+                     u32 *const *pay)
 {
     *in_b = 0;
     if (n <= 1) return IVX_OK;
@@ -270,9 +286,10 @@ ivx_status sort_impl(ivx_ctx *ctx, u64 *const *a, u64 *const *b, u64 n, const iv
             u64 *const *dst = cur ? a : b;
             CPtrs<NW> ci; Ptrs<NW> po;
             for (int q = 0; q < NW; q++) { ci.w[q] = src[q]; po.w[q] = dst[q]; }
+            ci.p = PAY ? pay[cur] : nullptr; po.p = PAY ? pay[cur ^ 1] : nullptr;
             hipLaunchKernelGGL(k_hist, dim3(nblk), dim3(RS_HT), 0, st, (const u64 *)src[fields[f].word], n, sh, nblk, hist);
             IVX_TRY(ivx_scan_exclusive_u32(ctx, hist, (u64)256 * nblk));
-            hipLaunchKernelGGL((k_scatter<NW>), dim3(nblk), dim3(RS_T), 0, st, ci, po, n, fields[f].word, sh, nblk, (const u32 *)hist);
+            hipLaunchKernelGGL((k_scatter<NW, PAY>), dim3(nblk), dim3(RS_T), 0, st, ci, po, n, fields[f].word, sh, nblk, (const u32 *)hist);
             cur ^= 1;
         }
     }
@@ -284,12 +301,13 @@ ivx_status sort_impl(ivx_ctx *ctx, u64 *const *a, u64 *const *b, u64 n, const iv
 }  // namespace
 
 ivx_status ivx_radix_sort(ivx_ctx *ctx, int nw, u64 *const *a, u64 *const *b, u64 n,
-                          const ivx_sort_field *fields, int nfields, int *in_b, bool tight)
+                          const ivx_sort_field *fields, int nfields, int *in_b, bool tight, u32 *const *pay)
 {
+    if (pay && nw != 1) return ctx->fail(IVX_ERR_INVALID, "sort: a 32-bit payload goes with one-word records");
     switch (nw) {
-    case 1: return sort_impl<1>(ctx, a, b, n, fields, nfields, in_b, tight);
-    case 2: return sort_impl<2>(ctx, a, b, n, fields, nfields, in_b, tight);
-    case 3: return sort_impl<3>(ctx, a, b, n, fields, nfields, in_b, tight);
+    case 1: return pay ? sort_impl<1, true>(ctx, a, b, n, fields, nfields, in_b, tight, pay) : sort_impl<1, false>(ctx, a, b, n, fields, nfields, in_b, tight, pay);
+    case 2: return sort_impl<2, false>(ctx, a, b, n, fields, nfields, in_b, tight, pay);
+    case 3: return sort_impl<3, false>(ctx, a, b, n, fields, nfields, in_b, tight, pay);
     default: return ctx->fail(IVX_ERR_INVALID, "sort: unsupported record width");
     }
 }
@@ -313,6 +331,29 @@ extern "C" ivx_status ivx_debug_sort(ivx_ctx *ctx, int nw, u64 *w0, u64 *w1, u64
     IVX_TRY(ivx_radix_sort(ctx, nw, a, b, n, f, nfields, &in_b));
     for (int q = 0; q < nw; q++)
         IVX_HIP(ctx, hipMemcpyAsync(host[q], in_b ? b[q] : a[q], n * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+    IVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return IVX_OK;
+}
+
+// test hook: one-word records with a 32-bit payload (pay may be NULL), fields at any bit position, `tight` as the library passes it
+extern "C" ivx_status ivx_debug_sort_pay(ivx_ctx *ctx, u64 *w0, u32 *pay, u64 n, int lo, int hi, int tight)
+{
+    if (!ctx || !w0) return IVX_ERR_INVALID;
+    IVX_HIP(ctx, hipSetDevice(ctx->device));
+    u64 *a[1], *b[1]; u32 *p[2] = {nullptr, nullptr};
+    IVX_TRY(ctx->get_scratch(WS_SA0, n * sizeof(u64), (void **)&a[0]));
+    IVX_TRY(ctx->get_scratch(WS_SB0, n * sizeof(u64), (void **)&b[0]));
+    IVX_HIP(ctx, hipMemcpyAsync(a[0], w0, n * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+    if (pay) {
+        IVX_TRY(ctx->get_scratch(WS_SA1, n * sizeof(u32), (void **)&p[0]));
+        IVX_TRY(ctx->get_scratch(WS_SB1, n * sizeof(u32), (void **)&p[1]));
+        IVX_HIP(ctx, hipMemcpyAsync(p[0], pay, n * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+    }
+    const ivx_sort_field f[1] = {{0, lo, hi}};
+    int in_b = 0;
+    IVX_TRY(ivx_radix_sort(ctx, 1, a, b, n, f, 1, &in_b, tight != 0, pay ? p : nullptr));
+    IVX_HIP(ctx, hipMemcpyAsync(w0, in_b ? b[0] : a[0], n * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+    if (pay) IVX_HIP(ctx, hipMemcpyAsync(pay, p[in_b], n * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
     IVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return IVX_OK;
 }

@@ -10,5 +10,7 @@ struct ivx_sort_field { int word, lo, hi; };
 // the sorted records ended up (1 = in b).  Uses scratch WS_SORTHIST and WS_SCAN*.
 // tight: the fields were packed from the value ranges of the data, so every digit varies (skips the pass that looks
 // for constant digits).
+// pay (nw == 1 only): pay[0] holds one 32-bit payload per record that travels with it (12-byte records), pay[1] is
+// same-sized scratch; the payloads end up in pay[*in_b].
 ivx_status ivx_radix_sort(ivx_ctx *ctx, int nw, u64 *const *a, u64 *const *b, u64 n,
-                          const ivx_sort_field *fields, int nfields, int *in_b, bool tight = false);
+                          const ivx_sort_field *fields, int nfields, int *in_b, bool tight = false, u32 *const *pay = nullptr);

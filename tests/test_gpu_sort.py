@@ -74,3 +74,28 @@ def test_sort_skewed_single_digit():
     want = _ref([w0, w1], [(0, 0, 8)])
     assert (got[0] == want[0]).all() and (got[1] == want[1]).all()
     ctx.close()
+
+
+@pytest.mark.parametrize("n,lo,hi,pay,tight", [(1, 0, 8, True, 0), (8191, 26, 58, True, 1), (8193, 26, 58, False, 1), (70_001, 3, 36, True, 0),
+                                              (1_000_003, 26, 58, True, 1), (1_000_003, 30, 63, False, 0), (3_000_000, 20, 53, True, 1)])
+def test_sort_one_word_with_payload(n, lo, hi, pay, tight):
+    # 8-byte records (+ a 32-bit payload riding along): the form the nearest index build and the sweeps sort
+    ctx = pyivx.Ctx(0)
+    rng = np.random.default_rng(n + lo)
+    w = rng.integers(0, 1 << 63, n, dtype=np.uint64)
+    if hi < 64:
+        w &= (np.uint64(1) << np.uint64(hi)) - np.uint64(1)
+    w = (w >> np.uint64(lo) << np.uint64(lo)) | (np.arange(n, dtype=np.uint64) & ((np.uint64(1) << np.uint64(lo)) - np.uint64(1)))
+    if n > 8:
+        w[: n // 7 * 7 : 7] = w[1 : n // 7 * 7 : 7]                   # ties
+    p = rng.integers(0, 1 << 32, n, dtype=np.uint32)
+    gw, gp = w.copy(), p.copy()
+    st = pyivx.lib().ivx_debug_sort_pay(ctx.h, gw.ctypes.data_as(C.c_void_p), gp.ctypes.data_as(C.c_void_p) if pay else None,
+                                        C.c_uint64(n), C.c_int(lo), C.c_int(hi), C.c_int(tight))
+    assert st == 0, pyivx.lib().ivx_last_error(ctx.h)
+    mask = (np.uint64(1) << np.uint64(hi - lo)) - np.uint64(1)
+    order = np.argsort((w >> np.uint64(lo)) & mask, kind="stable")
+    assert (gw == w[order]).all()
+    if pay:
+        assert (gp == p[order]).all()
+    ctx.close()
