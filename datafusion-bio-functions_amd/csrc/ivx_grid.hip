@@ -8,10 +8,14 @@ namespace {
 constexpr int GT = 256;
 constexpr u32 KEYS_IN_LDS = 2048;
 
-__global__ void k_init_keystats(i32 *kmin, i32 *kmax, u32 *kcnt, u32 nkeys)
+// (+ up to three short word ranges of the caller's to zero: flags and headers that would each be a memset launch)
+__global__ void k_init_keystats(i32 *kmin, i32 *kmax, u32 *kcnt, u32 nkeys, ivx_zero_ranges z)
 {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nkeys) { kmin[i] = INT32_MAX; kmax[i] = INT32_MIN; kcnt[i] = 0; }
+    if (blockIdx.x == 0)
+        for (int r = 0; r < 3; r++)
+            for (u32 j = threadIdx.x; j < z.n[r]; j += blockDim.x) z.p[r][j] = 0;
 }
 
 // per-key min / max of v and row counts, privatised in LDS; key ids >= nkeys raise *errflag.
@@ -202,10 +206,13 @@ ivx_status ivx_keystats(ivx_ctx *ctx, const u32 *key, const i32 *v, u64 n, u32 n
 }
 
 ivx_status ivx_keystats_len(ivx_ctx *ctx, const u32 *key, const i32 *v, u64 n, u32 nkeys,
-                            i32 *kmin, i32 *kmax, u32 *kcnt, u32 *errflag, u32 vstride, const i32 *vend, u32 *lenhist)
+                            i32 *kmin, i32 *kmax, u32 *kcnt, u32 *errflag, u32 vstride, const i32 *vend, u32 *lenhist,
+                            const ivx_zero_ranges *zero)
 {
     hipStream_t st = ctx->stream;
-    hipLaunchKernelGGL(k_init_keystats, dim3((nkeys + GT - 1) / GT), dim3(GT), 0, st, kmin, kmax, kcnt, nkeys);
+    ivx_zero_ranges z{};
+    if (zero) z = *zero;
+    hipLaunchKernelGGL(k_init_keystats, dim3((nkeys + GT - 1) / GT), dim3(GT), 0, st, kmin, kmax, kcnt, nkeys, z);
     if (n) {
         const u32 grid = ivx_stream_grid(n, GT * 8, 1024);
         const size_t shm = nkeys <= KEYS_IN_LDS ? (size_t)nkeys * 12 : 0;

@@ -50,5 +50,8 @@ ivx_status ivx_grid_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32
 ivx_status ivx_keystats(ivx_ctx *ctx, const u32 *key, const i32 *v, u64 n, u32 nkeys,
                         i32 *kmin, i32 *kmax, u32 *kcnt, u32 *errflag, u32 vstride);
 // ... and the histogram of the length classes of [v, vend] (33 counters, zeroed by the caller; vstride must be 1)
+// zero (nullable): short word ranges the initialising kernel clears on the way (the caller's flags / headers)
+struct ivx_zero_ranges { u32 *p[3]; u32 n[3]; };
 ivx_status ivx_keystats_len(ivx_ctx *ctx, const u32 *key, const i32 *v, u64 n, u32 nkeys,
-                            i32 *kmin, i32 *kmax, u32 *kcnt, u32 *errflag, u32 vstride, const i32 *vend, u32 *lenhist);
+                            i32 *kmin, i32 *kmax, u32 *kcnt, u32 *errflag, u32 vstride, const i32 *vend, u32 *lenhist,
+                            const ivx_zero_ranges *zero = nullptr);

@@ -559,16 +559,15 @@ ivx_status ivx_join_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32
     errflag = (u32 *)(ctx->d_scalars + 8);
     u32 *lenhist = (u32 *)(ctx->d_scalars + 32);                        // 33 counters
 
-    IVX_HIP(ctx, hipMemsetAsync(errflag, 0, sizeof(u32), st));
-    IVX_HIP(ctx, hipMemsetAsync(lenhist, 0, 34 * sizeof(u32), st));
     IVX_HIP(ctx, hipMemsetAsync(binstart, 0, (maxcells + 1) * sizeof(u32), st));
-    IVX_HIP(ctx, hipMemsetAsync(hdr, 0, HDR_WORDS * sizeof(u32), st));
+    const ivx_zero_ranges zr{{errflag, lenhist, hdr}, {1u, 34u, (u32)HDR_WORDS}};     // cleared by the key-statistics' first kernel
     // IVX_FILTER=0: no occupancy bitmap; =force: whenever it fits (tests); default: when it would reject most probe rows
     const char *fenv = getenv("IVX_FILTER");
     const int filter_mode = !fenv ? 1 : !strcmp(fenv, "0") ? 0 : !strcmp(fenv, "force") ? 2 : 1;
     if (filter_mode) IVX_HIP(ctx, hipMemsetAsync(fbits, 0, fwords * sizeof(u32), st));
-    IVX_TRY(ivx_keystats_len(ctx, key, s, n, nkeys, kmin, kmax, kcnt, errflag, 1u, e, lenhist));   // + the length classes for the layout
-    const u32 grid = ivx_stream_grid(n, BT * 8, 1024);
+    IVX_TRY(ivx_keystats_len(ctx, key, s, n, nkeys, kmin, kmax, kcnt, errflag, 1u, e, lenhist, &zr));   // + the length classes for the layout
+    // (every row's atomic returns a value, its loads depend on nothing: a row or two per thread, not a loop of eight round trips)
+    const u32 grid = ivx_stream_grid(n, BT * 2, 16384);
     hipLaunchKernelGGL(k_join_layout, dim3(1), dim3(1024), 0, st, kmin, kmax, kcnt, nkeys, n, origin, span, lbase, hdr, maxcells, kreg, rkey, (const u32 *)lenhist, (u32)(regcap - 1), fbase, filter_mode);
     if (filter_mode) hipLaunchKernelGGL(k_join_filter, dim3(grid), dim3(BT), 0, st, key, s, e, n, nkeys, (const i32 *)origin, (const u32 *)span, (const u32 *)fbase, (const u32 *)hdr, fbits);
     hipLaunchKernelGGL(k_join_count, dim3(grid), dim3(BT), 0, st, key, s, e, n, nkeys, origin, lbase, hdr, binstart, cellid, rank);

@@ -109,16 +109,16 @@ __device__ __forceinline__ u64 shr64(u64 x, u32 sh) { return sh >= 64 ? 0 : x >>
 __device__ __forceinline__ u64 low64(u64 x, u32 bits) { return bits >= 64 ? x : x & ((1ull << bits) - 1); }
 
 __global__ __launch_bounds__(ST) void k_pack1(const u32 *__restrict__ key, const i64 *__restrict__ s, const i64 *__restrict__ e,
-                                              u64 n, Pack64 p, u64 *w0, u64 *w1)
+                                              u64 n, Pack64 p, u64 *w0, u32 *w1)
 {
     const u64 i = (u64)blockIdx.x * ST + threadIdx.x;
     if (i >= n) return;
     const u64 k = key ? key[i] : 0u;
     w0[i] = shl64(k, p.bits_s + p.bits_e) | shl64((u64)s[i] - (u64)p.min_s, p.bits_e) | ((u64)e[i] - (u64)p.min_e);
-    if (w1) w1[i] = i;                                                  // (callers that do not ask for row ids sort the 8-byte words alone)
-}
+    if (w1) w1[i] = (u32)i;                                             // the row id rides along as a 32-bit payload (12-byte records); callers
+}                                                                       // that do not ask for row ids sort the 8-byte words alone
 
-__global__ __launch_bounds__(ST) void k_unpack1(const u64 *__restrict__ w0, const u64 *__restrict__ w1, u64 n, Pack64 p,
+__global__ __launch_bounds__(ST) void k_unpack1(const u64 *__restrict__ w0, const u32 *__restrict__ w1, u64 n, Pack64 p,
                                                 u32 *ks, i64 *ss, i64 *es, u32 *rows)
 {
     const u64 i = (u64)blockIdx.x * ST + threadIdx.x;
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(ST) void k_unpack1(const u64 *__restrict__ w0, cons
     ks[i] = (u32)shr64(w, p.bits_s + p.bits_e);
     ss[i] = (i64)(low64(shr64(w, p.bits_e), p.bits_s) + (u64)p.min_s);
     es[i] = (i64)(low64(w, p.bits_e) + (u64)p.min_e);
-    if (rows && w1) rows[i] = (u32)w1[i];
+    if (rows && w1) rows[i] = w1[i];
 }
 
 // rows that already are in (key,start,end) order: the sorted columns are the input columns, row ids 0..n-1
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(ST) void k_copy_sorted(const u32 *__restrict__ key,
 // rows), so the thread at the head of a run insertion-sorts it in place; a run longer than FIX_MAXRUN raises
 // *toolong and the host falls back to the full-width sort.
 constexpr u32 FIX_MAXRUN = 64;
-__global__ __launch_bounds__(ST) void k_fix_runs(u64 *__restrict__ w0, u64 *__restrict__ w1, u64 n, u32 lo_bits, u32 *toolong)
+__global__ __launch_bounds__(ST) void k_fix_runs(u64 *__restrict__ w0, u32 *__restrict__ w1, u64 n, u32 lo_bits, u32 *toolong)
 {
     const u64 i = (u64)blockIdx.x * ST + threadIdx.x;
     if (i >= n) return;
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(ST) void k_fix_runs(u64 *__restrict__ w0, u64 *__re
     while (i + len < n && len <= FIX_MAXRUN && (w0[i + len] >> lo_bits) == h) len++;
     if (len > FIX_MAXRUN) { *toolong = 1; return; }
     for (u32 a = 1; a < len; a++) {                                     // stable: equal words keep their (row) order
-        const u64 x0 = w0[i + a], x1 = w1 ? w1[i + a] : 0;
+        const u64 x0 = w0[i + a]; const u32 x1 = w1 ? w1[i + a] : 0u;
         u32 b = a;
         while (b > 0 && w0[i + b - 1] > x0) { w0[i + b] = w0[i + b - 1]; if (w1) w1[i + b] = w1[i + b - 1]; b--; }
         w0[i + b] = x0; if (w1) w1[i + b] = x1;
@@ -193,16 +193,22 @@ ivx_status sort64(ivx_ctx *ctx, int slot_a, int slot_b, const u32 *key, const i6
     const u32 bits_k = bits_of(nkeys ? nkeys - 1 : 0);
     const u32 total = p.bits_s + p.bits_e + bits_k;
     u64 *a[3] = {nullptr, nullptr, nullptr}, *b[3] = {nullptr, nullptr, nullptr};
-    // packed: one 64-bit sort word, plus the row ids only when the caller wants them back (merge / complement / the
-    // right side of subtract do not: equal words are equal rows, and the record is 8 bytes instead of 16)
-    const int nw = total <= 64 ? (rows ? 2 : 1) : 3;
+    // packed: one 64-bit sort word, plus the row ids -- a 32-bit payload -- only when the caller wants them back (merge /
+    // complement / the right side of subtract do not: equal words are equal rows, and the record is 8 bytes instead of 12)
+    const int nw = total <= 64 ? 1 : 3;
     for (int q = 0; q < nw; q++) {
         IVX_TRY(ctx->get_scratch(slot_a + q, n * sizeof(u64), (void **)&a[q]));
         IVX_TRY(ctx->get_scratch(slot_b + q, n * sizeof(u64), (void **)&b[q]));
     }
+    u32 *pay[2] = {nullptr, nullptr};
+    const bool with_rows = nw == 1 && rows != nullptr;
+    if (with_rows) {
+        IVX_TRY(ctx->get_scratch(slot_a + 1, n * sizeof(u32), (void **)&pay[0]));
+        IVX_TRY(ctx->get_scratch(slot_b + 1, n * sizeof(u32), (void **)&pay[1]));
+    }
     int in_b = 0;
-    if (nw <= 2) {
-        hipLaunchKernelGGL(k_pack1, dim3(grid1(n)), dim3(ST), 0, st, key, s, e, n, p, a[0], a[1]);
+    if (nw == 1) {
+        hipLaunchKernelGGL(k_pack1, dim3(grid1(n)), dim3(ST), 0, st, key, s, e, n, p, a[0], pay[0]);
         // Few rows share a (key,start) when the rows are sparse in the coordinate space: then sort on those bits
         // only -- the end bits would be three or four more digit passes -- and order the short runs of equal
         // (key,start) afterwards (k_fix_runs).
@@ -212,24 +218,24 @@ ivx_status sort64(ivx_ctx *ctx, int slot_a, int slot_b, const u32 *key, const i6
         if (two_step) {
             const int lo = (int)p.bits_e;
             const ivx_sort_field f[1] = {{0, lo, lo + (int)((total - p.bits_e + 7) / 8 * 8)}};
-            IVX_TRY(ivx_radix_sort(ctx, nw, a, b, n, f, 1, &in_b, true));
+            IVX_TRY(ivx_radix_sort(ctx, 1, a, b, n, f, 1, &in_b, true, with_rows ? pay : nullptr));
             o = in_b ? b : a;
             u32 *toolong = flags + 1;                                   // (upper half of the key-flag word; zeroed by the caller)
-            hipLaunchKernelGGL(k_fix_runs, dim3(grid1(n)), dim3(ST), 0, st, o[0], o[1], n, p.bits_e, toolong);
+            hipLaunchKernelGGL(k_fix_runs, dim3(grid1(n)), dim3(ST), 0, st, o[0], pay[in_b], n, p.bits_e, toolong);
             IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 8, flags, sizeof(u64), hipMemcpyDeviceToHost, st));
             IVX_HIP(ctx, hipStreamSynchronize(st));
             if (((const u32 *)(ctx->h_scalars + 8))[1]) {                // a long run of equal (key,start): the plain way after all
                 IVX_HIP(ctx, hipMemsetAsync(toolong, 0, sizeof(u32), st));
-                hipLaunchKernelGGL(k_pack1, dim3(grid1(n)), dim3(ST), 0, st, key, s, e, n, p, a[0], a[1]);
+                hipLaunchKernelGGL(k_pack1, dim3(grid1(n)), dim3(ST), 0, st, key, s, e, n, p, a[0], pay[0]);
                 two_step = false;
             }
         }
         if (!two_step) {
             const ivx_sort_field f[1] = {{0, 0, (int)((total + 7) / 8 * 8)}};
-            IVX_TRY(ivx_radix_sort(ctx, nw, a, b, n, f, 1, &in_b, true));
+            IVX_TRY(ivx_radix_sort(ctx, 1, a, b, n, f, 1, &in_b, true, with_rows ? pay : nullptr));
             o = in_b ? b : a;
         }
-        hipLaunchKernelGGL(k_unpack1, dim3(grid1(n)), dim3(ST), 0, st, (const u64 *)o[0], (const u64 *)o[1], n, p, ks, ss, es, rows);
+        hipLaunchKernelGGL(k_unpack1, dim3(grid1(n)), dim3(ST), 0, st, (const u64 *)o[0], (const u32 *)pay[in_b], n, p, ks, ss, es, rows);
     } else {
         hipLaunchKernelGGL(k_pack64, dim3(grid1(n)), dim3(ST), 0, st, key, s, e, n, nkeys, a[0], a[1], a[2], flags);
         const ivx_sort_field f[3] = {{0, 0, 64}, {1, 0, 64}, {2, 32, 64}};
