@@ -100,44 +100,120 @@ struct HeadIn {
         return h;
     }
 };
-struct HeadOut {
+// the run-head scan's results: row i closes its run when row i + 1 starts one (or is missing) -- the run is emitted right
+// here (its id is the number of heads so far, its first row the latest head); ha (nullable) keeps the per-row values for
+// cluster()
+struct HeadEmitOut {
     HeadAcc *ha;
-    __device__ void operator()(u64 i, const HeadAcc &h) const { ha[i] = h; }
+    const u32 *ks; const i64 *ss, *cur_end; i64 d; int strict; u64 n; ivx_runs_out out; u64 *m;
+    __device__ void operator()(u64 i, const HeadAcc &h) const
+    {
+        if (ha) ha[i] = h;
+        const bool last = i + 1 == n || ks[i + 1] != ks[i] || !merges(ss[i + 1], cur_end[i], d, strict);
+        if (last) {
+            const u32 id = h.heads - 1;
+            if (out.key) out.key[id] = ks[i];
+            if (out.start) out.start[id] = ss[h.last_head];
+            if (out.end) out.end[id] = cur_end[i];
+            if (out.count) out.count[id] = (i64)(i - h.last_head + 1);
+        }
+        if (i + 1 == n) *m = h.heads;
+    }
 };
 
-__global__ __launch_bounds__(RT) void k_emit_runs(const u32 *__restrict__ ks, const i64 *__restrict__ ss, const i64 *__restrict__ cur_end,
-                                                  const HeadAcc *__restrict__ ha, u64 n, ivx_runs_out out, u64 *m)
+// The cur_end scan's second pass (ivxscan::k_apply_f over MergeOp) which, holding cur_end BEFORE every row of its tile in
+// registers anyway, also decides the run heads and leaves the tile's head summary: the run-head scan then needs no
+// reduce pass of its own over the columns.
+__global__ __launch_bounds__(ivxscan::T_) void k_merge_apply(StateIn in, CurEndOut out, u64 n, const MState *__restrict__ offs, HeadAcc *__restrict__ hsums)
 {
-    const u64 i = (u64)blockIdx.x * RT + threadIdx.x;
-    if (i >= n) return;
-    const HeadAcc h = ha[i];
-    const bool last = i + 1 == n || ha[i + 1].heads != h.heads;
-    if (last) {
-        const u32 id = h.heads - 1;
-        if (out.key) out.key[id] = ks[i];
-        if (out.start) out.start[id] = ss[h.last_head];
-        if (out.end) out.end[id] = cur_end[i];
-        if (out.count) out.count[id] = (i64)(i - h.last_head + 1);
+    using namespace ivxscan;
+    __shared__ MState lds[T_ / IVX_WAVE + 1];
+    __shared__ MState edge[T_ / IVX_WAVE];
+    __shared__ HeadAcc hl[T_ / IVX_WAVE + 1];
+    const u64 base = (u64)blockIdx.x * TILE_ + (u64)threadIdx.x * I_;
+    MState v[I_];
+    MState s = MergeOp::identity();
+#pragma unroll
+    for (int i = 0; i < I_; i++) { v[i] = base + i < n ? in(base + i) : MergeOp::identity(); s = MergeOp::combine(s, v[i]); }
+    MState tot;
+    MState inc = block_incl<MergeOp>(s, lds, &tot);
+    MState run = offs ? offs[blockIdx.x] : MergeOp::identity();
+    MState prev = MergeOp::shfl_up(inc, 1);
+    if (lane_id() == IVX_WAVE - 1) edge[threadIdx.x / IVX_WAVE] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) prev = MergeOp::identity();
+    else if (lane_id() == 0) prev = edge[threadIdx.x / IVX_WAVE - 1];
+    run = MergeOp::combine(run, prev);
+    HeadAcc hacc = HeadOp::identity();
+#pragma unroll
+    for (int i = 0; i < I_; i++) {
+        const u64 idx = base + i;
+        if (idx < n) {
+            // (a key's first row -- and a strict row at i64::MAX -- is a constant state: a head; otherwise `run` covers row 0,
+            //  hence is constant, and run.c is cur_end after row idx - 1)
+            const bool head = v[i].konst || !merges(in.ss[idx], run.c, in.d, in.strict);
+            HeadAcc h; h.heads = head ? 1u : 0u; h.last_head = head ? (u32)idx : 0u;
+            hacc = HeadOp::combine(hacc, h);
+            run = MergeOp::combine(run, v[i]);
+            out(idx, run);
+        }
     }
-    if (i + 1 == n) *m = h.heads;
+    HeadAcc htot;
+    block_incl<HeadOp>(hacc, hl, &htot);
+    if (threadIdx.x == 0) hsums[blockIdx.x] = htot;
+}
+
+// The run-head scan's second pass with the tile's rows STRIPED over the threads (thread t takes rows t, t + 256, ... of
+// the tile, one workgroup scan per stripe): consecutive lanes hold consecutive rows, so the runs they emit -- and the
+// per-row values -- go out in whole cache lines (with a thread owning four consecutive rows every store is strided).
+__global__ __launch_bounds__(ivxscan::T_) void k_head_apply(HeadIn in, HeadEmitOut out, u64 n, const HeadAcc *__restrict__ offs)
+{
+    using namespace ivxscan;
+    __shared__ HeadAcc lds[T_ / IVX_WAVE + 1];
+    HeadAcc carry = offs ? offs[blockIdx.x] : HeadOp::identity();
+    const u64 base = (u64)blockIdx.x * TILE_ + threadIdx.x;
+    HeadAcc v[I_];
+#pragma unroll
+    for (int k = 0; k < I_; k++) { const u64 i = base + (u64)k * T_; v[k] = i < n ? in(i) : HeadOp::identity(); }
+#pragma unroll
+    for (int k = 0; k < I_; k++) {
+        const u64 i = base + (u64)k * T_;
+        HeadAcc tot;
+        const HeadAcc inc = block_incl<HeadOp>(v[k], lds, &tot);
+        if (i < n) out(i, HeadOp::combine(carry, inc));
+        carry = HeadOp::combine(carry, tot);
+    }
 }
 
 }  // namespace
 
-// cur_end scan -> run-head scan -> runs; both scans compute their elements from the sorted columns on the fly (no
-// state array: 124 instead of 232 bytes of traffic per row); leaves cur_end / ha (n entries each) in WS_T5 / WS_T6
+// cur_end scan -> run-head scan -> runs; both scans compute their elements from the sorted columns on the fly, the first
+// one's second pass doubles as the second one's first, and the runs are emitted by the last pass itself: 68 bytes of
+// traffic per row (232 with a materialised state array, 108 with two separate scans and an emit pass).  Leaves cur_end
+// (n entries) in WS_T5 and, if want_ha, the per-row head counts in WS_T6.
 static ivx_status sweep(ivx_ctx *ctx, const u32 *ks, const i64 *ss, const i64 *es, u64 n,
-                        i64 min_dist, int strict, const ivx_runs_out &out, const HeadAcc **ha_out, u64 *m)
+                        i64 min_dist, int strict, const ivx_runs_out &out, const HeadAcc **ha_out, u64 *m, bool want_ha)
 {
+    using namespace ivxscan;
     hipStream_t stq = ctx->stream;
-    i64 *cur_end; HeadAcc *ha;
+    i64 *cur_end; HeadAcc *ha = nullptr;
     IVX_TRY(ctx->get_scratch(WS_T5, n * sizeof(i64), (void **)&cur_end));
-    IVX_TRY(ctx->get_scratch(WS_T6, n * sizeof(HeadAcc), (void **)&ha));
-    const u32 grid = (u32)((n + RT - 1) / RT);
-    IVX_TRY((ivxscan::inclusive_f<MergeOp>(ctx, StateIn{ks, ss, es, min_dist, strict}, CurEndOut{cur_end}, n)));
-    IVX_TRY((ivxscan::inclusive_f<HeadOp>(ctx, HeadIn{ks, ss, cur_end, min_dist, strict}, HeadOut{ha}, n)));
+    if (want_ha) IVX_TRY(ctx->get_scratch(WS_T6, n * sizeof(HeadAcc), (void **)&ha));
+    const u64 nblk = (n + TILE_ - 1) / TILE_;
+    MState *sums; HeadAcc *hsums;
+    IVX_TRY(ctx->get_scratch(WS_SCAN0, nblk * sizeof(MState), (void **)&sums));
+    IVX_TRY(ctx->get_scratch(WS_SCAN2, nblk * sizeof(HeadAcc), (void **)&hsums));
+    const StateIn in{ks, ss, es, min_dist, strict};
+    if (nblk > 1) {
+        hipLaunchKernelGGL((k_reduce_f<MergeOp, StateIn>), dim3((u32)nblk), dim3(T_), 0, stq, in, n, sums);
+        IVX_TRY((scan_rec<MergeOp, false>(ctx, sums, nblk, 1, WS_SCAN0)));
+    }
+    hipLaunchKernelGGL(k_merge_apply, dim3((u32)nblk), dim3(T_), 0, stq, in, CurEndOut{cur_end}, n, nblk > 1 ? (const MState *)sums : (const MState *)nullptr, hsums);
+    if (nblk > 1) IVX_TRY((scan_rec<HeadOp, false>(ctx, hsums, nblk, 1, WS_SCAN0)));
     u64 *d_m = ctx->d_scalars + 2;
-    hipLaunchKernelGGL(k_emit_runs, dim3(grid), dim3(RT), 0, stq, ks, ss, (const i64 *)cur_end, (const HeadAcc *)ha, n, out, d_m);
+    const HeadIn hin{ks, ss, cur_end, min_dist, strict};
+    const HeadEmitOut hout{ha, ks, ss, cur_end, min_dist, strict, n, out, d_m};
+    hipLaunchKernelGGL(k_head_apply, dim3((u32)nblk), dim3(T_), 0, stq, hin, hout, n, nblk > 1 ? (const HeadAcc *)hsums : (const HeadAcc *)nullptr);
     IVX_HIP(ctx, hipGetLastError());
     IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 2, d_m, sizeof(u64), hipMemcpyDeviceToHost, stq));
     *ha_out = ha;
@@ -151,7 +227,7 @@ ivx_status ivx_merge_runs(ivx_ctx *ctx, const u32 *ks, const i64 *ss, const i64 
     *m = 0;
     if (n == 0) return IVX_OK;
     const HeadAcc *ha;
-    IVX_TRY(sweep(ctx, ks, ss, es, n, min_dist, strict, out, &ha, m));
+    IVX_TRY(sweep(ctx, ks, ss, es, n, min_dist, strict, out, &ha, m, false));
     IVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *m = ctx->h_scalars[2];
     return IVX_OK;
@@ -210,7 +286,7 @@ ivx_status ivx_cluster_rows(ivx_ctx *ctx, const u32 *ks, const i64 *ss, const i6
         IVX_TRY(ctx->get_scratch(WS_T7, n * sizeof(i64), (void **)&run_end));
         const HeadAcc *ha;
         const ivx_runs_out ro{nullptr, nullptr, run_end, nullptr};
-        IVX_TRY(sweep(ctx, ks, ss, es, n, min_dist, strict, ro, &ha, m));
+        IVX_TRY(sweep(ctx, ks, ss, es, n, min_dist, strict, ro, &ha, m, true));
         const u32 grid = (u32)((n + RT - 1) / RT);
         hipLaunchKernelGGL(k_key_runs, dim3(grid), dim3(RT), 0, stq, ks, ha, n, nkeys, kfirst, klast);
         hipLaunchKernelGGL(k_cluster_rows, dim3(grid), dim3(RT), 0, stq, ks, ss, ha, (const i64 *)run_end, n, nkeys,

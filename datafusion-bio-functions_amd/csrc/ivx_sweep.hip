@@ -118,16 +118,38 @@ __global__ __launch_bounds__(ST) void k_pack1(const u32 *__restrict__ key, const
     if (w1) w1[i] = (u32)i;                                             // the row id rides along as a 32-bit payload (12-byte records); callers
 }                                                                       // that do not ask for row ids sort the 8-byte words alone
 
+// FIX: the words were sorted (stably) on their bits above lo_bits only -- (key, start) -- so rows of equal (key, start)
+// sit together in input order and still have to be ordered by their low bits (end), then row.  Such runs are short
+// for genomic data (two or three rows): every row finds its own place inside its run by counting the run's rows that
+// sort before it, and is written there -- no pass over the words to repair them first.  A run beyond FIX_MAXRUN rows
+// raises *toolong and the host falls back to the full-width sort.
+constexpr u32 FIX_MAXRUN = 64;
+template <bool FIX>
 __global__ __launch_bounds__(ST) void k_unpack1(const u64 *__restrict__ w0, const u32 *__restrict__ w1, u64 n, Pack64 p,
-                                                u32 *ks, i64 *ss, i64 *es, u32 *rows)
+                                                u32 *ks, i64 *ss, i64 *es, u32 *rows, u32 lo_bits, u32 *toolong)
 {
     const u64 i = (u64)blockIdx.x * ST + threadIdx.x;
     if (i >= n) return;
     const u64 w = w0[i];
-    ks[i] = (u32)shr64(w, p.bits_s + p.bits_e);
-    ss[i] = (i64)(low64(shr64(w, p.bits_e), p.bits_s) + (u64)p.min_s);
-    es[i] = (i64)(low64(w, p.bits_e) + (u64)p.min_e);
-    if (rows && w1) rows[i] = w1[i];
+    u64 pos = i;
+    if (FIX) {
+        // (the neighbours' loads are issued with the row's own: most rows are alone in their run and never enter a loop)
+        const u64 wp = i > 0 ? w0[i - 1] : 0, wn = i + 1 < n ? w0[i + 1] : 0;
+        const u64 hd = shr64(w, lo_bits);
+        u64 h = i, t = i + 1;
+        if (i > 0 && shr64(wp, lo_bits) == hd) { h--; while (h > 0 && i - h < FIX_MAXRUN && shr64(w0[h - 1], lo_bits) == hd) h--; }
+        if (i + 1 < n && shr64(wn, lo_bits) == hd) { t++; while (t < n && t - i < FIX_MAXRUN && shr64(w0[t], lo_bits) == hd) t++; }
+        if (t - h > 1) {
+            if (t - h > FIX_MAXRUN) { *toolong = 1; return; }
+            u32 below = 0;
+            for (u64 j = h; j < t; j++) { const u64 x = w0[j]; below += (x < w || (x == w && j < i)) ? 1u : 0u; }
+            pos = h + below;
+        }
+    }
+    ks[pos] = (u32)shr64(w, p.bits_s + p.bits_e);
+    ss[pos] = (i64)(low64(shr64(w, p.bits_e), p.bits_s) + (u64)p.min_s);
+    es[pos] = (i64)(low64(w, p.bits_e) + (u64)p.min_e);
+    if (rows && w1) rows[pos] = w1[i];
 }
 
 // rows that already are in (key,start,end) order: the sorted columns are the input columns, row ids 0..n-1
@@ -138,29 +160,6 @@ __global__ __launch_bounds__(ST) void k_copy_sorted(const u32 *__restrict__ key,
     if (i >= n) return;
     ks[i] = key ? key[i] : 0u; ss[i] = s[i]; es[i] = e[i];
     if (rows) rows[i] = (u32)i;
-}
-
-// After a (stable) sort on the packed word's (key,start) bits only: rows with equal (key,start) sit together in
-// input order and still have to be ordered by end, then row.  Such runs are short for genomic data (two or three
-// rows), so the thread at the head of a run insertion-sorts it in place; a run longer than FIX_MAXRUN raises
-// *toolong and the host falls back to the full-width sort.
-constexpr u32 FIX_MAXRUN = 64;
-__global__ __launch_bounds__(ST) void k_fix_runs(u64 *__restrict__ w0, u32 *__restrict__ w1, u64 n, u32 lo_bits, u32 *toolong)
-{
-    const u64 i = (u64)blockIdx.x * ST + threadIdx.x;
-    if (i >= n) return;
-    const u64 h = w0[i] >> lo_bits;
-    if (i && (w0[i - 1] >> lo_bits) == h) return;                       // not the head of its run
-    if (i + 1 >= n || (w0[i + 1] >> lo_bits) != h) return;              // a run of one
-    u32 len = 2;
-    while (i + len < n && len <= FIX_MAXRUN && (w0[i + len] >> lo_bits) == h) len++;
-    if (len > FIX_MAXRUN) { *toolong = 1; return; }
-    for (u32 a = 1; a < len; a++) {                                     // stable: equal words keep their (row) order
-        const u64 x0 = w0[i + a]; const u32 x1 = w1 ? w1[i + a] : 0u;
-        u32 b = a;
-        while (b > 0 && w0[i + b - 1] > x0) { w0[i + b] = w0[i + b - 1]; if (w1) w1[i + b] = w1[i + b - 1]; b--; }
-        w0[i + b] = x0; if (w1) w1[i + b] = x1;
-    }
 }
 
 u32 bits_of(u64 x) { u32 b = 0; while (x) { b++; x >>= 1; } return b; }
@@ -221,7 +220,8 @@ ivx_status sort64(ivx_ctx *ctx, int slot_a, int slot_b, const u32 *key, const i6
             IVX_TRY(ivx_radix_sort(ctx, 1, a, b, n, f, 1, &in_b, true, with_rows ? pay : nullptr));
             o = in_b ? b : a;
             u32 *toolong = flags + 1;                                   // (upper half of the key-flag word; zeroed by the caller)
-            hipLaunchKernelGGL(k_fix_runs, dim3(grid1(n)), dim3(ST), 0, st, o[0], pay[in_b], n, p.bits_e, toolong);
+            hipLaunchKernelGGL((k_unpack1<true>), dim3(grid1(n)), dim3(ST), 0, st, (const u64 *)o[0], (const u32 *)pay[in_b], n, p, ks, ss, es, rows,
+                               p.bits_e, toolong);
             IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 8, flags, sizeof(u64), hipMemcpyDeviceToHost, st));
             IVX_HIP(ctx, hipStreamSynchronize(st));
             if (((const u32 *)(ctx->h_scalars + 8))[1]) {                // a long run of equal (key,start): the plain way after all
@@ -234,8 +234,9 @@ ivx_status sort64(ivx_ctx *ctx, int slot_a, int slot_b, const u32 *key, const i6
             const ivx_sort_field f[1] = {{0, 0, (int)((total + 7) / 8 * 8)}};
             IVX_TRY(ivx_radix_sort(ctx, 1, a, b, n, f, 1, &in_b, true, with_rows ? pay : nullptr));
             o = in_b ? b : a;
+            hipLaunchKernelGGL((k_unpack1<false>), dim3(grid1(n)), dim3(ST), 0, st, (const u64 *)o[0], (const u32 *)pay[in_b], n, p, ks, ss, es, rows,
+                               0u, (u32 *)nullptr);
         }
-        hipLaunchKernelGGL(k_unpack1, dim3(grid1(n)), dim3(ST), 0, st, (const u64 *)o[0], (const u32 *)pay[in_b], n, p, ks, ss, es, rows);
     } else {
         hipLaunchKernelGGL(k_pack64, dim3(grid1(n)), dim3(ST), 0, st, key, s, e, n, nkeys, a[0], a[1], a[2], flags);
         const ivx_sort_field f[3] = {{0, 0, 64}, {1, 0, 64}, {2, 32, 64}};
