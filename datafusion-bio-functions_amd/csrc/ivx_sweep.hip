@@ -62,22 +62,48 @@ __global__ __launch_bounds__(ST) void k_unpack64(const u64 *__restrict__ w0, con
 // radix digits in total
 struct Range64 { long long min_s, max_s, min_e, max_e; unsigned long long unsorted; };   // unsorted: some row sorts before its predecessor
 
+// kmin / kmax (nullable; nkeys <= LIN_KEYS): also every key's own range of starts, for the linearised sort word below --
+// privatised in LDS, and a bound is touched by an atomic only when a row moves it (a plain read comes first)
+constexpr u32 LIN_KEYS = 2048;
+__global__ void k_init_keyrange64(i64 *kmin, i64 *kmax, u32 nkeys)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nkeys) { kmin[i] = INT64_MAX; kmax[i] = INT64_MIN; }
+}
 __global__ __launch_bounds__(ST) void k_range64(const u32 *__restrict__ key, const i64 *__restrict__ s, const i64 *__restrict__ e,
-                                                u64 n, u32 nkeys, Range64 *out, u32 *flags)
+                                                u64 n, u32 nkeys, Range64 *out, u32 *flags, long long *kmin, long long *kmax)
 {
     __shared__ i64 red[4][ST / IVX_WAVE];
+    extern __shared__ long long s_kr[];                                 // [2 * nkeys] when kmin
+    long long *smin = s_kr, *smax = s_kr + nkeys;
+    if (kmin) {
+        for (u32 k = threadIdx.x; k < nkeys; k += ST) { smin[k] = INT64_MAX; smax[k] = INT64_MIN; }
+        __syncthreads();
+    }
     i64 lo_s = INT64_MAX, hi_s = INT64_MIN, lo_e = INT64_MAX, hi_e = INT64_MIN;
     bool bad = false, inv = false;
-    for (u64 i = (u64)blockIdx.x * ST + threadIdx.x; i < n; i += (u64)gridDim.x * ST) {
-        const i64 a = s[i], b = e[i];
-        lo_s = a < lo_s ? a : lo_s; hi_s = a > hi_s ? a : hi_s;
-        lo_e = b < lo_e ? b : lo_e; hi_e = b > hi_e ? b : hi_e;
-        const u32 k = key ? key[i] : 0u;
-        bad |= k >= nkeys;
-        if (i) {                                                        // (key,start,end) below the row before it?
-            const u32 pk = key ? key[i - 1] : 0u;
-            const i64 pa = s[i - 1], pb = e[i - 1];
-            inv |= k != pk ? k < pk : (a != pa ? a < pa : b < pb);
+    constexpr int U = 4;                                                // rows per thread in flight (their loads depend on nothing)
+    for (u64 i0 = (u64)blockIdx.x * (ST * U) + threadIdx.x; i0 < n; i0 += (u64)gridDim.x * (ST * U)) {
+        i64 a[U], b[U], pa[U], pb[U]; u32 k[U], pk[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const u64 i = i0 + (u64)u * ST;
+            const bool in = i < n, hp = in && i > 0;
+            a[u] = in ? s[i] : 0; b[u] = in ? e[i] : 0; k[u] = in ? (key ? key[i] : 0u) : 0u;
+            pa[u] = hp ? s[i - 1] : INT64_MIN; pb[u] = hp ? e[i - 1] : INT64_MIN; pk[u] = hp ? (key ? key[i - 1] : 0u) : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (i0 + (u64)u * ST >= n) continue;
+            lo_s = a[u] < lo_s ? a[u] : lo_s; hi_s = a[u] > hi_s ? a[u] : hi_s;
+            lo_e = b[u] < lo_e ? b[u] : lo_e; hi_e = b[u] > hi_e ? b[u] : hi_e;
+            bad |= k[u] >= nkeys;
+            if (kmin && k[u] < nkeys) {
+                if (a[u] < *(volatile long long *)&smin[k[u]]) atomicMin(&smin[k[u]], (long long)a[u]);
+                if (a[u] > *(volatile long long *)&smax[k[u]]) atomicMax(&smax[k[u]], (long long)a[u]);
+            }
+            // (key,start,end) below the row before it?
+            inv |= k[u] != pk[u] ? k[u] < pk[u] : (a[u] != pa[u] ? a[u] < pa[u] : b[u] < pb[u]);
         }
     }
 #pragma unroll
@@ -101,9 +127,48 @@ __global__ __launch_bounds__(ST) void k_range64(const u32 *__restrict__ key, con
         atomicMin(&out->min_s, (long long)lo_s); atomicMax(&out->max_s, (long long)hi_s);
         atomicMin(&out->min_e, (long long)lo_e); atomicMax(&out->max_e, (long long)hi_e);
     }
+    if (kmin)
+        for (u32 k = threadIdx.x; k < nkeys; k += ST)
+            if (smin[k] <= smax[k]) { atomicMin(&kmin[k], smin[k]); atomicMax(&kmax[k], smax[k]); }
 }
 
-struct Pack64 { i64 min_s, min_e; u32 bits_s, bits_e; };
+// one workgroup: base[k] = number of (key, start) positions before key k when every key spans just its own starts
+// (base[nkeys] = all of them; hdr[0] = 0 when the count leaves 64 bits)
+__global__ __launch_bounds__(1024) void k_lin_layout64(const long long *kmin, const long long *kmax, u32 nkeys, u64 *base, u64 *hdr)
+{
+    __shared__ u64 red[1024 / IVX_WAVE + 1];
+    __shared__ u32 s_bad;
+    const u32 t = threadIdx.x;
+    if (t == 0) s_bad = 0;
+    __syncthreads();
+    u64 run = 0;
+    for (u32 k0 = 0; k0 < nkeys; k0 += 1024) {
+        const u32 k = k0 + t;
+        u64 w = 0;
+        if (k < nkeys && kmin[k] <= kmax[k]) {
+            w = (u64)kmax[k] - (u64)kmin[k] + 1;
+            if (w == 0 || w > (1ull << 62)) { s_bad = 1; w = 0; }
+        }
+        u64 tot;
+        const u64 ex = block_excl_scan<u64, 1024>(w, red, &tot);
+        if (k < nkeys) base[k] = run + ex;
+        if (run + tot < run || run + tot > (1ull << 62)) s_bad = 1;
+        run += tot;
+    }
+    __syncthreads();
+    if (t == 0) { base[nkeys] = run; hdr[0] = s_bad ? 0 : 1; hdr[1] = run; }
+}
+
+// lin: the word's upper part is base[key] + (start - kmin[key]) -- bits_s bits, no separate key bits -- instead of
+// key ‖ (start - min_s): a human genome's (contig, position) pairs number 3.1e9 = 32 bits = four radix digits, where
+// 5 key bits + 28 position bits take five
+struct Pack64 { i64 min_s, min_e; u32 bits_s, bits_e; const u64 *base; const long long *kmin; u32 lin, nkeys; };
+__device__ __forceinline__ u32 lin_key64(const u64 *base, u32 nkeys, u64 lin)
+{
+    u32 a = 0, b = nkeys;                                              // first k with base[k + 1] > lin (keys without rows are skipped)
+    while (a < b) { const u32 m = (a + b) >> 1; if (base[m + 1] > lin) b = m; else a = m + 1; }
+    return a;
+}
 __device__ __forceinline__ u64 shl64(u64 x, u32 sh) { return sh >= 64 ? 0 : x << sh; }
 __device__ __forceinline__ u64 shr64(u64 x, u32 sh) { return sh >= 64 ? 0 : x >> sh; }
 __device__ __forceinline__ u64 low64(u64 x, u32 bits) { return bits >= 64 ? x : x & ((1ull << bits) - 1); }
@@ -114,7 +179,8 @@ __global__ __launch_bounds__(ST) void k_pack1(const u32 *__restrict__ key, const
     const u64 i = (u64)blockIdx.x * ST + threadIdx.x;
     if (i >= n) return;
     const u64 k = key ? key[i] : 0u;
-    w0[i] = shl64(k, p.bits_s + p.bits_e) | shl64((u64)s[i] - (u64)p.min_s, p.bits_e) | ((u64)e[i] - (u64)p.min_e);
+    if (p.lin) w0[i] = shl64(p.base[k] + ((u64)s[i] - (u64)p.kmin[k]), p.bits_e) | ((u64)e[i] - (u64)p.min_e);
+    else w0[i] = shl64(k, p.bits_s + p.bits_e) | shl64((u64)s[i] - (u64)p.min_s, p.bits_e) | ((u64)e[i] - (u64)p.min_e);
     if (w1) w1[i] = (u32)i;                                             // the row id rides along as a 32-bit payload (12-byte records); callers
 }                                                                       // that do not ask for row ids sort the 8-byte words alone
 
@@ -124,32 +190,64 @@ __global__ __launch_bounds__(ST) void k_pack1(const u32 *__restrict__ key, const
 // sort before it, and is written there -- no pass over the words to repair them first.  A run beyond FIX_MAXRUN rows
 // raises *toolong and the host falls back to the full-width sort.
 constexpr u32 FIX_MAXRUN = 64;
+constexpr u32 UNPACK_TILES = 8;
 template <bool FIX>
 __global__ __launch_bounds__(ST) void k_unpack1(const u64 *__restrict__ w0, const u32 *__restrict__ w1, u64 n, Pack64 p,
                                                 u32 *ks, i64 *ss, i64 *es, u32 *rows, u32 lo_bits, u32 *toolong)
 {
-    const u64 i = (u64)blockIdx.x * ST + threadIdx.x;
-    if (i >= n) return;
-    const u64 w = w0[i];
-    u64 pos = i;
-    if (FIX) {
-        // (the neighbours' loads are issued with the row's own: most rows are alone in their run and never enter a loop)
-        const u64 wp = i > 0 ? w0[i - 1] : 0, wn = i + 1 < n ? w0[i + 1] : 0;
-        const u64 hd = shr64(w, lo_bits);
-        u64 h = i, t = i + 1;
-        if (i > 0 && shr64(wp, lo_bits) == hd) { h--; while (h > 0 && i - h < FIX_MAXRUN && shr64(w0[h - 1], lo_bits) == hd) h--; }
-        if (i + 1 < n && shr64(wn, lo_bits) == hd) { t++; while (t < n && t - i < FIX_MAXRUN && shr64(w0[t], lo_bits) == hd) t++; }
-        if (t - h > 1) {
-            if (t - h > FIX_MAXRUN) { *toolong = 1; return; }
-            u32 below = 0;
-            for (u64 j = h; j < t; j++) { const u64 x = w0[j]; below += (x < w || (x == w && j < i)) ? 1u : 0u; }
-            pos = h + below;
+    __shared__ u64 s_base[LIN_KEYS + 1];
+    // the tile's words + FIX_MAXRUN on either side: a row looks at its neighbours in LDS (a chain of dependent global
+    // loads per row in a run held every wavefront up)
+    __shared__ u64 s_w[FIX ? ST + 2 * FIX_MAXRUN : 1];
+    if (p.lin) for (u32 k = threadIdx.x; k <= p.nkeys; k += ST) s_base[k] = p.base[k];
+    // (UNPACK_TILES tiles per workgroup: the key table is staged once for all of them)
+    for (u32 tile = 0; tile < UNPACK_TILES; tile++) {
+        const u64 t0 = ((u64)blockIdx.x * UNPACK_TILES + tile) * ST;
+        if (t0 >= n) break;                                             // (whole workgroup)
+        const u64 i = t0 + threadIdx.x;
+        u64 w = 0;
+        if (FIX) {
+            __syncthreads();                                            // (the previous tile's readers are done; first tile: s_base is written)
+            // slot x of s_w holds row t0 - FIX_MAXRUN + x
+            for (u32 x = threadIdx.x; x < ST + 2 * FIX_MAXRUN; x += ST) {
+                const u64 g = t0 + x;
+                s_w[FIX ? x : 0] = (g >= FIX_MAXRUN && g - FIX_MAXRUN < n) ? w0[g - FIX_MAXRUN] : 0;
+            }
+            __syncthreads();
+            w = s_w[FIX ? threadIdx.x + FIX_MAXRUN : 0];
+        } else {
+            if (tile == 0) __syncthreads();
+            if (i < n) w = w0[i];
         }
+        if (i >= n) continue;
+        u64 pos = i;
+        if (FIX) {
+            const u64 hd = shr64(w, lo_bits);
+            const u32 me = threadIdx.x + FIX_MAXRUN;                    // my slot; slot x is a row iff t0 + x - FIX_MAXRUN in [0, n)
+            const u32 xlo = t0 >= FIX_MAXRUN ? 0u : (u32)(FIX_MAXRUN - t0);                               // first slot that is a row
+            const u32 xhi = (u32)((n - t0 < (u64)(ST + FIX_MAXRUN) ? n - t0 : (u64)(ST + FIX_MAXRUN)) + FIX_MAXRUN);   // one past the last
+            u32 h = me, t = me + 1;
+            while (h > xlo && me - h < FIX_MAXRUN && shr64(s_w[FIX ? h - 1 : 0], lo_bits) == hd) h--;
+            while (t < xhi && t - me < FIX_MAXRUN && shr64(s_w[FIX ? t : 0], lo_bits) == hd) t++;
+            if (t - h > 1) {
+                if (t - h > FIX_MAXRUN) { *toolong = 1; continue; }
+                u32 below = 0;
+                for (u32 j = h; j < t; j++) { const u64 x = s_w[FIX ? j : 0]; below += (x < w || (x == w && j < me)) ? 1u : 0u; }
+                pos = t0 + h + below - FIX_MAXRUN;
+            }
+        }
+        if (p.lin) {
+            const u64 lin = shr64(w, p.bits_e);
+            const u32 k = lin_key64(s_base, p.nkeys, lin);
+            ks[pos] = k;
+            ss[pos] = (i64)((u64)p.kmin[k] + (lin - s_base[k]));
+        } else {
+            ks[pos] = (u32)shr64(w, p.bits_s + p.bits_e);
+            ss[pos] = (i64)(low64(shr64(w, p.bits_e), p.bits_s) + (u64)p.min_s);
+        }
+        es[pos] = (i64)(low64(w, p.bits_e) + (u64)p.min_e);
+        if (rows && w1) rows[pos] = w1[i];
     }
-    ks[pos] = (u32)shr64(w, p.bits_s + p.bits_e);
-    ss[pos] = (i64)(low64(shr64(w, p.bits_e), p.bits_s) + (u64)p.min_s);
-    es[pos] = (i64)(low64(w, p.bits_e) + (u64)p.min_e);
-    if (rows && w1) rows[pos] = w1[i];
 }
 
 // rows that already are in (key,start,end) order: the sorted columns are the input columns, row ids 0..n-1
@@ -175,8 +273,22 @@ ivx_status sort64(ivx_ctx *ctx, int slot_a, int slot_b, const u32 *key, const i6
     Range64 *h_init = (Range64 *)(ctx->h_scalars + 48);                   // pinned, so the async copy may read it later
     *h_init = Range64{INT64_MAX, INT64_MIN, INT64_MAX, INT64_MIN, 0ull};
     IVX_HIP(ctx, hipMemcpyAsync(d_rng, h_init, sizeof(Range64), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_range64, dim3(ivx_stream_grid(n, ST * 8, 2048)), dim3(ST), 0, st, key, s, e, n, nkeys, d_rng, flags);
-    IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 24, d_rng, sizeof(Range64), hipMemcpyDeviceToHost, st));
+    // every key's own range of starts as well, when the key table fits LDS (the linearised sort word, Pack64)
+    long long *kmin = nullptr, *kmax = nullptr; u64 *base = nullptr;
+    u64 *d_lin = ctx->d_scalars + 30;                                   // {usable, (key, start) positions in all}
+    const bool try_lin = nkeys <= LIN_KEYS && !getenv("IVX_NO_LIN");
+    if (try_lin) {
+        // (the third record slots: free whenever the one-word form is in use, and owned by this call -- the callers keep
+        //  their own tables in the WS_GRID / WS_T slots across it)
+        IVX_TRY(ctx->get_scratch(slot_a + 2, (size_t)nkeys * 2 * sizeof(long long), (void **)&kmin));
+        kmax = kmin + nkeys;
+        IVX_TRY(ctx->get_scratch(slot_b + 2, ((size_t)nkeys + 1) * sizeof(u64), (void **)&base));
+        hipLaunchKernelGGL(k_init_keyrange64, dim3((nkeys + ST - 1) / ST), dim3(ST), 0, st, (i64 *)kmin, (i64 *)kmax, nkeys);
+    }
+    hipLaunchKernelGGL(k_range64, dim3(ivx_stream_grid(n, ST * 16, 4096)), dim3(ST), try_lin ? (size_t)nkeys * 16 : 0, st, key, s, e, n, nkeys, d_rng, flags,
+                       kmin, kmax);
+    if (try_lin) hipLaunchKernelGGL(k_lin_layout64, dim3(1), dim3(1024), 0, st, (const long long *)kmin, (const long long *)kmax, nkeys, base, d_lin);
+    IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 24, d_rng, 8 * sizeof(u64), hipMemcpyDeviceToHost, st));   // Range64 (5 words) .. d_lin (2 words)
     IVX_HIP(ctx, hipStreamSynchronize(st));
     const Range64 r = *(const Range64 *)(ctx->h_scalars + 24);
     if (!r.unsorted && !getenv("IVX_FORCE_SORT")) {
@@ -187,9 +299,14 @@ ivx_status sort64(ivx_ctx *ctx, int slot_a, int slot_b, const u32 *key, const i6
         return IVX_OK;
     }
     Pack64 p;
-    p.min_s = r.min_s; p.min_e = r.min_e;
+    p.min_s = r.min_s; p.min_e = r.min_e; p.base = base; p.kmin = kmin; p.lin = 0; p.nkeys = nkeys;
     p.bits_s = bits_of((u64)r.max_s - (u64)r.min_s); p.bits_e = bits_of((u64)r.max_e - (u64)r.min_e);
-    const u32 bits_k = bits_of(nkeys ? nkeys - 1 : 0);
+    u32 bits_k = bits_of(nkeys ? nkeys - 1 : 0);
+    double positions = (double)(nkeys ? nkeys : 1) * (p.bits_s >= 62 ? 4.6e18 : (double)(1ull << p.bits_s));
+    if (try_lin && ctx->h_scalars[30] && ctx->h_scalars[31]) {
+        const u32 bits_lin = bits_of(ctx->h_scalars[31] - 1);
+        if (bits_lin < bits_k + p.bits_s) { p.lin = 1; p.bits_s = bits_lin; bits_k = 0; positions = (double)ctx->h_scalars[31]; }
+    }
     const u32 total = p.bits_s + p.bits_e + bits_k;
     u64 *a[3] = {nullptr, nullptr, nullptr}, *b[3] = {nullptr, nullptr, nullptr};
     // packed: one 64-bit sort word, plus the row ids -- a 32-bit payload -- only when the caller wants them back (merge /
@@ -211,7 +328,7 @@ ivx_status sort64(ivx_ctx *ctx, int slot_a, int slot_b, const u32 *key, const i6
         // Few rows share a (key,start) when the rows are sparse in the coordinate space: then sort on those bits
         // only -- the end bits would be three or four more digit passes -- and order the short runs of equal
         // (key,start) afterwards (k_fix_runs).
-        const double per_pos = (double)n / ((double)(nkeys ? nkeys : 1) * (p.bits_s >= 62 ? 4.6e18 : (double)(1ull << p.bits_s)));
+        const double per_pos = (double)n / positions;
         bool two_step = p.bits_e >= 8 && n >= (1u << 16) && per_pos <= 0.25 && !getenv("IVX_FORCE_SORT");
         u64 *const *o = a;
         if (two_step) {
@@ -220,7 +337,7 @@ ivx_status sort64(ivx_ctx *ctx, int slot_a, int slot_b, const u32 *key, const i6
             IVX_TRY(ivx_radix_sort(ctx, 1, a, b, n, f, 1, &in_b, true, with_rows ? pay : nullptr));
             o = in_b ? b : a;
             u32 *toolong = flags + 1;                                   // (upper half of the key-flag word; zeroed by the caller)
-            hipLaunchKernelGGL((k_unpack1<true>), dim3(grid1(n)), dim3(ST), 0, st, (const u64 *)o[0], (const u32 *)pay[in_b], n, p, ks, ss, es, rows,
+            hipLaunchKernelGGL((k_unpack1<true>), dim3((grid1(n) + UNPACK_TILES - 1) / UNPACK_TILES), dim3(ST), 0, st, (const u64 *)o[0], (const u32 *)pay[in_b], n, p, ks, ss, es, rows,
                                p.bits_e, toolong);
             IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 8, flags, sizeof(u64), hipMemcpyDeviceToHost, st));
             IVX_HIP(ctx, hipStreamSynchronize(st));
@@ -234,7 +351,7 @@ ivx_status sort64(ivx_ctx *ctx, int slot_a, int slot_b, const u32 *key, const i6
             const ivx_sort_field f[1] = {{0, 0, (int)((total + 7) / 8 * 8)}};
             IVX_TRY(ivx_radix_sort(ctx, 1, a, b, n, f, 1, &in_b, true, with_rows ? pay : nullptr));
             o = in_b ? b : a;
-            hipLaunchKernelGGL((k_unpack1<false>), dim3(grid1(n)), dim3(ST), 0, st, (const u64 *)o[0], (const u32 *)pay[in_b], n, p, ks, ss, es, rows,
+            hipLaunchKernelGGL((k_unpack1<false>), dim3((grid1(n) + UNPACK_TILES - 1) / UNPACK_TILES), dim3(ST), 0, st, (const u64 *)o[0], (const u32 *)pay[in_b], n, p, ks, ss, es, rows,
                                0u, (u32 *)nullptr);
         }
     } else {

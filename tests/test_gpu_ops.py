@@ -336,10 +336,40 @@ def test_merge_random(ctx, seed):
         s[::31] = s[1::31][: len(s[::31])]
     md = [0, 0, 5, 1000, 0, 37][seed]
     for strict in (False, True):
-        got = ctx.merge(k, s, e, n_keys=nk, min_dist=md, strict=strict)
         want = orc.merge(k, s, e, min_dist=md, strict=strict)
-        for g, w in zip(got, want):
-            assert len(g) == len(w) and (g == w).all()
+        for nolin in (False, True):                         # the sort word with and without the linearised (key, start)
+            if nolin:
+                os.environ["IVX_NO_LIN"] = "1"
+            try:
+                got = ctx.merge(k, s, e, n_keys=nk, min_dist=md, strict=strict)
+            finally:
+                os.environ.pop("IVX_NO_LIN", None)
+            for g, w in zip(got, want):
+                assert len(g) == len(w) and (g == w).all()
+
+
+def test_sweeps_uneven_contigs(ctx):
+    # contigs of very different lengths (and some without rows), as in a genome: the sort word numbers the
+    # (contig, start) pairs consecutively, contig by contig
+    rng = np.random.default_rng(91)
+    spans = np.array([250_000_000, 0, 5_000, 130_000_000, 1, 0, 48_000_000, 16_000, 90_000_000, 0], np.int64)
+    nk, n = len(spans), 300_000
+    live = np.flatnonzero(spans > 0)
+    k = rng.choice(live, n, p=spans[live] / spans[live].sum()).astype(np.uint32)
+    s = (rng.random(n) * spans[k]).astype(np.int64) + rng.integers(-1000, 1000, nk)[k]
+    e = s + rng.integers(0, 2_000, n)
+    s[::13] = s[1::13][: len(s[::13])]; k[::13] = k[1::13][: len(k[::13])]; e[::13] = np.maximum(e[::13], s[::13])
+    got = ctx.merge(k, s, e, n_keys=nk)
+    want = orc.merge(k, s, e)
+    for g, w in zip(got, want):
+        assert len(g) == len(w) and (g == w).all()
+    _same_cluster(ctx.cluster(k, s, e, n_keys=nk), orc.cluster(k, s, e, n_keys=nk))
+    rk = rng.choice(live, n // 5).astype(np.uint32)
+    rs = (rng.random(n // 5) * spans[rk]).astype(np.int64); re = rs + rng.integers(0, 5_000, n // 5)
+    gs = ctx.subtract(k, s, e, rk, rs, re, n_keys=nk)
+    ws = orc.subtract(k, s, e, rk, rs, re)
+    for g, w in zip(gs, ws):
+        assert len(g) == len(w) and (g == w).all()
 
 
 @pytest.mark.parametrize("variant", ["sorted", "one_inversion", "all_equal", "sorted_by_start_only"])
