@@ -612,6 +612,10 @@ struct Slice {
     u32 sh0, nlev, k, lb, slo, shi, e0, ncell0; bool inlds, upper, lev0;
     i32 origin; u32 span;
     i32 rbase;                  // coordinate of the region's first cell (packed rows hold their start relative to it)
+    // packed rows (start relative to rbase, length) find their cells in 32-bit arithmetic when `fast`: the whole region is
+    // one LDS-resident level.  off = cells between the slice's first cell and the region's (0 or 1), cmax = the key's last
+    // cell and ncm1 = the slice's last cell, both relative to the slice
+    bool fast; u32 off, cmax, ncm1;
 };
 
 // every match of one probe row: f(v, is_slot, start, end) -- v is a slot of the staged slice (build row =
@@ -672,6 +676,31 @@ __device__ __forceinline__ void probe_row(const Slice &S, i32 qs, i32 qe, F &&f)
     }
 }
 
+// The same for a packed row (rel = start - S.rbase < 2^24, len = end - start; ok = the row really is in that form): on a
+// `fast` slice its cells follow from two shifts -- (start - origin) = (region's first cell) * cell + rel -- instead of
+// the 64-bit coordinate arithmetic above (the walk is bound by the instructions it issues, and those were a fifth of them)
+template <class F>
+__device__ __forceinline__ void probe_row_rel(const Slice &S, u32 rel, u32 len, bool ok, i32 qs, i32 qe, F &&f)
+{
+    if (S.fast && ok) {
+        const u32 t = ((rel + 1u) >> S.sh0) + S.off;                  // first cell a matching build row can start in: one cell back
+        const u32 bl = t ? t - 1u : 0u;
+        u32 bh = ((rel + len) >> S.sh0) + S.off;
+        bh = bh < S.cmax ? bh : S.cmax;
+        if (bh < S.ncm1) {
+            if (bl <= bh) {
+                const u32 a = S.s_off[bl], b = S.s_off[bh + 1u];
+                for (u32 j = a; j < b; j++) {
+                    const u64 x = S.s_ent[j];
+                    if ((i32)(u32)x <= qe && (i32)(u32)(x >> 32) >= qs) f(j, true, (i32)(u32)x, (i32)(u32)(x >> 32));
+                }
+            }
+            return;
+        }
+    }
+    probe_row(S, qs, qe, f);
+}
+
 // ------------------------------------------------------------------ shared pieces of the probe kernels
 
 struct ProbeLds {
@@ -705,6 +734,9 @@ __device__ __forceinline__ void slice_load(const JoinIndexView &ix, Slice &S, co
     const u32 ne = d.ne;
     const u32 nc = S.shi - S.slo + 1u;
     S.inlds = ne <= RP_ECAP && nc <= RP_CCAP;
+    S.fast = S.inlds && S.lev0 && !S.upper;
+    S.off = (u32)(((i64)S.rbase - (i64)S.origin) >> S.sh0) - S.slo;
+    S.cmax = S.ncell0 - 1u - S.slo; S.ncm1 = S.shi - S.slo;
     if (S.inlds && reload) {
         for (u32 c0 = 0; c0 < nc; c0 += RP_T * 4) {
             u32 v[4];
@@ -733,17 +765,23 @@ __device__ __forceinline__ void slice_load(const JoinIndexView &ix, Slice &S, co
 // the wavefront's own running counter (lanes of one instruction are serialised by the LDS unit and get
 // distinct slots), so no per-row match stash, prefix sum or second walk is needed.  Returns the batch's
 // pair count; direct = true if it did not fit the ring (see batch_write_direct).
-template <bool FILL, int B>
+// PK: rel / len hold the rows' packed form (valid where relmask has the row's bit)
+template <bool FILL, int B, bool PK = false>
 __device__ __forceinline__ u32 batch_walk(const Slice &S, const ProbeLds &L, const i32 (&qs)[B], const i32 (&qe)[B],
-                                          const u32 (&rowv)[B], u32 okmask, u32 wv, u32 ring_tail, u32 &ring_start, bool &direct, int dbg)
+                                          const u32 (&rowv)[B], u32 okmask, u32 wv, u32 ring_tail, u32 &ring_start, bool &direct, int dbg,
+                                          const u32 (&rel)[B], const u32 (&len)[B], u32 relmask)
 {
+    auto walk = [&](int q, auto &&f) {
+        if (PK) probe_row_rel(S, rel[q], len[q], (relmask >> q) & 1u, qs[q], qe[q], f);
+        else probe_row(S, qs[q], qe[q], f);
+    };
     if (!FILL) {
         u32 tsum = 0;
 #pragma unroll
         for (int q = 0; q < B; q++) {
             if (!((okmask >> q) & 1u)) continue;
             if (dbg & 4) tsum += (u32)(qs[q] ^ qe[q]) & 1u;
-            else probe_row(S, qs[q], qe[q], [&](u32, bool, i32, i32) { tsum++; });
+            else walk(q, [&](u32, bool, i32, i32) { tsum++; });
         }
         return tsum;
     }
@@ -753,7 +791,8 @@ __device__ __forceinline__ u32 batch_walk(const Slice &S, const ProbeLds &L, con
 #pragma unroll
     for (int q = 0; q < B; q++) {
         if (!((okmask >> q) & 1u)) continue;
-        probe_row(S, qs[q], qe[q], [&](u32 v, bool sl, i32, i32) {
+        if (dbg & 128) continue;
+        walk(q, [&](u32 v, bool sl, i32, i32) {
             const u32 pos = __hip_atomic_fetch_add(cp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (pos - ring_tail < RP_RING && !(dbg & 64))
                 L.s_q[wv][pos & (RP_RING - 1)] = (u64)(sl ? S.s_row[v] : v) | ((u64)rowv[q] << 32);
@@ -995,32 +1034,43 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
                 u64 b0 = lo + (u64)wv * IVX_WAVE;
                 const u64 rf = PAGED ? rfirst(r) : 0;
                 pages_load(lo, c_hi, r, rf);
+                // (a scalar-base fast path for rounds that lie inside one pool page -- no bounds test, page lookup or 64-bit
+                //  address arithmetic per row -- was measured and dropped: fill 641 -> 703 us; the second copy of the loads
+                //  makes the kernel's code, already at the instruction cache's size, longer)
+                auto prefetch = [&](u64, u64 bl) -> bool {
 #pragma unroll
-                for (int q = 0; q < B; q++) {
-                    const u64 i = b0 + (u64)q * (RP_W * IVX_WAVE) + ln;
-                    const u64 at = i < c_hi ? row_at(i, r, rf) : 0;
-                    nx[q] = i < c_hi ? row_se(at) : 0;
-                    nxr[q] = (FILL && !PK && i < c_hi) ? row_id(i, at) : 0u;
-                }
+                    for (int q = 0; q < B; q++) {
+                        const u64 i = bl + (u64)q * (RP_W * IVX_WAVE) + ln;
+                        const u64 at = i < c_hi ? row_at(i, r, rf) : 0;
+                        nx[q] = i < c_hi ? row_se(at) : 0;
+                        nxr[q] = (FILL && !PK && i < c_hi) ? row_id(i, at) : 0u;
+                    }
+                    return false;
+                };
+                bool nfull = prefetch(lo, b0);
                 slice_load(ix, S, L, r, r != loaded_r);
                 loaded_r = r;
                 for (u64 r0 = lo; r0 < c_hi; r0 += (u64)RP_W * WB, b0 += (u64)RP_W * WB) {
                     i32 qs[B], qe[B]; u32 rowv[B];
+                    u32 prel[PK ? B : 1], plen[PK ? B : 1], relmask = 0;   // the packed form, for the walk's 32-bit cell arithmetic
                     u32 okmask = 0;
 #pragma unroll
                     for (int q = 0; q < B; q++) {
                         if (PK) {
                             const u32 lo32 = (u32)nx[q], hi32 = (u32)(nx[q] >> 32);
                             const u32 len = (lo32 >> 24) | ((rowbits < 32 ? (hi32 >> rowbits) & 0xFFu : 0u) << 8);
+                            prel[PK ? q : 0] = lo32 & 0xFFFFFFu; plen[PK ? q : 0] = len;
                             qs[q] = (i32)((u32)S.rbase + (lo32 & 0xFFFFFFu)); qe[q] = (i32)((u32)qs[q] + len); rowv[q] = hi32 & rowmask;
                             nxr[q] = len;                               // (kept for the escape test below; the row id prefetch slot is free here)
                         } else { qs[q] = (i32)(u32)nx[q]; qe[q] = (i32)(u32)(nx[q] >> 32); rowv[q] = nxr[q]; }
-                        if (b0 + (u64)q * (RP_W * IVX_WAVE) + ln < c_hi) okmask |= 1u << q;
+                        if (!nfull && b0 + (u64)q * (RP_W * IVX_WAVE) + ln < c_hi) okmask |= 1u << q;
                     }
+                    if (nfull) okmask = (1u << B) - 1u;
                     if (PK) {                                           // rows that did not fit the packed form (rare)
                         u32 esc = 0;
 #pragma unroll
                         for (int q = 0; q < B; q++) if (((okmask >> q) & 1u) && nxr[q] == maxlen) esc |= 1u << q;
+                        relmask = okmask & ~esc;
                         if (__any(esc != 0)) {                          // all the gathers first, then their uses: one round trip, not 2 * B
                             i32 ts[B], te[B];
 #pragma unroll
@@ -1029,16 +1079,7 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
                             for (int q = 0; q < B; q++) if ((esc >> q) & 1u) { qs[q] = (i32)((u32)ts[q] + adj); qe[q] = (i32)((u32)te[q] - adj); }
                         }
                     }
-                    {
-                        const u64 b1 = b0 + (u64)RP_W * WB;
-#pragma unroll
-                        for (int q = 0; q < B; q++) {
-                            const u64 i = b1 + (u64)q * (RP_W * IVX_WAVE) + ln;
-                            const u64 at = i < c_hi ? row_at(i, r, rf) : 0;
-                            nx[q] = i < c_hi ? row_se(at) : 0;
-                            nxr[q] = (FILL && !PK && i < c_hi) ? row_id(i, at) : 0u;
-                        }
-                    }
+                    nfull = prefetch(r0 + (u64)RP_W * WB, b0 + (u64)RP_W * WB);
                     if (MODE >= RV_COUNT) {
                         u32 val[B];
                         batch_rowval<MODE, B>(S, qs, qe, okmask, val);
@@ -1055,7 +1096,9 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
                     }
                     u32 start = 0;
                     bool direct = false;
-                    u32 got = batch_walk<FILL, B>(S, L, qs, qe, rowv, okmask, wv, pend_start, start, direct, dbg);
+                    u32 got;
+                    if constexpr (PK) got = batch_walk<FILL, B, true>(S, L, qs, qe, rowv, okmask, wv, pend_start, start, direct, dbg, (const u32 (&)[B])prel, (const u32 (&)[B])plen, relmask);
+                    else got = batch_walk<FILL, B, false>(S, L, qs, qe, rowv, okmask, wv, pend_start, start, direct, dbg, (const u32 (&)[B])qs, (const u32 (&)[B])qs, 0u);
                     if (MODE == 0) { wcur += got; continue; }
                     if (!(dbg & 32)) {
                         round_publish(L, got, round, wv, cursor);
@@ -1888,15 +1931,15 @@ ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nre
             u32 *bsel = (u32 *)(ctx->d_scalars + 11);
             const u32 force = getenv("IVX_RP_ROWS") ? (u32)atoi(getenv("IVX_RP_ROWS")) : 0u;
             hipLaunchKernelGGL(k_pick_rows, dim3(1), dim3(1), 0, st, rfirst, nreg, hint, force, bsel);
-#define IVX_FILLP2(B_, P_) hipLaunchKernelGGL((k_probe_regions<1, B_, false, true, P_>), dim3(RP_GRID), dim3(RP_T), 0, st, jv, (const void *)pool_se, (const void *)pool_row, rfirst, 1u, RP_VGRID / RP_GRID, ob, op, cap, cur, 1u, 0u, (const u32 *)nullptr, 0, pt, (const u32 *)bsel, s, e, rowbits)
+#define IVX_FILLP2(B_, P_) hipLaunchKernelGGL((k_probe_regions<1, B_, false, true, P_>), dim3(RP_GRID), dim3(RP_T), 0, st, jv, (const void *)pool_se, (const void *)pool_row, rfirst, 1u, RP_VGRID / RP_GRID, ob, op, cap, cur, 1u, 0u, (const u32 *)nullptr, dbg, pt, (const u32 *)bsel, s, e, rowbits)
 #define IVX_FILLP(B_) do { if (packed) IVX_FILLP2(B_, true); else IVX_FILLP2(B_, false); } while (0)
             IVX_FILLP(8); IVX_FILLP(4); IVX_FILLP(2); IVX_FILLP(1);
 #undef IVX_FILLP
 #undef IVX_FILLP2
         } else if (packed) {
-            hipLaunchKernelGGL((k_probe_regions<0, RP_B, false, true, true>), dim3(RP_VGRID), dim3(RP_T), 0, st, jv, (const void *)pool_se, (const void *)pool_row, rfirst, 1u, 1u, ob, op, cap, cur, 1u, 0u, (const u32 *)nullptr, 0, pt, (const u32 *)nullptr, s, e, rowbits);
+            hipLaunchKernelGGL((k_probe_regions<0, RP_B, false, true, true>), dim3(RP_VGRID), dim3(RP_T), 0, st, jv, (const void *)pool_se, (const void *)pool_row, rfirst, 1u, 1u, ob, op, cap, cur, 1u, 0u, (const u32 *)nullptr, dbg, pt, (const u32 *)nullptr, s, e, rowbits);
         } else {
-            hipLaunchKernelGGL((k_probe_regions<0, RP_B, false, true>), dim3(RP_VGRID), dim3(RP_T), 0, st, jv, (const void *)pool_se, (const void *)pool_row, rfirst, 1u, 1u, ob, op, cap, cur, 1u, 0u, (const u32 *)nullptr, 0, pt);
+            hipLaunchKernelGGL((k_probe_regions<0, RP_B, false, true>), dim3(RP_VGRID), dim3(RP_T), 0, st, jv, (const void *)pool_se, (const void *)pool_row, rfirst, 1u, 1u, ob, op, cap, cur, 1u, 0u, (const u32 *)nullptr, dbg, pt);
         }
         IVX_HIP(ctx, hipGetLastError());
         return IVX_OK;
