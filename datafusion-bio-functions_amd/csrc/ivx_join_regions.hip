@@ -836,20 +836,25 @@ enum { RV_COUNT = 2, RV_COVERAGE = 3, RV_MATCHES = 4 };   // RV_MATCHES: the joi
 __device__ __forceinline__ i32 rv_wadd(i32 a, i32 b) { return (i32)((u32)a + (u32)b); }
 __device__ __forceinline__ i32 rv_wsub(i32 a, i32 b) { return (i32)((u32)a - (u32)b); }
 
-template <int KIND, int B>
-__device__ __forceinline__ void batch_rowval(const Slice &S, const i32 (&qs)[B], const i32 (&qe)[B], u32 okmask, u32 (&val)[B])
+template <int KIND, int B, bool PK = false>
+__device__ __forceinline__ void batch_rowval(const Slice &S, const i32 (&qs)[B], const i32 (&qe)[B], u32 okmask, u32 (&val)[B],
+                                             const u32 (&rel)[B], const u32 (&len)[B], u32 relmask)
 {
+    auto walk = [&](int q, auto &&f) {
+        if (PK) probe_row_rel(S, rel[q], len[q], (relmask >> q) & 1u, qs[q], qe[q], f);
+        else probe_row(S, qs[q], qe[q], f);
+    };
 #pragma unroll
     for (int q = 0; q < B; q++) {
         u32 v = 0;
         if ((okmask >> q) & 1u) {
             if (KIND == RV_COUNT) {
-                if (!(qe[q] < qs[q])) probe_row(S, qs[q], qe[q], [&](u32, bool, i32, i32) { v++; });
+                if (!(qe[q] < qs[q])) walk(q, [&](u32, bool, i32, i32) { v++; });
             } else if (KIND == RV_MATCHES) {
-                probe_row(S, qs[q], qe[q], [&](u32, bool, i32, i32) { v++; });
+                walk(q, [&](u32, bool, i32, i32) { v++; });
             } else {
                 const i32 a = rv_wadd(qe[q], 1), b = rv_wsub(qs[q], 1);
-                probe_row(S, qs[q], qe[q], [&](u32, bool, i32 first, i32 last) {
+                walk(q, [&](u32, bool, i32 first, i32 last) {
                     const i32 d = rv_wsub(a < last ? a : last, b > first ? b : first);
                     v = (u32)rv_wadd((i32)v, d > 1 ? d : 1);
                 });
@@ -1082,7 +1087,8 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
                     nfull = prefetch(r0 + (u64)RP_W * WB, b0 + (u64)RP_W * WB);
                     if (MODE >= RV_COUNT) {
                         u32 val[B];
-                        batch_rowval<MODE, B>(S, qs, qe, okmask, val);
+                        if constexpr (PK) batch_rowval<MODE, B, true>(S, qs, qe, okmask, val, (const u32 (&)[B])prel, (const u32 (&)[B])plen, relmask);
+                        else batch_rowval<MODE, B, false>(S, qs, qe, okmask, val, (const u32 (&)[B])qs, (const u32 (&)[B])qs, 0u);
 #pragma unroll
                         for (int q = 0; q < B; q++) {
                             if (!((okmask >> q) & 1u)) continue;
