@@ -580,6 +580,53 @@ uint64_t orc_nearest(const uint32_t *bkey, const int32_t *bs, const int32_t *be,
     return w;
 }
 
+/* k = 1 only, for full-size checks: one output row per probe row (out index = probe row), the per-key sorts and the
+ * probe loop spread over `threads` host threads.  Same index, same nearest_one as above. */
+uint64_t orc_nearest1_mt(const uint32_t *bkey, const int32_t *bs, const int32_t *be, uint64_t nb,
+                         const uint32_t *pkey, const int32_t *ps, const int32_t *pe, uint64_t np,
+                         int strict, int include_overlaps, uint32_t *out_build, int64_t *out_dist, int threads)
+{
+    if (threads < 1) threads = 1;
+    tree_index_t t;
+    t.g = group_by_key(bkey, nb);
+    t.iv = (iv32_t *)malloc((nb ? nb : 1) * sizeof(iv32_t));
+    t.maxe = (int32_t *)malloc((nb ? nb : 1) * sizeof(int32_t));
+    iv32_t *by_end = (iv32_t *)malloc((nb ? nb : 1) * sizeof(iv32_t));
+    int32_t *pmax = (int32_t *)malloc((nb ? nb : 1) * sizeof(int32_t));
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (uint64_t i = 0; i < nb; i++) {
+        uint64_t r = t.g.rows[i];
+        t.iv[i].s = bs[r]; t.iv[i].e = be[r]; t.iv[i].row = (uint32_t)r;
+    }
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
+    for (uint32_t kk = 0; kk < t.g.nkeys; kk++) {
+        uint64_t lo = t.g.off[kk], hi = t.g.off[kk + 1];
+        qsort(t.iv + lo, hi - lo, sizeof(iv32_t), cmp_iv32_start);       /* by_start order = (start,end,row), :50-55 */
+        memcpy(by_end + lo, t.iv + lo, (hi - lo) * sizeof(iv32_t));
+        qsort(by_end + lo, hi - lo, sizeof(iv32_t), cmp_iv32_end);        /* :77-82 */
+        int32_t m = INT32_MIN;                                            /* :58-63 */
+        for (uint64_t i = lo; i < hi; i++) { if (t.iv[i].e > m) m = t.iv[i].e; pmax[i] = m; }
+    }
+#pragma omp parallel for num_threads(threads) schedule(static)
+    for (uint64_t i = 0; i < np; i++) {
+        int32_t qs = ps[i], qe = pe[i];
+        if (strict) { qs = wrap_add32(qs, 1); qe = wrap_sub32(qe, 1); }   /* nearest.rs:341-344 */
+        uint32_t kk = pkey[i];
+        iv32_t best;
+        int found = 0;
+        if (kk < t.g.nkeys && t.g.off[kk] != t.g.off[kk + 1]) {
+            uint64_t lo = t.g.off[kk];
+            nidx_t x = { t.iv + lo, by_end + lo, pmax + lo, t.maxe + lo, t.g.off[kk + 1] - lo };
+            found = nearest_one(&x, qs, qe, include_overlaps, &best);
+        }
+        out_build[i] = found ? best.row : ORC_NULL_IDX;
+        if (out_dist) out_dist[i] = found ? cand_dist(ps[i], pe[i], best.s, best.e) : -1;
+    }
+    free(by_end); free(pmax);
+    tree_index_free(&t);
+    return np;
+}
+
 /* ------------------------------------------------- a7+a8: merge sweep */
 
 typedef struct { int64_t s, e; uint64_t row; } iv64_t;

@@ -104,6 +104,10 @@ uint64_t orc_nearest(const uint32_t *bkey, const int32_t *bs, const int32_t *be,
                      const uint32_t *pkey, const int32_t *ps, const int32_t *pe, uint64_t np,
                      int strict, uint32_t k, int include_overlaps,
                      uint32_t *out_build, uint32_t *out_probe, int64_t *out_dist, uint64_t cap);
+/* k = 1, one output row per probe row at the probe row's index, `threads` host threads (full-size checks) */
+uint64_t orc_nearest1_mt(const uint32_t *bkey, const int32_t *bs, const int32_t *be, uint64_t nb,
+                         const uint32_t *pkey, const int32_t *ps, const int32_t *pe, uint64_t np,
+                         int strict, int include_overlaps, uint32_t *out_build, int64_t *out_dist, int threads);
 
 /* ---- a7+a8: merge (grouped_stream.rs:50-113, merge.rs:282-350) ----------
  * Groups by key (ascending key id = the host's byte-lexicographic contig

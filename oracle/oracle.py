@@ -41,6 +41,7 @@ def lib():
         _lib.orc_join_brute.restype = C.c_uint64
         _lib.orc_join_tree.restype = C.c_uint64
         _lib.orc_nearest.restype = C.c_uint64
+        _lib.orc_nearest1_mt.restype = C.c_uint64
         _lib.orc_merge.restype = C.c_uint64
         _lib.orc_subtract.restype = C.c_uint64
         _lib.orc_merge_intervals_i32.restype = C.c_uint64
@@ -169,6 +170,17 @@ def nearest(bkey, bs, be, pkey, ps, pe, k=1, overlap=True, strict=False):
     n = L.orc_nearest(_p(bk), _p(bs_), _p(be_), nb, _p(pk), _p(ps_), _p(pe_), npr, C.c_int(int(strict)),
                       C.c_uint32(int(k)), C.c_int(int(overlap)), _p(ob), _p(op), _p(od), C.c_uint64(cap))
     return ob[:n], op[:n], od[:n]
+
+
+def nearest1(bkey, bs, be, pkey, ps, pe, overlap=True, strict=False, threads=16):
+    """k = 1 over `threads` host threads -> (build_rows u32 per probe row (NULL_IDX = null), distance i64 (-1 = null))"""
+    L = lib()
+    bk, bs_, be_, nb = _side32(bkey, bs, be)
+    pk, ps_, pe_, npr = _side32(pkey, ps, pe)
+    ob = np.empty(len(pk), np.uint32); od = np.empty(len(pk), np.int64)
+    L.orc_nearest1_mt(_p(bk), _p(bs_), _p(be_), nb, _p(pk), _p(ps_), _p(pe_), npr, C.c_int(int(strict)),
+                      C.c_int(int(overlap)), _p(ob), _p(od), C.c_int(int(threads)))
+    return ob, od
 
 
 def merge(key, s, e, min_dist=0, strict=False):

@@ -1,5 +1,5 @@
 """-m gpu: BASELINE.json configurations at FULL size, bit-exact against the CPU oracle where the oracle
-finishes in seconds with 16 host threads (C2, C3: join pair multiset, count_overlaps and coverage columns), and
+finishes in seconds with 16 host threads (C2, C3: join pair multiset, count_overlaps and coverage columns; C4: nearest), and
 through size-independent properties where it does not (C5: merge and subtract on 10^9 rows).
 
 The reference's own scale harness compares row-multiset checksums (R/tests/integration_test.rs:4289-4349) and
@@ -83,6 +83,28 @@ def test_c3_count_coverage_100Mx1M_bit_exact(ctx):
         assert np.array_equal(cov, orc.coverage(*hb, *hp, strict=strict, threads=THREADS))
         del cov
     ixc.free(); ixv.free()
+
+
+def test_c4_nearest_50Mx50M_bit_exact(ctx):
+    """BASELINE.json configs[3] on one GPU: nearest(), k = 1, 50M x 50M rows over 24 contigs -- the build-row index
+    and the distance of EVERY probe row against the oracle (16 host threads), with and without overlapping rows."""
+    n = 50_000_000
+    bk, bs, be = synth.gen_torch(n, 1000, 24, 0x5EED0006, DEV)
+    pk, ps, pe = synth.gen_torch(n, 150, 24, 0x5EED0007, DEV)
+    torch.cuda.synchronize()
+    ix = ctx.build(pyivx.KIND_NEAREST, bk, bs, be, n_keys=24)
+    hb, hp = _host(bk, bs, be), _host(pk, ps, pe)
+    for ovl in (True, False):
+        b, p, d = ctx.nearest(ix, pk, ps, pe, k=1, overlap=ovl)
+        torch.cuda.synchronize()
+        assert b.numel() == n
+        gb, gd = b.cpu().numpy().view(np.uint32), d.cpu().numpy()
+        assert bool((p.long() == torch.arange(n, device=DEV)).all())
+        del b, p, d
+        wb, wd = orc.nearest1(*hb, *hp, overlap=ovl, threads=THREADS)
+        assert np.array_equal(gb, wb) and np.array_equal(gd, wd), ovl
+        del gb, gd, wb, wd
+    ix.free()
 
 
 def test_c2_10Mx100k_single_contig_bit_exact(ctx):

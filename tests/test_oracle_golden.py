@@ -270,3 +270,19 @@ def test_cluster_exons_issue_373(golden):
     case, names, k, s, e = _exons_cluster_case(golden)
     c = orc.cluster(k, s, e, n_keys=len(names))
     assert _selected_cluster_rows(case, names, c) == sorted(case["expect"])
+
+
+def test_nearest_threaded_equals_single():
+    # the threaded k = 1 form the full-size GPU check uses == the plain one
+    rng = np.random.default_rng(5)
+    nb, npr, nk = 30_000, 50_000, 5
+    bk = rng.integers(0, nk, nb).astype(np.uint32); bs = rng.integers(0, 400_000, nb).astype(np.int32)
+    be = (bs + rng.integers(0, 900, nb)).astype(np.int32)
+    bs[::19] = bs[1::19][: len(bs[::19])]
+    pk = rng.integers(0, nk + 1, npr).astype(np.uint32); ps = rng.integers(0, 400_000, npr).astype(np.int32)
+    pe = (ps + rng.integers(0, 300, npr)).astype(np.int32)
+    for ovl in (True, False):
+        for strict in (False, True):
+            wb, wp, wd = orc.nearest(bk, bs, be, pk, ps, pe, k=1, overlap=ovl, strict=strict)
+            gb, gd = orc.nearest1(bk, bs, be, pk, ps, pe, overlap=ovl, strict=strict, threads=4)
+            assert (wp == np.arange(npr)).all() and (gb == wb).all() and (gd == wd).all()
