@@ -348,32 +348,36 @@ __device__ __forceinline__ u32 route_prep(const JoinIndexView &ix, const KeyTab2
     const bool kok = k < kt.nkeys;
     const u32 kk = kok ? k : 0u;
     const u32 kreg = KLDS ? kt.s_kreg[kk] : (ix.kcnt[kk] ? ix.kreg[kk] : 0xFFFFFFFFu);
-    const i64 o = KLDS ? kt.s_origin[kk] : ix.origin[kk];
+    const i32 o = KLDS ? kt.s_origin[kk] : ix.origin[kk];
     const u32 span = KLDS ? kt.s_span[kk] : ix.span[kk];
-    const i64 hi = (i64)qe - o;                                     // < 0: every build row of the key starts behind qe
-    const i64 d = (i64)qs - o;
-    const bool ok = kok & (kreg != 0xFFFFFFFFu) & (hi >= 0);
+    // qe - o and qs - o in 32 bits: exact as unsigned numbers whenever they are not negative, which one signed compare tells
+    // (the partition is bound by the instructions it issues as much as by its LDS phases; 64-bit differences, shifts and
+    // clamps were a sixth of them)
+    const bool hi_ok = qe >= o;                                     // else: every build row of the key starts behind qe
+    const bool d_ok = qs >= o;
+    const u32 hi32 = (u32)qe - (u32)o, d32 = (u32)qs - (u32)o;
+    const bool ok = kok & (kreg != 0xFFFFFFFFu) & hi_ok;
     fpos = 0;
     if (FILT) {
         const u32 lastb = (span >> kt.fg) + 1u;                     // the overflow block
-        const u64 x0 = (u64)(d < 0 ? 0 : d) >> kt.fg, x1 = (u64)(hi < 0 ? 0 : hi) >> kt.fg;
-        const u32 c0 = x0 > lastb ? lastb : (u32)x0, c1 = x1 > lastb ? lastb : (u32)x1;
+        const u32 x0 = d_ok ? d32 >> kt.fg : 0u, x1 = hi_ok ? hi32 >> kt.fg : 0u;
+        const u32 c0 = x0 > lastb ? lastb : x0, c1 = x1 > lastb ? lastb : x1;
         const u32 b0 = c0 < c1 ? c0 : c1, b1 = c0 < c1 ? c1 : c0;   // (a row with end < start matches build rows that contain [end, start])
         const u32 nb1 = b1 - b0;                                    // blocks - 1
         const u32 fb = KLDS ? kt.s_fbase[kk] : ix.fbase[kk];
         fpos = ok ? (fb + b0) | ((nb1 > 31u ? 0x3Fu : nb1) << 26) : 0u;
     }
     const u32 last = span >> kt.sh0;
-    const i64 c64 = d <= 0 ? 0 : (d >> kt.sh0);
-    const u32 c = c64 > (i64)last ? last : (u32)c64;
+    const u32 cc = d_ok ? d32 >> kt.sh0 : 0u;
+    const u32 c = cc > last ? last : cc;
     const u32 rin = kt.cs != 0xFFFFFFFFu ? c >> kt.cs : (u32)(((u64)c * kt.rmul) >> 40);    // region inside the key
     packed = PK_ESCAPE;
     if (PK) {
-        // 32-bit arithmetic is exact here: for d >= 0 the region's first coordinate (rin * R << sh0 <= span) is at most d,
-        // and for end >= start the length is below 2^32
-        const u32 rel = (u32)d - ((rin * kt.rcells) << kt.sh0);
+        // for d >= 0 the region's first coordinate (rin * R << sh0 <= span) is at most d, and for end >= start the length
+        // is below 2^32
+        const u32 rel = d32 - ((rin * kt.rcells) << kt.sh0);
         const u32 len = (u32)qe - (u32)qs;
-        if (d >= 0 && rel < (1u << 24) && qe >= qs && len < maxlen) packed = (u64)rel | ((u64)len << 24);
+        if (d_ok && rel < (1u << 24) && qe >= qs && len < maxlen) packed = (u64)rel | ((u64)len << 24);
     }
     return ok ? kreg + rin : NO_REGION;
 }
@@ -438,7 +442,8 @@ __global__ __launch_bounds__(T, 4) void k_part_onepass(JoinIndexView ix, const u
     __shared__ unsigned short r_slot[PK ? 1 : TILE];            // (packed rows carry their row id with them)
     using DigT = typename std::conditional<(ND > 256), unsigned short, unsigned char>::type;
     __shared__ DigT r_dig[TILE];
-    __shared__ u32 dstart[ND], vbase[ND], pg0[ND];
+    __shared__ u32 dstart[ND];
+    __shared__ uint2 wtab[ND];                                   // per region, for the write-out: {virtual row of the run - its LDS start, first pool page | its page slot << 16}
     __shared__ u32 scan_lds[T / IVX_WAVE + 1];
     __shared__ i32 s_origin[KT_MAX];
     __shared__ u32 s_span[KT_MAX], s_kreg[KT_MAX], s_fbase[KT_MAX];
@@ -547,8 +552,7 @@ __global__ __launch_bounds__(T, 4) void k_part_onepass(JoinIndexView ix, const u
                 if (own0) __hip_atomic_store(&row[p0], got + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (own1) __hip_atomic_store(&row[p1], got + (own0 ? 2u : 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            vbase[tid] = v;
-            pg0[tid] = own0 ? got : page_wait(&row[p0]);
+            wtab[tid] = make_uint2(v - ds, (own0 ? got : page_wait(&row[p0])) | (p0 << 16));    // (pool pages and page slots number at most ~5000: host)
         }
         __syncthreads();
 #pragma unroll
@@ -556,9 +560,10 @@ __global__ __launch_bounds__(T, 4) void k_part_onepass(JoinIndexView ix, const u
             const u32 j = k * T + tid;
             if (j < tot) {
                 const u32 d = r_dig[j];
-                const u32 x = vbase[d] + (j - dstart[d]);                       // virtual row number in region d
-                u32 pg = pg0[d];
-                if ((x >> pt.lgpg) != (vbase[d] >> pt.lgpg)) pg = page_wait(pt.ptab + (u64)d * pt.pstride + (x >> pt.lgpg));   // the run's second page
+                const uint2 w = wtab[d];                                        // (one 8-byte LDS read instead of three lookups)
+                const u32 x = w.x + j;                                          // virtual row number in region d
+                u32 pg = w.y & 0xFFFFu;
+                if ((x >> pt.lgpg) != (w.y >> 16)) pg = page_wait(pt.ptab + (u64)d * pt.pstride + (x >> pt.lgpg));   // the run's second page
                 const u64 g = ((u64)pg << pt.lgpg) + (x & pmask);
                 out_se[g] = r_se[j];
                 if (!PK) out_row[g] = (u32)(t0 + r_slot[j]);
