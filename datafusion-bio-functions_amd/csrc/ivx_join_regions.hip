@@ -1044,10 +1044,28 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
                 u64 b0 = lo + (u64)wv * IVX_WAVE;
                 const u64 rf = PAGED ? rfirst(r) : 0;
                 pages_load(lo, c_hi, r, rf);
-                // (a scalar-base fast path for rounds that lie inside one pool page -- no bounds test, page lookup or 64-bit
-                //  address arithmetic per row -- was measured and dropped: fill 641 -> 703 us; the second copy of the loads
-                //  makes the kernel's code, already at the instruction cache's size, longer)
+                // PAGED: when the lane's B rows of the round lie inside the segment and inside one pool page -- nearly always --
+                // the first row's place in the pool gives the others' (they are RP_W * 64 rows apart): one bounds test and one
+                // page lookup per lane and round instead of B.  (Doing the same with a scalar base per wavefront was measured
+                // and dropped, fill 641 -> 703 us: the scalar page lookup waits where the vector one overlaps.)
+                u64 nat0 = 0, cat0 = 0;                               // pool position of the lane's first row: of the round in flight / being walked
                 auto prefetch = [&](u64, u64 bl) -> bool {
+                    if (PAGED) {
+                        const u64 i0 = bl + ln, i7 = i0 + (u64)(B - 1) * (RP_W * IVX_WAVE);
+                        const u32 x0 = (u32)(i0 - rf), x7 = (u32)(i7 - rf);
+                        const bool one = i7 < c_hi && (x0 >> pt.lgpg) == (x7 >> pt.lgpg);
+                        if (__ballot(!one) == 0) {                     // (uniform: every lane of the wavefront)
+                            const u64 at0 = row_at(i0, r, rf);
+                            nat0 = at0;
+#pragma unroll
+                            for (int q = 0; q < B; q++) {
+                                const u64 at = at0 + (u64)q * (RP_W * IVX_WAVE);
+                                nx[q] = row_se(at);
+                                nxr[q] = (FILL && !PK) ? row_id(i0 + (u64)q * (RP_W * IVX_WAVE), at) : 0u;
+                            }
+                            return true;
+                        }
+                    }
 #pragma unroll
                     for (int q = 0; q < B; q++) {
                         const u64 i = bl + (u64)q * (RP_W * IVX_WAVE) + ln;
@@ -1076,6 +1094,8 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
                         if (!nfull && b0 + (u64)q * (RP_W * IVX_WAVE) + ln < c_hi) okmask |= 1u << q;
                     }
                     if (nfull) okmask = (1u << B) - 1u;
+                    const bool cfull = nfull;
+                    cat0 = nat0;
                     if (PK) {                                           // rows that did not fit the packed form (rare)
                         u32 esc = 0;
 #pragma unroll
@@ -1099,7 +1119,7 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
                             if (!((okmask >> q) & 1u)) continue;
                             const u64 i = b0 + (u64)q * (RP_W * IVX_WAVE) + ln;
                             if (PAGED) {    // in place: the value takes the low half of the row's packed word, the row id stays above it
-                                const u64 at = row_at(i, r, rf);
+                                const u64 at = cfull ? cat0 + (u64)q * (RP_W * IVX_WAVE) : row_at(i, r, rf);
                                 ((u64 *)ob)[at] = (u64)val[q] | ((u64)rowv[q] << 32);      // (ob = the page pool itself)
                             } else ob[i] = val[q];
                         }
