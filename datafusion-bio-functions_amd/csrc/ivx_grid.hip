@@ -1,5 +1,6 @@
 // ivx_grid.hip -- per-key statistics and the rank-grid build (see ivx_grid.hpp).
 // Counting sort with atomics: histogram of cells, exclusive scan, scatter.
+#include <cstdlib>
 #include "ivx_grid.hpp"
 #include "ivx_scan.hpp"
 
@@ -93,7 +94,7 @@ __device__ __forceinline__ u32 gcells(u32 cnt, u32 span, u32 sh) { return cnt ? 
 
 // one workgroup: origin/span, row offsets per key, cell width, first cell per key
 __global__ __launch_bounds__(1024) void k_grid_layout(const i32 *kmin, const i32 *kmax, const u32 *kcnt, u32 nkeys, u64 n,
-                                                      i32 *origin, u32 *span, u32 *koff, u32 *kbase, u32 *hdr)
+                                                      i32 *origin, u32 *span, u32 *koff, u32 *kbase, u32 *hdr, u64 budget)
 {
     __shared__ u64 red[1024 / IVX_WAVE + 1];
     __shared__ u32 s_sh;
@@ -104,7 +105,6 @@ __global__ __launch_bounds__(1024) void k_grid_layout(const i32 *kmin, const i32
         span[k] = c ? (u32)((i64)kmax[k] - (i64)kmin[k]) : 0u;
     }
     __syncthreads();
-    const u64 budget = 2 * n + nkeys;
     u32 lo = 0, hi = 31;
     while (lo < hi) {
         const u32 mid = (lo + hi) / 2;
@@ -248,7 +248,10 @@ ivx_status ivx_grid_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32
     if (!sorted) IVX_HIP(ctx, hipMemsetAsync(cursor, 0, (maxcells + 1) * sizeof(u32), st));
     if (sorted && n) hipLaunchKernelGGL(k_keystats_sorted, dim3((nkeys + GT - 1) / GT), dim3(GT), 0, st, key, v, n, nkeys, kmin, kmax, kcnt, vstride);
     else IVX_TRY(ivx_keystats(ctx, key, v, n, nkeys, kmin, kmax, kcnt, errflag, vstride));
-    hipLaunchKernelGGL(k_grid_layout, dim3(1), dim3(1024), 0, st, kmin, kmax, kcnt, nkeys, n, origin, span, koff, kbase, hdr);
+    // cells: two per value (fewer, e.g. one per two values for the nearest index's grids over record fields, was measured:
+    // the cell tables shrink but the cell scans grow, k=1 probe 3.10 -> 3.28 ms per 50M rows at one per two)
+    const u64 budget = 2 * n + nkeys;
+    hipLaunchKernelGGL(k_grid_layout, dim3(1), dim3(1024), 0, st, kmin, kmax, kcnt, nkeys, n, origin, span, koff, kbase, hdr, budget);
     if (n && sorted) {
         const u32 grid = ivx_stream_grid(n, GT * 2, 1u << 20);          // (a row's loads depend on nothing: many short threads hide their latency)
         hipLaunchKernelGGL(k_grid_bounds, dim3(grid), dim3(GT), 0, st, key, v, n, nkeys, origin, kbase, hdr, binstart, vstride);
