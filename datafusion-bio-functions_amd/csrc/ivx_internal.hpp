@@ -57,6 +57,7 @@ struct ivx_join_plan {
     // ptab = [region][page slot] -> page + 1
     bool paged = false, packed = false;   // packed: 8-byte routed rows (start in region | length | row), else (start,end) + row id
     const u32 *ptab = nullptr; u32 pstride = 0, lgpg = 0, rowbits = 32;
+    bool all_routed = false;              // no occupancy bitmap in use: every row was routed (the fill's rows-per-lane rule is then known on the host)
 };
 
 struct ivx_ctx {

@@ -1899,6 +1899,7 @@ ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nre
     if ((planned && pl.paged) || (!planned && !two_pass)) {
         const bool wide = nreg > IVX_MAXREG;
         PageTab pt; const u32 *rfirst; const u64 *pool_se; const u32 *pool_row;
+        bool all_routed = false;
         // 8-byte routed rows whenever a region's coordinates fit 24 bits (IVX_PACK=0: the 12-byte form, for A/B runs and tests)
         const bool pack_off = getenv("IVX_PACK") && !strcmp(getenv("IVX_PACK"), "0");
         bool packed = pk24 && !pack_off;
@@ -1907,7 +1908,7 @@ ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nre
         if (planned) {
             rowbits = pl.rowbits;
             pt = PageTab{const_cast<u32 *>(pl.ptab), pl.pstride, pl.lgpg};
-            rfirst = pl.hist; pool_se = pl.pse; pool_row = pl.prow; packed = pl.packed;
+            rfirst = pl.hist; pool_se = pl.pse; pool_row = pl.prow; packed = pl.packed; all_routed = pl.all_routed;
             s = pl.ds; e = pl.de;                                       // (the columns the count call read: packed rows refer to them)
         } else {
             u32 lgpg = 14;                                              // a page holds at least a tile; at most ~4096 pages per region
@@ -1938,6 +1939,7 @@ ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nre
             const bool filter_off = getenv("IVX_FILTER") && !strcmp(getenv("IVX_FILTER"), "0");   // experiments: IVX_FILTER=0 routes every row
             const bool use_filter = has_filter && !filter_off;
             if (use_filter) rowbits = 32;                               // (see pk_maxlen)
+            all_routed = !use_filter;
             if (wide) { if (vec) IVX_ONEPASS(true, 1024, 8); else IVX_ONEPASS(false, 1024, 8); }
             else { if (vec) IVX_ONEPASS(true, 256, 12); else IVX_ONEPASS(false, 256, 12); }
 #undef IVX_ONEPASS2
@@ -1948,7 +1950,7 @@ ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nre
             rfirst = rf; pool_se = pse; pool_row = prow;
             if (mode == JP_COUNT) {
                 pl.hist = rf; pl.pse = pse; pl.prow = prow; pl.ds = s; pl.de = e; pl.chunk = 0; pl.nblk = 1;
-                pl.paged = true; pl.packed = packed; pl.rowbits = rowbits; pl.ptab = ptab; pl.pstride = (u32)pstride; pl.lgpg = lgpg;
+                pl.paged = true; pl.packed = packed; pl.rowbits = rowbits; pl.ptab = ptab; pl.pstride = (u32)pstride; pl.lgpg = lgpg; pl.all_routed = all_routed;
                 pl.slots = (1ull << WS_SORTHIST) | (1ull << WS_T0) | (1ull << WS_T1) | (1ull << WS_T2) | (1ull << WS_IN_START) | (1ull << WS_IN_END);
                 pl.valid = true;
             }
@@ -1959,12 +1961,15 @@ ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nre
         if (mode == JP_FILL && dense_fill_wanted(hint, n))
             return dense_fill(ctx, jv, nreg, (const void *)pool_se, (const void *)pool_row, 1u, s, e, rfirst, 1u, nullptr, n, ob, op, cap, d_cursor, &pt, packed, rowbits);
         if (mode == JP_FILL) {
-            u32 *bsel = (u32 *)(ctx->d_scalars + 11);
+            // rows per lane follow from the pairs per ROUTED row: known here when every row was routed; with the occupancy
+            // bitmap in use the count sits on the device, k_pick_rows decides there and every variant is launched (three exit)
+            u32 *bsel = all_routed ? nullptr : (u32 *)(ctx->d_scalars + 11);
             const u32 force = getenv("IVX_RP_ROWS") ? (u32)atoi(getenv("IVX_RP_ROWS")) : 0u;
-            hipLaunchKernelGGL(k_pick_rows, dim3(1), dim3(1), 0, st, rfirst, nreg, hint, force, bsel);
+            if (bsel) hipLaunchKernelGGL(k_pick_rows, dim3(1), dim3(1), 0, st, rfirst, nreg, hint, force, bsel);
 #define IVX_FILLP2(B_, P_) hipLaunchKernelGGL((k_probe_regions<1, B_, false, true, P_>), dim3(RP_GRID), dim3(RP_T), 0, st, jv, (const void *)pool_se, (const void *)pool_row, rfirst, 1u, RP_VGRID / RP_GRID, ob, op, cap, cur, 1u, 0u, (const u32 *)nullptr, dbg, pt, (const u32 *)bsel, s, e, rowbits)
 #define IVX_FILLP(B_) do { if (packed) IVX_FILLP2(B_, true); else IVX_FILLP2(B_, false); } while (0)
-            IVX_FILLP(8); IVX_FILLP(4); IVX_FILLP(2); IVX_FILLP(1);
+            if (bsel) { IVX_FILLP(8); IVX_FILLP(4); IVX_FILLP(2); IVX_FILLP(1); }
+            else switch (fill_rows_per_lane(hint, n)) { case 1: IVX_FILLP(1); break; case 2: IVX_FILLP(2); break; case 4: IVX_FILLP(4); break; default: IVX_FILLP(8); }
 #undef IVX_FILLP
 #undef IVX_FILLP2
         } else if (packed) {
