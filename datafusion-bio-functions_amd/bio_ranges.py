@@ -244,8 +244,8 @@ class Session:
 
     # ---- f3: compute::take of payload columns on the device (interval_join.rs:1655-1667, nearest.rs:469-482)
     def take(self, column, idx):
-        """column: pyarrow Array / ChunkedArray; idx: UInt32 array (nulls -> null rows).  Raises for layouts the
-        device gather does not cover (nested types): those stay with the caller's own take."""
+        """column: pyarrow Array / ChunkedArray of any flat, dictionary-encoded or nested (struct / list / map) type;
+        idx: UInt32 array (nulls -> null rows).  Raises for layouts the gather does not cover (unions, run-end encoding)."""
         if isinstance(column, pa.ChunkedArray):
             column = column.combine_chunks() if column.num_chunks != 1 else column.chunk(0)
         if isinstance(idx, pa.ChunkedArray):

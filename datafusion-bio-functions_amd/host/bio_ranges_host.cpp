@@ -225,7 +225,10 @@ int build_keys(brh_session *s, const std::vector<std::pair<brh_batch, brh_column
 }
 
 // ---- Arrow output helpers
-struct OutPriv { std::vector<void *> bufs; const void *ptrs[4] = {nullptr, nullptr, nullptr, nullptr}; char *fmt = nullptr; ArrowArray *dict = nullptr; };
+struct OutPriv {
+    std::vector<void *> bufs; const void *ptrs[4] = {nullptr, nullptr, nullptr, nullptr}; char *fmt = nullptr; ArrowArray *dict = nullptr;
+    std::vector<ArrowArray *> children;                 // nested outputs (struct / list): owned, released with the parent
+};
 
 void release_array(ArrowArray *a)
 {
@@ -233,6 +236,7 @@ void release_array(ArrowArray *a)
     OutPriv *p = (OutPriv *)a->private_data;
     for (void *b : p->bufs) std::free(b);
     if (p->dict) { if (p->dict->release) p->dict->release(p->dict); std::free(p->dict); }
+    for (ArrowArray *c : p->children) { if (c->release) c->release(c); std::free(c); }
     delete p;
     a->release = nullptr;
 }
@@ -241,6 +245,8 @@ void release_schema(ArrowSchema *sc)
     if (!sc || !sc->release) return;
     std::free((void *)sc->format); std::free((void *)sc->name);
     if (sc->dictionary) { if (sc->dictionary->release) sc->dictionary->release(sc->dictionary); std::free(sc->dictionary); }
+    for (int64_t c = 0; c < sc->n_children; c++) { if (sc->children[c]->release) sc->children[c]->release(sc->children[c]); std::free(sc->children[c]); }
+    std::free(sc->children);
     sc->release = nullptr;
 }
 
@@ -675,6 +681,83 @@ extern "C" int brh_take(brh_session *s, const ArrowArray *column, const ArrowSch
     const uint64_t n_src = (uint64_t)column->length;
     std::memset(out, 0, sizeof *out);
     const bool str32 = !std::strcmp(f, "u") || !std::strcmp(f, "z"), str64 = !std::strcmp(f, "U") || !std::strcmp(f, "Z");
+    const bool is_struct = !std::strcmp(f, "+s"), is_list = !std::strcmp(f, "+l") || !std::strcmp(f, "+m"), is_llist = !std::strcmp(f, "+L"),
+               is_fsl = !std::strncmp(f, "+w:", 3);
+    if (is_struct || is_list || is_llist || is_fsl) {
+        // nested columns (arrow's take handles any type, interval_join.rs:1655-1667): the row selection of a struct is the same
+        // take on every child; a list's rows become ranges of child elements, i.e. one more index array for a take on the
+        // child.  The leaves end in the device gathers below; offsets and validity of the nesting levels are host work.
+        for (int64_t i = 0; i < n; i++) {
+            if (ix[i] != IVX_NULL_IDX && ix[i] >= n_src) return fail(s, "take: index " + std::to_string(ix[i]) + " out of range (column has " + std::to_string(n_src) + " rows)");
+            valid[i] = ix[i] != IVX_NULL_IDX && (!svb || ((svb[ix[i] >> 3] >> (ix[i] & 7)) & 1));
+        }
+        const int64_t nchild = column->n_children;
+        if (nchild != column_schema->n_children || (!is_struct && nchild != 1)) return fail(s, "take: malformed nested column");
+        OutPriv *p = new OutPriv();
+        ArrowSchema **cschemas = (ArrowSchema **)std::calloc((size_t)(nchild ? nchild : 1), sizeof(ArrowSchema *));
+        auto cleanup = [&](int64_t upto) {
+            for (int64_t c = 0; c < upto; c++) { if (cschemas[c]->release) cschemas[c]->release(cschemas[c]); std::free(cschemas[c]); }
+            std::free(cschemas);
+            for (ArrowArray *c : p->children) { if (c->release) c->release(c); std::free(c); }
+            for (void *b : p->bufs) std::free(b);
+            delete p;
+        };
+        // the child rows to take, as a UInt32 index array with nulls
+        std::vector<uint32_t> cidx; std::vector<uint8_t> cvalid_bits;
+        int n_buffers = 1;
+        if (is_struct) {
+            cidx = ix;                                              // (null indices stay null; rows under a null struct are taken as they are)
+        } else if (is_fsl) {
+            const int64_t w = std::atoll(f + 3);
+            if (w < 0 || (uint64_t)(column->offset + (int64_t)n_src) * (uint64_t)w >= 0xFFFFFFFFull) { cleanup(0); return fail(s, "take: fixed-size list child too large for 32-bit indices"); }
+            cidx.resize((size_t)((n * w) > 0 ? n * w : 1));
+            for (int64_t i = 0; i < n; i++)
+                for (int64_t j = 0; j < w; j++) cidx[(size_t)(i * w + j)] = ix[i] == IVX_NULL_IDX ? IVX_NULL_IDX : (uint32_t)((column->offset + (int64_t)ix[i]) * w + j);
+        } else {
+            const size_t ow = is_llist ? 8 : 4;
+            const uint8_t *off = (const uint8_t *)column->buffers[1] + (size_t)column->offset * ow;
+            auto at = [&](uint64_t r) -> int64_t { return is_llist ? ((const int64_t *)off)[r] : (int64_t)((const int32_t *)off)[r]; };
+            void *noff = std::malloc((size_t)(n + 1) * ow);
+            int64_t run = 0;
+            for (int64_t i = 0; i <= n; i++) {
+                if (is_llist) ((int64_t *)noff)[i] = run; else ((int32_t *)noff)[i] = (int32_t)run;
+                if (i < n && valid[i]) {
+                    const int64_t a = at(ix[i]), b = at((uint64_t)ix[i] + 1);
+                    for (int64_t e = a; e < b; e++) cidx.push_back((uint32_t)e);
+                    if ((uint64_t)b >= 0xFFFFFFFFull) { std::free(noff); cleanup(0); return fail(s, "take: list child too large for 32-bit indices"); }
+                    run += b - a;
+                }
+            }
+            if (!is_llist && run > INT32_MAX) { std::free(noff); cleanup(0); return fail(s, "take: the gathered lists overflow 32-bit offsets"); }
+            p->bufs.push_back(noff); p->ptrs[1] = noff; n_buffers = 2;
+            if (cidx.empty()) cidx.push_back(0);
+        }
+        const int64_t n_cidx = is_struct ? n : is_fsl ? n * std::atoll(f + 3) : ((!is_llist) ? (int64_t)((const int32_t *)p->ptrs[1])[n] : ((const int64_t *)p->ptrs[1])[n]);
+        // a UInt32 Arrow array over cidx (nulls where IVX_NULL_IDX)
+        cvalid_bits.assign((size_t)(n_cidx + 7) / 8 + 1, 0);
+        int64_t cnulls = 0;
+        for (int64_t i = 0; i < n_cidx; i++) { if (cidx[(size_t)i] != IVX_NULL_IDX) cvalid_bits[(size_t)i >> 3] |= (uint8_t)(1u << (i & 7)); else cnulls++; }
+        const void *cbufs[2] = {cnulls ? (const void *)cvalid_bits.data() : nullptr, cidx.data()};
+        ArrowArray cia; std::memset(&cia, 0, sizeof cia);
+        cia.length = n_cidx; cia.null_count = cnulls; cia.n_buffers = 2; cia.buffers = cbufs;
+        for (int64_t c = 0; c < nchild; c++) {
+            ArrowArray cc = *column->children[c];                   // (a shallow view: nothing of it is released here)
+            if (is_struct) { cc.offset += column->offset; cc.length = column->length; cc.null_count = -1; }
+            ArrowArray *co = (ArrowArray *)std::malloc(sizeof(ArrowArray));
+            cschemas[c] = (ArrowSchema *)std::malloc(sizeof(ArrowSchema));
+            if (brh_take(s, &cc, column_schema->children[c], &cia, idx_schema, co, cschemas[c])) { std::free(co); std::free(cschemas[c]); cleanup(c); return 1; }
+            // the child's field keeps its own name and nullability
+            cschemas[c]->flags = column_schema->children[c]->flags;
+            p->children.push_back(co);
+        }
+        finish_array(out, p, n, valid.data(), n_buffers);
+        out->n_children = nchild;
+        out->children = p->children.data();
+        make_schema(out_schema, f, column_schema->name ? column_schema->name : "", true);
+        out_schema->flags |= column_schema->flags & 4;              // ARROW_FLAG_MAP_KEYS_SORTED
+        out_schema->n_children = nchild; out_schema->children = cschemas;
+        return 0;
+    }
     if (column_schema->dictionary) {
         // dictionary-encoded column (arrow's take gathers the keys and keeps the dictionary): the keys are a fixed-width
         // gather on the device, the output carries an owned copy of the dictionary values
@@ -759,7 +842,7 @@ extern "C" int brh_take(brh_session *s, const ArrowArray *column, const ArrowSch
         finish_array(out, p, n, valid.data(), 2);
     } else {
         const uint32_t w = fixed_width(f);
-        if (!w) return fail(s, "take: unsupported column type " + std::string(f) + " (fixed-width primitives, Boolean, Utf8/LargeUtf8/Binary/LargeBinary and their views only)");
+        if (!w) return fail(s, "take: unsupported column type " + std::string(f) + " (fixed-width primitives, Boolean, Utf8/LargeUtf8/Binary/LargeBinary and their views, dictionaries and struct / list nestings of those only)");
         const uint8_t *src = (const uint8_t *)column->buffers[1] + (size_t)column->offset * w;
         void *o = std::malloc((size_t)(n ? n : 1) * w);
         const ivx_status st = ivx_take_fixed(s->ctx, IVX_MEM_HOST, src, w, n_src, svb, ix.data(), (uint64_t)n, o, valid.data());

@@ -132,8 +132,10 @@ int brh_complement(brh_session *s, brh_batch table, brh_columns cols, brh_batch 
  * Boolean, Utf8 / LargeUtf8 / Binary / LargeBinary, or Utf8View / BinaryView (the output is compacted
  * into one data buffer), or a dictionary-encoded column over any of the flat value types (the keys are gathered, the
  * output carries its own copy of the dictionary); idx: UInt32, nulls allowed (-> null output slots).
- * Nested layouts (struct, list, ...) return an error: the caller keeps them on its own take.  The output has the
- * column's type and is nullable. */
+ * Nested columns -- Struct, List / LargeList / FixedSizeList, Map, in any nesting over the types above -- are taken level
+ * by level (a struct's row selection on every child, a list's rows as ranges of child elements); their leaves go through
+ * the same device gathers, offsets and validity of the nesting levels are host work.  Union and run-end-encoded layouts
+ * return an error.  The output has the column's type and is nullable. */
 int brh_take(brh_session *s, const struct ArrowArray *column, const struct ArrowSchema *column_schema,
              const struct ArrowArray *idx, const struct ArrowSchema *idx_schema,
              struct ArrowArray *out, struct ArrowSchema *out_schema);

@@ -241,9 +241,42 @@ def test_device_take_matches_arrow_take(ctx):
             got.validate(full=True)
             assert got.dictionary.to_pylist() == col.chunk(0).dictionary.to_pylist()      # the dictionary rides along unchanged
     with pytest.raises(br.BioRangesError, match="unsupported column type"):
-        ctx.take(pa.array([[1], [2]]), pa.array([0], pa.uint32()))             # nested: stays with the caller
+        ctx.take(pa.array([b"abc", b"def"], pa.binary(3)), pa.array([0], pa.uint32()))    # 3-byte elements: no device gather for that width
     with pytest.raises(br.BioRangesError, match="out of bounds"):
         ctx.take(pa.array([1, 2]), pa.array([2], pa.uint32()))
+
+
+def test_take_nested_columns(ctx):
+    """arrow's take handles any type (interval_join.rs:1655-1667): struct, list, large_list, fixed_size_list and map columns
+    -- and nestings of them -- go down to the device gathers of their leaves; checked against pyarrow's take"""
+    import pyarrow.compute as pc
+    n = 300
+    def maybe(i, v, m):
+        return None if i % m == 0 else v
+    cols = {
+        "struct": pa.array([maybe(i, {"a": maybe(i, i, 7), "b": maybe(i, "s%d" % i, 5), "c": i % 2 == 0}, 11) for i in range(n)],
+                           pa.struct([("a", pa.int64()), ("b", pa.string()), ("c", pa.bool_())])),
+        "list_i32": pa.array([maybe(i, [maybe(j, i * 10 + j, 4) for j in range(i % 5)], 9) for i in range(n)], pa.list_(pa.int32())),
+        "llist_str": pa.array([maybe(i, ["x" * (j + i % 3) for j in range(i % 4)], 13) for i in range(n)], pa.large_list(pa.string())),
+        "fsl_f32": pa.array([maybe(i, [float(i), float(i) + 0.5, -float(i)], 6) for i in range(n)], pa.list_(pa.float32(), 3)),
+        "list_struct": pa.array([maybe(i, [{"k": "q%d" % j, "v": maybe(j, j * i, 3)} for j in range(i % 3)], 8) for i in range(n)],
+                                pa.list_(pa.struct([("k", pa.string()), ("v", pa.int64())]))),
+        "map": pa.array([maybe(i, [("k%d" % j, j + i) for j in range(i % 3)], 10) for i in range(n)], pa.map_(pa.string(), pa.int32())),
+        "struct_list": pa.array([{"xs": [i, i + 1][: i % 3], "tag": maybe(i, "t", 4)} for i in range(n)],
+                                pa.struct([("xs", pa.list_(pa.int16())), ("tag", pa.string())])),
+    }
+    t = pa.table(cols).slice(5)                                       # non-zero offsets at every level
+    idx = pa.array([None if i % 17 == 0 else (i * 11) % t.num_rows for i in range(700)], pa.uint32())
+    for name in t.schema.names:
+        col = t.column(name)
+        got = ctx.take(col, idx)
+        want = pc.take(col, idx).combine_chunks()
+        got.validate(full=True)
+        assert got.type == want.type and got.to_pylist() == want.to_pylist(), name
+    empty = ctx.take(t.column("list_struct"), pa.array([], pa.uint32()))
+    assert len(empty) == 0 and empty.type == t.column("list_struct").type
+    with pytest.raises(br.BioRangesError, match="out of range"):
+        ctx.take(pa.array([[1], [2]]), pa.array([2], pa.uint32()))
 
 
 def test_sql_range_join_with_device_take(ctx, golden):
