@@ -247,7 +247,7 @@ def main():
             assert len(b) == pairs
         out["e2e"] = {"ms": 1e3 * best, "pairs_per_s": pairs / best, "probe_rows_per_s": n_probe / best,
                       "h2d_bytes": 12 * n_probe, "d2h_bytes": 8 * pairs, "link_gbps": (12 * n_probe + 8 * pairs) / best / 1e9,
-                      "what": "ivx_probe_overlap_fill with IVX_MEM_HOST: pageable host columns in, pairs out to host buffers (index already built)"}
+                      "what": "ivx_probe_overlap_fill with IVX_MEM_HOST: pageable host columns in, pairs out to host buffers (index already built); the library cuts the batch into 4 chunks and copies the pairs of one back while the next uploads"}
         ix.free()
       except Exception as ex:                                    # noqa: BLE001 -- extras never cost the official line
         out["extras_error"] = f"{type(ex).__name__}: {ex}"

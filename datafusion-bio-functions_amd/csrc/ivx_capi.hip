@@ -8,6 +8,9 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <thread>
+#include <condition_variable>
+#include <deque>
 
 // ------------------------------------------------------------- ctx helpers
 
@@ -417,11 +420,121 @@ extern "C" ivx_status ivx_probe_overlap_count(ivx_ctx *ctx, const ivx_index *ix,
     return overlap_common(ctx, ix, mem, per_row ? JP_PER_ROW : JP_COUNT, key, start, end, n, per_row, nullptr, nullptr, nullptr, 0, total);
 }
 
+// ---- host-resident fill of a big batch: chunks, so that the link runs in both directions at once
+// The columns of 100 M probe rows cross the link in ~21 ms, the pairs come back in ~5 ms, the kernels take 1.3 ms: done one
+// after the other that is what the call costs.  Cut into chunks, the pairs of chunk c go back to the host (a helper thread
+// on a stream of its own: a copy from or to pageable memory occupies the thread that issues it) while the columns of chunk
+// c + 1 come in.  Every chunk is a device-resident fill of its own that appends to the same pair buffers; probe row ids
+// are shifted by the chunk's first row afterwards.  Order of the pairs is free, as everywhere.
+__global__ void k_add_base(u32 *__restrict__ p, u64 n, u32 base)
+{
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) p[i] += base;
+}
+
+static ivx_status overlap_fill_host_chunked(ivx_ctx *ctx, const ivx_index *ix, const u32 *key, const i32 *start, const i32 *end, u64 n,
+                                            u32 *bidx, u32 *pidx, u64 cap, u64 *written, u32 nchunk)
+{
+    IVX_TRY(check_probe_args(ctx, ix, IVX_KIND_OVERLAP, IVX_MEM_HOST, start, end, n));
+    hipStream_t st = ctx->stream;
+    const u64 rows = ((n + nchunk - 1) / nchunk + 65535) & ~65535ull;           // rows per chunk
+    u32 *d_b, *d_p;
+    IVX_TRY(ctx->get_scratch(WS_OUT_C, (size_t)(cap ? cap : 1) * sizeof(u32), (void **)&d_b));
+    IVX_TRY(ctx->get_scratch(WS_OUT_D, (size_t)(cap ? cap : 1) * sizeof(u32), (void **)&d_p));
+    // two sets of staged columns: chunk c + 1 arrives while the kernels of chunk c may still read theirs
+    u32 *dk[2] = {nullptr, nullptr}; i32 *ds[2], *de[2];
+    for (int b = 0; b < 2; b++) {
+        if (key) IVX_TRY(ctx->get_scratch(b ? WS_IN2_KEY : WS_IN_KEY, rows * sizeof(u32), (void **)&dk[b]));
+        IVX_TRY(ctx->get_scratch(b ? WS_IN2_START : WS_IN_START, rows * sizeof(i32), (void **)&ds[b]));
+        IVX_TRY(ctx->get_scratch(b ? WS_IN2_END : WS_IN_END, rows * sizeof(i32), (void **)&de[b]));
+    }
+    hipStream_t cs;
+    IVX_HIP(ctx, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    struct Job { u64 at, cnt; hipEvent_t ev; };
+    std::mutex mu; std::condition_variable cv; std::deque<Job> jobs; bool closed = false; hipError_t herr = hipSuccess;
+    const int device = ctx->device;
+    std::thread helper([&]() {
+        (void)hipSetDevice(device);
+        for (;;) {
+            Job j;
+            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return closed || !jobs.empty(); }); if (jobs.empty()) return; j = jobs.front(); jobs.pop_front(); }
+            hipError_t e = hipStreamWaitEvent(cs, j.ev, 0);
+            if (e == hipSuccess && j.cnt) e = hipMemcpyAsync(bidx + j.at, d_b + j.at, j.cnt * sizeof(u32), hipMemcpyDeviceToHost, cs);
+            if (e == hipSuccess && j.cnt) e = hipMemcpyAsync(pidx + j.at, d_p + j.at, j.cnt * sizeof(u32), hipMemcpyDeviceToHost, cs);
+            if (e == hipSuccess) e = hipStreamSynchronize(cs);
+            if (e != hipSuccess) { std::lock_guard<std::mutex> lk(mu); herr = e; }
+        }
+    });
+    std::vector<hipEvent_t> evs;
+    auto finish = [&]() {
+        { std::lock_guard<std::mutex> lk(mu); closed = true; }
+        cv.notify_all();
+        helper.join();
+        for (hipEvent_t e : evs) (void)hipEventDestroy(e);
+        (void)hipStreamDestroy(cs);
+    };
+    const ivx_metrics m0 = ctx->metrics;                                        // (the chunks are one batch to the caller)
+    u64 cum = 0, need = 0;
+    ivx_status rc = IVX_OK;
+    bool over = false;                                                          // the pair buffers ran out: only count from here on
+    for (u32 c = 0; c < nchunk && rc == IVX_OK; c++) {
+        const u64 c0 = (u64)c * rows, c1 = c0 + rows < n ? c0 + rows : n;
+        if (c0 >= c1) break;
+        const int b = (int)(c & 1u);
+        const u64 nc = c1 - c0;
+        hipError_t e = hipSuccess;
+        if (key) e = hipMemcpyAsync(dk[b], key + c0, nc * sizeof(u32), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(ds[b], start + c0, nc * sizeof(i32), hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(de[b], end + c0, nc * sizeof(i32), hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) { rc = ctx->fail_hip("hipMemcpyAsync(chunk)", e); break; }
+        u64 tot = 0;
+        if (!over) {
+            rc = overlap_common(ctx, ix, IVX_MEM_DEVICE, JP_FILL, dk[b], ds[b], de[b], nc, nullptr, nullptr, d_b + cum, d_p + cum, cap - cum, &tot);
+            if (rc == IVX_ERR_CAPACITY) { over = true; rc = IVX_OK; need = cum + tot; continue; }
+            if (rc != IVX_OK) break;
+            if (tot && c0) hipLaunchKernelGGL(k_add_base, dim3(1024), dim3(256), 0, st, d_p + cum, tot, (u32)c0);
+            hipEvent_t ev;
+            e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (e == hipSuccess) { evs.push_back(ev); e = hipEventRecord(ev, st); }
+            if (e != hipSuccess) { rc = ctx->fail_hip("hipEventRecord(chunk)", e); break; }
+            { std::lock_guard<std::mutex> lk(mu); jobs.push_back(Job{cum, tot, ev}); }
+            cv.notify_all();
+            cum += tot;
+        } else {
+            rc = overlap_common(ctx, ix, IVX_MEM_DEVICE, JP_COUNT, dk[b], ds[b], de[b], nc, nullptr, nullptr, nullptr, nullptr, 0, &tot);
+            need += tot;
+        }
+    }
+    // (the staged columns of the last chunks must not be reused before their kernels are done: the stream is idle here)
+    const hipError_t es = hipStreamSynchronize(st);
+    finish();
+    ctx->join_plan.valid = false;                                               // (the count calls above may have left one: it refers to a chunk)
+    ctx->metrics.input_batches = m0.input_batches + 1;
+    ctx->metrics.output_batches = m0.output_batches + ((rc == IVX_OK && !over && cum) ? 1 : 0);
+    if (over) ctx->metrics.output_rows = m0.output_rows;
+    if (rc != IVX_OK) return rc;
+    if (es != hipSuccess) return ctx->fail_hip("hipStreamSynchronize", es);
+    if (herr != hipSuccess) return ctx->fail_hip("hipMemcpyAsync(pairs)", herr);
+    if (written) *written = over ? need : cum;
+    if (over) return ctx->fail(IVX_ERR_CAPACITY, "pair buffers too small");
+    return IVX_OK;
+}
+
 extern "C" ivx_status ivx_probe_overlap_fill(ivx_ctx *ctx, const ivx_index *ix, int mem, const uint32_t *key,
                                              const int32_t *start, const int32_t *end, uint64_t n,
                                              uint32_t *build_idx, uint32_t *probe_idx, uint64_t cap, uint64_t *written)
 {
     if (ctx && cap && (!build_idx || !probe_idx)) return ctx->fail(IVX_ERR_INVALID, "null pair buffers");
+    // host-resident columns of a big batch, and no count call left its routed rows (and device copies) behind: chunked
+    // (IVX_HOST_CHUNKS = number of chunks, 1 switches it off; default 4 from 16 M rows)
+    if (ctx && ix && mem == IVX_MEM_HOST && cap && start && end) {
+        const char *ce = getenv("IVX_HOST_CHUNKS");
+        const u32 nchunk = ce ? (u32)atoi(ce) : (n >= (16ull << 20) ? 4u : 1u);
+        const void *in[3] = {key, start, end};
+        const ivx_join_plan &pl = ctx->join_plan;
+        const bool planned = pl.valid && pl.mem == mem && memcmp(pl.in, in, sizeof(in)) == 0 && pl.n == n && pl.ix == (const void *)ix && pl.ix_serial == ix->serial;
+        if (nchunk > 1 && n >= (u64)nchunk * 65536 && !planned && ix->kind == IVX_KIND_OVERLAP)
+            return overlap_fill_host_chunked(ctx, ix, key, start, end, n, build_idx, probe_idx, cap, written, nchunk);
+    }
     return overlap_common(ctx, ix, mem, JP_FILL, key, start, end, n, nullptr, nullptr, build_idx, probe_idx, cap, written);
 }
 

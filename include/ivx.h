@@ -148,7 +148,12 @@ ivx_status ivx_probe_overlap_count(ivx_ctx *ctx, const ivx_index *ix, int mem,
  *       work (and takes the counted total, not cap, as the density hint) --
  *       the three columns must not change between the two calls.  The state
  *       serves ONE successful fill call (it survives an IVX_ERR_CAPACITY
- *       retry); any other call drops it and a fill call does everything itself. */
+ *       retry); any other call drops it and a fill call does everything itself.
+ *       An IVX_MEM_HOST fill of a big batch (16 M rows or more) that has no such
+ *       state to use runs in chunks: the pairs of one chunk are copied to
+ *       build_idx / probe_idx by a helper thread while the next chunk's columns
+ *       are uploaded (both directions of the link at once).  On IVX_ERR_CAPACITY
+ *       the buffers may then hold the pairs of the first chunks. */
 ivx_status ivx_probe_overlap_fill(ivx_ctx *ctx, const ivx_index *ix, int mem,
                                   const uint32_t *key, const int32_t *start, const int32_t *end, uint64_t n,
                                   uint32_t *build_idx, uint32_t *probe_idx, uint64_t cap, uint64_t *written);

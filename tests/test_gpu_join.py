@@ -210,6 +210,35 @@ def test_join_more_than_255_regions(ctx):
     _check_join(ctx, bk, bs, be, pk, ps, pe, 4)
 
 
+@pytest.mark.parametrize("with_key", [True, False])
+def test_host_fill_in_chunks(ctx, with_key):
+    # host-resident columns of a big batch cross the link in chunks (pairs of chunk c go back while chunk c + 1 comes in):
+    # the same pair multiset as the oracle, probe row ids over the whole batch; too small buffers report the full count
+    nk = 5 if with_key else 1
+    bk, bs, be = synth(40_000, 91, nkeys=nk, mean_len=800, span=6_000_000)
+    pk, ps, pe = synth(900_000, 92, nkeys=nk, mean_len=120, span=6_000_000)
+    ix = ctx.build(pyivx.KIND_OVERLAP, bk if with_key else None, bs, be, n_keys=nk)
+    want_b, want_p = orc.join(bk, bs, be, pk, ps, pe, threads=4)
+    want = pair_set(want_b, want_p)
+    for chunks in ("1", "3", "7"):
+        os.environ["IVX_HOST_CHUNKS"] = chunks
+        try:
+            ob, op = ctx.overlap_fill(ix, pk if with_key else None, ps, pe, cap=len(want_b) + 5)
+            assert len(ob) == len(want_b) and np.array_equal(pair_set(ob, op), want), chunks
+            ob, op = ctx.overlap_fill(ix, pk if with_key else None, ps, pe, cap=len(want_b))          # exactly enough
+            assert np.array_equal(pair_set(ob, op), want), chunks
+            with pytest.raises(pyivx.IvxError) as ei:
+                ctx.overlap_fill(ix, pk if with_key else None, ps, pe, cap=len(want_b) // 2)
+            assert ei.value.status == pyivx.ERR_CAPACITY and f"need {len(want_b)} pairs" in str(ei.value), chunks
+            # a count call's plan still serves the fill that follows it (no second upload)
+            total = ctx.overlap_count(ix, pk if with_key else None, ps, pe)
+            ob, op = ctx.overlap_fill(ix, pk if with_key else None, ps, pe, cap=total)
+            assert total == len(want_b) and np.array_equal(pair_set(ob, op), want), chunks
+        finally:
+            del os.environ["IVX_HOST_CHUNKS"]
+    ix.free()
+
+
 def test_capacity_error(ctx):
     bk, bs, be = synth(5000, 3, span=100_000)
     ix = ctx.build(pyivx.KIND_OVERLAP, bk, bs, be, n_keys=1)
