@@ -431,6 +431,59 @@ __global__ void k_add_base(u32 *__restrict__ p, u64 n, u32 base)
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) p[i] += base;
 }
 
+// device -> host copies on a thread and stream of their own, each after an event of the compute stream
+struct HostCopier {
+    struct Job { void *dst; const void *src; size_t bytes; hipEvent_t ev; };
+    std::mutex mu; std::condition_variable cv, cv_done; std::deque<Job> jobs; bool closed = false; hipError_t herr = hipSuccess;
+    u64 done = 0;                                           // copies finished so far (in the order they were pushed)
+    hipStream_t cs = nullptr; std::thread th; std::vector<hipEvent_t> evs; bool started = false;
+    hipError_t start(int device)
+    {
+        const hipError_t e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+        if (e != hipSuccess) return e;
+        started = true;
+        th = std::thread([this, device]() {
+            (void)hipSetDevice(device);
+            for (;;) {
+                Job j;
+                { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return closed || !jobs.empty(); }); if (jobs.empty()) return; j = jobs.front(); jobs.pop_front(); }
+                hipError_t e2 = j.ev ? hipStreamWaitEvent(cs, j.ev, 0) : hipSuccess;
+                if (e2 == hipSuccess && j.bytes) e2 = hipMemcpyAsync(j.dst, j.src, j.bytes, hipMemcpyDeviceToHost, cs);
+                if (e2 == hipSuccess) e2 = hipStreamSynchronize(cs);
+                { std::lock_guard<std::mutex> lk(mu); if (e2 != hipSuccess) herr = e2; done++; }
+                cv_done.notify_all();
+            }
+        });
+        return hipSuccess;
+    }
+    // an event recorded on `st` now; the copies pushed with it run after everything enqueued on `st` so far
+    hipError_t mark(hipStream_t st, hipEvent_t *ev)
+    {
+        hipError_t e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
+        if (e != hipSuccess) return e;
+        evs.push_back(*ev);
+        return hipEventRecord(*ev, st);
+    }
+    void push(void *dst, const void *src, size_t bytes, hipEvent_t ev)
+    {
+        { std::lock_guard<std::mutex> lk(mu); jobs.push_back(Job{dst, src, bytes, ev}); }
+        cv.notify_all();
+    }
+    void wait_until(u64 k) { std::unique_lock<std::mutex> lk(mu); cv_done.wait(lk, [&] { return done >= k; }); }   // the first k copies are done
+    hipError_t finish()                                     // waits for every copy
+    {
+        if (!started) return hipSuccess;
+        { std::lock_guard<std::mutex> lk(mu); closed = true; }
+        cv.notify_all();
+        th.join();
+        for (hipEvent_t e : evs) (void)hipEventDestroy(e);
+        (void)hipStreamDestroy(cs);
+        started = false;
+        return herr;
+    }
+    ~HostCopier() { (void)finish(); }
+};
+
 static ivx_status overlap_fill_host_chunked(ivx_ctx *ctx, const ivx_index *ix, const u32 *key, const i32 *start, const i32 *end, u64 n,
                                             u32 *bidx, u32 *pidx, u64 cap, u64 *written, u32 nchunk)
 {
@@ -447,31 +500,8 @@ static ivx_status overlap_fill_host_chunked(ivx_ctx *ctx, const ivx_index *ix, c
         IVX_TRY(ctx->get_scratch(b ? WS_IN2_START : WS_IN_START, rows * sizeof(i32), (void **)&ds[b]));
         IVX_TRY(ctx->get_scratch(b ? WS_IN2_END : WS_IN_END, rows * sizeof(i32), (void **)&de[b]));
     }
-    hipStream_t cs;
-    IVX_HIP(ctx, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-    struct Job { u64 at, cnt; hipEvent_t ev; };
-    std::mutex mu; std::condition_variable cv; std::deque<Job> jobs; bool closed = false; hipError_t herr = hipSuccess;
-    const int device = ctx->device;
-    std::thread helper([&]() {
-        (void)hipSetDevice(device);
-        for (;;) {
-            Job j;
-            { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return closed || !jobs.empty(); }); if (jobs.empty()) return; j = jobs.front(); jobs.pop_front(); }
-            hipError_t e = hipStreamWaitEvent(cs, j.ev, 0);
-            if (e == hipSuccess && j.cnt) e = hipMemcpyAsync(bidx + j.at, d_b + j.at, j.cnt * sizeof(u32), hipMemcpyDeviceToHost, cs);
-            if (e == hipSuccess && j.cnt) e = hipMemcpyAsync(pidx + j.at, d_p + j.at, j.cnt * sizeof(u32), hipMemcpyDeviceToHost, cs);
-            if (e == hipSuccess) e = hipStreamSynchronize(cs);
-            if (e != hipSuccess) { std::lock_guard<std::mutex> lk(mu); herr = e; }
-        }
-    });
-    std::vector<hipEvent_t> evs;
-    auto finish = [&]() {
-        { std::lock_guard<std::mutex> lk(mu); closed = true; }
-        cv.notify_all();
-        helper.join();
-        for (hipEvent_t e : evs) (void)hipEventDestroy(e);
-        (void)hipStreamDestroy(cs);
-    };
+    HostCopier hc;
+    IVX_HIP(ctx, hc.start(ctx->device));
     const ivx_metrics m0 = ctx->metrics;                                        // (the chunks are one batch to the caller)
     u64 cum = 0, need = 0;
     ivx_status rc = IVX_OK;
@@ -493,11 +523,10 @@ static ivx_status overlap_fill_host_chunked(ivx_ctx *ctx, const ivx_index *ix, c
             if (rc != IVX_OK) break;
             if (tot && c0) hipLaunchKernelGGL(k_add_base, dim3(1024), dim3(256), 0, st, d_p + cum, tot, (u32)c0);
             hipEvent_t ev;
-            e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-            if (e == hipSuccess) { evs.push_back(ev); e = hipEventRecord(ev, st); }
+            e = hc.mark(st, &ev);
             if (e != hipSuccess) { rc = ctx->fail_hip("hipEventRecord(chunk)", e); break; }
-            { std::lock_guard<std::mutex> lk(mu); jobs.push_back(Job{cum, tot, ev}); }
-            cv.notify_all();
+            hc.push(bidx + cum, d_b + cum, tot * sizeof(u32), ev);
+            hc.push(pidx + cum, d_p + cum, tot * sizeof(u32), ev);
             cum += tot;
         } else {
             rc = overlap_common(ctx, ix, IVX_MEM_DEVICE, JP_COUNT, dk[b], ds[b], de[b], nc, nullptr, nullptr, nullptr, nullptr, 0, &tot);
@@ -506,7 +535,7 @@ static ivx_status overlap_fill_host_chunked(ivx_ctx *ctx, const ivx_index *ix, c
     }
     // (the staged columns of the last chunks must not be reused before their kernels are done: the stream is idle here)
     const hipError_t es = hipStreamSynchronize(st);
-    finish();
+    const hipError_t herr = hc.finish();
     ctx->join_plan.valid = false;                                               // (the count calls above may have left one: it refers to a chunk)
     ctx->metrics.input_batches = m0.input_batches + 1;
     ctx->metrics.output_batches = m0.output_batches + ((rc == IVX_OK && !over && cum) ? 1 : 0);
@@ -578,6 +607,54 @@ static ivx_status per_row_i64(ivx_ctx *ctx, const ivx_index *ix, int kind, int m
     if (n && !out) return ctx->fail(IVX_ERR_INVALID, "null output column");
     CallMetrics cm(ctx, false, n);
     cm.out(n);
+    // host-resident columns of a big batch: in chunks, the values of chunk c go back (helper thread, own stream) while the
+    // columns of chunk c + 1 come in -- see overlap_fill_host_chunked
+    const char *ce = getenv("IVX_HOST_CHUNKS");
+    const u32 nchunk = ce ? (u32)atoi(ce) : (n >= (16ull << 20) ? 4u : 1u);
+    if (mem == IVX_MEM_HOST && nchunk > 1 && n >= (u64)nchunk * 65536) {
+        hipStream_t st = ctx->stream;
+        const u64 rows = ((n + nchunk - 1) / nchunk + 65535) & ~65535ull;
+        u32 *dkk[2] = {nullptr, nullptr}; i32 *dss[2], *dee[2]; i64 *doo[2];
+        for (int b = 0; b < 2; b++) {
+            if (key) IVX_TRY(ctx->get_scratch(b ? WS_IN2_KEY : WS_IN_KEY, rows * sizeof(u32), (void **)&dkk[b]));
+            IVX_TRY(ctx->get_scratch(b ? WS_IN2_START : WS_IN_START, rows * sizeof(i32), (void **)&dss[b]));
+            IVX_TRY(ctx->get_scratch(b ? WS_IN2_END : WS_IN_END, rows * sizeof(i32), (void **)&dee[b]));
+            IVX_TRY(ctx->get_scratch(b ? WS_OUT_B : WS_OUT_A, rows * sizeof(i64), (void **)&doo[b]));
+        }
+        HostCopier hc;
+        IVX_HIP(ctx, hc.start(ctx->device));
+        ivx_status rc = IVX_OK;
+        for (u32 c = 0; c < nchunk && rc == IVX_OK; c++) {
+            const u64 c0 = (u64)c * rows, c1 = c0 + rows < n ? c0 + rows : n;
+            if (c0 >= c1) break;
+            const int b = (int)(c & 1u);
+            const u64 nc = c1 - c0;
+            // (input set b was last read by the kernels of chunk c - 2, earlier on this stream; output set b by the COPY of
+            //  chunk c - 2, on the helper's stream: that one is awaited before this chunk's kernels are enqueued)
+            hipError_t e = hipSuccess;
+            if (key) e = hipMemcpyAsync(dkk[b], key + c0, nc * sizeof(u32), hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(dss[b], start + c0, nc * sizeof(i32), hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(dee[b], end + c0, nc * sizeof(i32), hipMemcpyHostToDevice, st);
+            if (e != hipSuccess) { rc = ctx->fail_hip("hipMemcpyAsync(chunk)", e); break; }
+            if (c >= 2) hc.wait_until(c - 1);
+            {
+                KernelTimer t(ctx);
+                rc = kind == IVX_KIND_COUNT ? ivx_count_probe(ctx, ix, dkk[b], dss[b], dee[b], nc, strict, doo[b])
+                                            : ivx_coverage_probe(ctx, ix, dkk[b], dss[b], dee[b], nc, strict, doo[b]);
+            }
+            if (rc != IVX_OK) break;
+            hipEvent_t ev;
+            e = hc.mark(st, &ev);
+            if (e != hipSuccess) { rc = ctx->fail_hip("hipEventRecord(chunk)", e); break; }
+            hc.push(out + c0, doo[b], nc * sizeof(i64), ev);
+        }
+        const hipError_t es = hipStreamSynchronize(st);
+        const hipError_t herr = hc.finish();
+        if (rc != IVX_OK) return rc;
+        if (es != hipSuccess) return ctx->fail_hip("hipStreamSynchronize", es);
+        if (herr != hipSuccess) return ctx->fail_hip("hipMemcpyAsync(values)", herr);
+        return IVX_OK;
+    }
     const u32 *dk; const i32 *ds, *de; i64 *dout;
     IVX_TRY(stage_in(ctx, mem, WS_IN_KEY, key, n, &dk));
     IVX_TRY(stage_in(ctx, mem, WS_IN_START, start, n, &ds));

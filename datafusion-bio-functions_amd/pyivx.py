@@ -240,9 +240,11 @@ class Ctx:
         return out
 
     # ---- a4 / a5 ----
-    def _per_row_i64(self, fn, ix, key, start, end, strict):
+    def _per_row_i64(self, fn, ix, key, start, end, strict, out=None):
         key, s, e, n, mem = _cols(key, start, end, np.int32)
-        if mem == MEM_DEVICE:
+        if out is not None:
+            assert len(out) >= n                                    # (a caller's own int64 buffer, e.g. one it has touched before)
+        elif mem == MEM_DEVICE:
             import torch
             out = torch.empty(n, dtype=torch.int64, device=s.device)
         else:
@@ -250,11 +252,11 @@ class Ctx:
         self._chk(fn(self.h, ix.h, C.c_int(mem), _ptr(key), _ptr(s), _ptr(e), C.c_uint64(n), C.c_int(int(strict)), _ptr(out)))
         return out
 
-    def count_overlaps(self, ix, key, start, end, strict=False):
-        return self._per_row_i64(lib().ivx_probe_count, ix, key, start, end, strict)
+    def count_overlaps(self, ix, key, start, end, strict=False, out=None):
+        return self._per_row_i64(lib().ivx_probe_count, ix, key, start, end, strict, out)
 
-    def coverage(self, ix, key, start, end, strict=False):
-        return self._per_row_i64(lib().ivx_probe_coverage, ix, key, start, end, strict)
+    def coverage(self, ix, key, start, end, strict=False, out=None):
+        return self._per_row_i64(lib().ivx_probe_coverage, ix, key, start, end, strict, out)
 
     # ---- a6 ----
     def nearest(self, ix, key, start, end, k=1, overlap=True, strict=False, distance=True):

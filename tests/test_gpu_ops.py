@@ -165,6 +165,27 @@ def test_count_random(ctx, seed):
             assert (ctx.count_overlaps(ix, pk, ps, pe, strict=strict) == want).all(), (strict, path)
 
 
+@pytest.mark.parametrize("chunks", ["2", "5"])
+def test_count_coverage_host_columns_in_chunks(ctx, chunks):
+    # host-resident columns of a big batch go through the device in chunks (values of chunk c are copied back while chunk
+    # c + 1 uploads): same columns as the oracle, with and without a key column
+    bk, bs, be = synth(50_000, 301, nkeys=6, mean_len=700, span=4_000_000)
+    pk, ps, pe = synth(700_000, 302, nkeys=7, mean_len=150, span=4_000_000)
+    os.environ["IVX_HOST_CHUNKS"] = chunks
+    try:
+        for kind, fn, ofn in ((pyivx.KIND_COUNT, "count_overlaps", orc.count_overlaps), (pyivx.KIND_COVERAGE, "coverage", orc.coverage)):
+            ix = ctx.build(kind, bk, bs, be, n_keys=7)
+            for strict in (False, True):
+                assert (getattr(ctx, fn)(ix, pk, ps, pe, strict=strict) == ofn(bk, bs, be, pk, ps, pe, strict=strict)).all(), (fn, strict)
+            ix.free()
+            k0 = np.zeros(len(bk), np.uint32)
+            ix = ctx.build(kind, None, bs, be, n_keys=1)
+            assert (getattr(ctx, fn)(ix, None, ps, pe) == ofn(k0, bs, be, np.zeros(len(pk), np.uint32), ps, pe)).all(), fn
+            ix.free()
+    finally:
+        del os.environ["IVX_HOST_CHUNKS"]
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_coverage_random(ctx, seed):
     nk = [1, 5, 24][seed % 3]
