@@ -464,59 +464,124 @@ struct SubPlan { u32 h_lo, h_hi; i64 tail_from; u32 has_tail; };
 // other three sit next to them (the row's end is a few rights after its start), so they gallop from there.
 // [ha, hb]: bounds of the first search (the heads at or below the row's start): the caller's workgroup holds consecutive
 // rows of the sorted left side, so the answers of its first and last row bracket everybody's (0 .. nh if unknown)
-__device__ __forceinline__ SubPlan plan_row(u32 k, i64 ls, i64 le, int strict,
-                                            const u32 *hk, const i64 *hrs, const u32 *hj, u32 nh,
-                                            const u32 *rk, const i64 *rs, const SegMax64 *sm, u32 nr, u32 ha, u32 hb)
+// the arrays plan_row searches, read from global memory ...
+struct SubGlobal {
+    const u32 *hk; const i64 *hrs; const u32 *hj; const u32 *rk; const i64 *rs; const SegMax64 *sm;
+    __device__ __forceinline__ u32 Hk(u32 i) const { return hk[i]; }
+    __device__ __forceinline__ i64 Hrs(u32 i) const { return hrs[i]; }
+    __device__ __forceinline__ u32 Hj(u32 i) const { return hj[i]; }
+    __device__ __forceinline__ u32 Rk(u32 i) const { return rk[i]; }
+    __device__ __forceinline__ i64 Rs(u32 i) const { return rs[i]; }
+    __device__ __forceinline__ i64 Pm(u32 i) const { return sm[i].v; }
+};
+// ... or from the workgroup's LDS copy of the stretch its rows need: heads [h0, h1), rights [r0, r1).  An index outside
+// raises `esc` and reads as 0 -- the caller then plans that row again from global memory.  (Every read here is an LDS
+// read; an accessor that falls back to global memory per access compiles to flat loads with full waits, 36 -> 46 ms.)
+struct SubLds {
+    const u32 *hk; const i64 *hrs; const u32 *hj; const u32 *rk; const i64 *rs; const i64 *pm;
+    u32 h0, hn, r0, rn;
+    mutable bool esc;
+    __device__ __forceinline__ u32 hi_(u32 i) const { const u32 x = i - h0; if (x >= hn) { esc = true; return 0u; } return x; }
+    __device__ __forceinline__ u32 ri_(u32 i) const { const u32 x = i - r0; if (x >= rn) { esc = true; return 0u; } return x; }
+    __device__ __forceinline__ u32 Hk(u32 i) const { return hk[hi_(i)]; }
+    __device__ __forceinline__ i64 Hrs(u32 i) const { return hrs[hi_(i)]; }
+    __device__ __forceinline__ u32 Hj(u32 i) const { return hj[hi_(i)]; }
+    __device__ __forceinline__ u32 Rk(u32 i) const { return rk[ri_(i)]; }
+    __device__ __forceinline__ i64 Rs(u32 i) const { return rs[ri_(i)]; }
+    __device__ __forceinline__ i64 Pm(u32 i) const { return pm[ri_(i)]; }
+};
+
+template <class A>
+__device__ __forceinline__ SubPlan plan_row(u32 k, i64 ls, i64 le, int strict, const A &a, u32 nh, u32 nr, u32 ha, u32 hb)
 {
     SubPlan p;
     const bool incl = !strict;
     // heads with rs <= ls never emit
-    const u32 h_ls = bisect(ha, hb, [&](u32 i) { const u32 mk = hk[i]; if (mk != k) return mk < k; return hrs[i] <= ls; });
+    const u32 h_ls = bisect(ha, hb, [&](u32 i) { const u32 mk = a.Hk(i); if (mk != k) return mk < k; return a.Hrs(i) <= ls; });
     // right_cursor (subtract.rs:401-412): first right whose running max end reaches ls.  Everything before the
     // last head at or below ls ends below that head's start, so the search starts there; it normally ends
     // before the next head (checked, not assumed: rights with end < start break it)
     const bool pm_le = strict != 0;
-    auto pm_before = [&](u32 i) { const u32 mk = rk[i]; if (mk != k) return mk < k; const i64 mv = sm[i].v; return pm_le ? (mv <= ls) : (mv < ls); };
-    const u32 rc_lo = h_ls > 0 ? hj[h_ls - 1] : 0u;
-    u32 rc_hi = h_ls < nh ? hj[h_ls] : nr;
+    auto pm_before = [&](u32 i) { const u32 mk = a.Rk(i); if (mk != k) return mk < k; const i64 mv = a.Pm(i); return pm_le ? (mv <= ls) : (mv < ls); };
+    const u32 rc_lo = h_ls > 0 ? a.Hj(h_ls - 1) : 0u;
+    u32 rc_hi = h_ls < nh ? a.Hj(h_ls) : nr;
     if (rc_hi < nr && pm_before(rc_hi)) rc_hi = nr;
     const u32 rc = bisect(rc_lo, rc_hi, pm_before);
     // heads behind the cursor are skipped: first head at or after it, at or just before h_ls
-    const u32 hc = rank_near_down(h_ls, nh, [&](u32 i) { return hj[i] < rc; });
+    const u32 hc = rank_near_down(h_ls, nh, [&](u32 i) { return a.Hj(i) < rc; });
     p.h_lo = hc > h_ls ? hc : h_ls;
     // heads with rs <= le (strict: rs < le)
-    p.h_hi = rank_near_up(h_ls, nh, [&](u32 i) { const u32 mk = hk[i]; if (mk != k) return mk < k; const i64 mv = hrs[i]; return incl ? (mv <= le) : (mv < le); });
+    p.h_hi = rank_near_up(h_ls, nh, [&](u32 i) { const u32 mk = a.Hk(i); if (mk != k) return mk < k; const i64 mv = a.Hrs(i); return incl ? (mv <= le) : (mv < le); });
     if (p.h_hi < p.h_lo) p.h_hi = p.h_lo;
     // rights visited by the walk: rs <= le (strict: <); they begin at the cursor
-    const u32 jhi = rank_near_up(rc, nr, [&](u32 i) { const u32 mk = rk[i]; if (mk != k) return mk < k; const i64 mv = rs[i]; return incl ? (mv <= le) : (mv < le); });
+    const u32 jhi = rank_near_up(rc, nr, [&](u32 i) { const u32 mk = a.Rk(i); if (mk != k) return mk < k; const i64 mv = a.Rs(i); return incl ? (mv <= le) : (mv < le); });
     i64 cursor = ls;
-    if (jhi > 0 && rk[jhi - 1] == k) { const i64 pm = sm[jhi - 1].v; if (pm > cursor) cursor = pm; }
+    if (jhi > 0 && a.Rk(jhi - 1) == k) { const i64 pm = a.Pm(jhi - 1); if (pm > cursor) cursor = pm; }
     p.tail_from = cursor;
     p.has_tail = cursor < le ? 1u : 0u;                                 // subtract.rs:435
     return p;
 }
 
-// (Staging the block's stretch of heads and rights in LDS, with a per-access fall-back to global memory for indices
-//  outside the window, was measured SLOWER: 36.4 -> 45.8 ms -- an accessor that may read LDS or global memory compiles
-//  to flat loads with full waits.)
+// The workgroup's rows are consecutive rows of the sorted left side: the heads at or below its first and last row's start
+// bracket everybody's first search, and the heads / rights all its searches touch are a short stretch around that bracket
+// -- staged in LDS (SUB_HW heads, SUB_RW rights), so that the ~70 dependent reads of a row's five partition points are LDS
+// reads (11.7 -> ... ms for 200 M rows); a row whose searches leave the stretch (a long row, rights with end < start) is
+// planned again from global memory, and a workgroup whose stretch does not fit plans all its rows there.
+constexpr u32 SUB_HW = 512, SUB_RW = 1024, SUB_MARGIN = 64;
+// brk[b] = heads at or below the start of the first left row of workgroup b (brk[#workgroups]: of the last row): one thread
+// per boundary, all searches in flight together.  (Done by two threads at the head of every k_sub_count workgroup, the two
+// full-length searches -- ~24 dependent reads -- held the other 254 threads up: 9 of the kernel's 11.7 ms.)
+__global__ __launch_bounds__(ST) void k_sub_brackets(const u32 *__restrict__ lk, const i64 *__restrict__ lsv, u64 nl, const u32 *hk, const i64 *hrs, u32 nh,
+                                                     u32 nblk, u32 *__restrict__ brk)
+{
+    const u32 b = blockIdx.x * ST + threadIdx.x;
+    if (b > nblk) return;
+    const u64 r = b < nblk ? (u64)b * ST : nl - 1;
+    brk[b] = r < nl ? lex_rank(hk, hrs, nh, lk[r], lsv[r], true) : nh;
+}
+
 __global__ __launch_bounds__(ST) void k_sub_count(const u32 *__restrict__ lk, const i64 *__restrict__ lsv, const i64 *__restrict__ lev, u64 nl,
                                                   int strict, const u32 *hk, const i64 *hrs, const u32 *hj, u32 nh,
                                                   const u32 *rk, const i64 *rs, const SegMax64 *sm, u32 nr, u64 *cnt,
-                                                  u32 *__restrict__ plan_hlo, i64 *__restrict__ plan_tail)
+                                                  u32 *__restrict__ plan_hlo, i64 *__restrict__ plan_tail, const u32 *__restrict__ brk)
 {
-    // the full-length search for the heads at or below a row's start is done for the block's first and last row only: the
-    // left side is sorted, so their answers bracket every other row's, a few hundred heads apart instead of all nh
-    __shared__ u32 s_h[2];
+    __shared__ u32 s_h[2], s_win[4];
+    __shared__ u32 l_hk[SUB_HW], l_hj[SUB_HW], l_rk[SUB_RW];
+    __shared__ i64 l_hrs[SUB_HW], l_rs[SUB_RW], l_pm[SUB_RW];
     const u64 i0 = (u64)blockIdx.x * ST;
-    if (threadIdx.x < 2 && i0 < nl) {
-        const u64 r = threadIdx.x == 0 ? i0 : (i0 + ST <= nl ? i0 + ST - 1 : nl - 1);
-        s_h[threadIdx.x] = lex_rank(hk, hrs, nh, lk[r], lsv[r], true);
+    // the answers of the workgroup's first row and of the next workgroup's first row (the last row's, for the last
+    // workgroup) bracket everybody's first search: the left side is sorted
+    if (threadIdx.x < 2 && i0 < nl) s_h[threadIdx.x] = brk[blockIdx.x + threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0 && i0 < nl) {
+        const u32 h0 = s_h[0] > SUB_MARGIN + 1 ? s_h[0] - SUB_MARGIN - 1 : 0u;
+        const u32 h1 = nh - s_h[1] > SUB_MARGIN ? s_h[1] + SUB_MARGIN : nh;
+        const u32 r0 = h0 < nh ? hj[h0] : nr;
+        u32 r1 = h1 < nh ? hj[h1] : nr;
+        r1 = nr - r1 > SUB_MARGIN ? r1 + SUB_MARGIN : nr;
+        s_win[0] = h0; s_win[1] = h1 - h0; s_win[2] = r0 < r1 ? r0 : r1; s_win[3] = r1 > r0 ? r1 - r0 : 0u;
     }
     __syncthreads();
+    const bool lds = i0 < nl && s_win[1] <= SUB_HW && s_win[3] <= SUB_RW;          // (the same for the whole workgroup)
+    if (lds) {
+        const u32 h0 = s_win[0], hn = s_win[1], r0 = s_win[2], rn = s_win[3];
+        for (u32 x = threadIdx.x; x < hn; x += ST) { l_hk[x] = hk[h0 + x]; l_hrs[x] = hrs[h0 + x]; l_hj[x] = hj[h0 + x]; }
+        for (u32 x = threadIdx.x; x < rn; x += ST) { l_rk[x] = rk[r0 + x]; l_rs[x] = rs[r0 + x]; l_pm[x] = sm[r0 + x].v; }
+        __syncthreads();
+    }
     const u64 i = i0 + threadIdx.x;
     if (i > nl) return;
     if (i == nl) { cnt[i] = 0; return; }
-    const SubPlan p = plan_row(lk[i], lsv[i], lev[i], strict, hk, hrs, hj, nh, rk, rs, sm, nr, s_h[0], s_h[1]);
+    const u32 k = lk[i]; const i64 ls = lsv[i], le = lev[i];
+    const SubGlobal g{hk, hrs, hj, rk, rs, sm};
+    SubPlan p;
+    bool redo = !lds;
+    if (lds) {
+        SubLds a{l_hk, l_hrs, l_hj, l_rk, l_rs, l_pm, s_win[0], s_win[1], s_win[2], s_win[3], false};
+        p = plan_row(k, ls, le, strict, a, nh, nr, s_h[0], s_h[1]);
+        redo = a.esc;
+    }
+    if (redo) p = plan_row(k, ls, le, strict, g, nh, nr, s_h[0], s_h[1]);
     cnt[i] = (u64)(p.h_hi - p.h_lo) + p.has_tail;
     // the row's plan stays for the fill pass (12 bytes per row instead of the five searches again): its first head and
     // where its tail fragment starts; the number of heads follows from the scanned counts, has_tail from tail < end
@@ -807,9 +872,13 @@ ivx_status ivx_subtract_device(ivx_ctx *ctx, const u32 *lkey, const i64 *ls, con
     IVX_TRY(ctx->get_scratch(WS_RA2, (nl + 1) * sizeof(u64), (void **)&cnt));
     IVX_TRY(ctx->get_scratch(WS_RB1, nl * sizeof(u32), (void **)&plan_hlo));
     IVX_TRY(ctx->get_scratch(WS_RB2, nl * sizeof(i64), (void **)&plan_tail));
-    hipLaunchKernelGGL(k_sub_count, dim3(grid1(nl + 1)), dim3(ST), 0, st, (const u32 *)lk, (const i64 *)lsv, (const i64 *)lev, nl, strict,
+    const u32 nblk_c = grid1(nl + 1);
+    u32 *brk;
+    IVX_TRY(ctx->get_scratch(WS_GRID0, ((size_t)nblk_c + 2) * sizeof(u32), (void **)&brk));
+    hipLaunchKernelGGL(k_sub_brackets, dim3(grid1((u64)nblk_c + 1)), dim3(ST), 0, st, (const u32 *)lk, (const i64 *)lsv, nl, (const u32 *)hk, (const i64 *)hrs, (u32)nh, nblk_c, brk);
+    hipLaunchKernelGGL(k_sub_count, dim3(nblk_c), dim3(ST), 0, st, (const u32 *)lk, (const i64 *)lsv, (const i64 *)lev, nl, strict,
                        (const u32 *)hk, (const i64 *)hrs, (const u32 *)hj, (u32)nh, (const u32 *)rk, (const i64 *)rsv, (const SegMax64 *)sm, (u32)nr, cnt,
-                       plan_hlo, plan_tail);
+                       plan_hlo, plan_tail, (const u32 *)brk);
     IVX_TRY(ivx_scan_exclusive_u64(ctx, cnt, nl + 1));
     IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 5, cnt + nl, sizeof(u64), hipMemcpyDeviceToHost, st));
     IVX_HIP(ctx, hipStreamSynchronize(st));
