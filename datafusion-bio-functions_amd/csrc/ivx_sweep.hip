@@ -527,7 +527,7 @@ __device__ __forceinline__ SubPlan plan_row(u32 k, i64 ls, i64 le, int strict, c
 // -- staged in LDS (SUB_HW heads, SUB_RW rights), so that the ~70 dependent reads of a row's five partition points are LDS
 // reads (11.7 -> ... ms for 200 M rows); a row whose searches leave the stretch (a long row, rights with end < start) is
 // planned again from global memory, and a workgroup whose stretch does not fit plans all its rows there.
-constexpr u32 SUB_HW = 512, SUB_RW = 1024, SUB_MARGIN = 64;
+constexpr u32 SUB_HW = 256, SUB_RW = 640, SUB_MARGIN = 48;      // (17 KB of LDS: eight workgroups per CU)
 // brk[b] = heads at or below the start of the first left row of workgroup b (brk[#workgroups]: of the last row): one thread
 // per boundary, all searches in flight together.  (Done by two threads at the head of every k_sub_count workgroup, the two
 // full-length searches -- ~24 dependent reads -- held the other 254 threads up: 9 of the kernel's 11.7 ms.)
