@@ -200,6 +200,18 @@ __global__ __launch_bounds__(ST) void k_unpack1(const u64 *__restrict__ w0, cons
     // loads per row in a run held every wavefront up)
     __shared__ u64 s_w[FIX ? ST + 2 * FIX_MAXRUN : 1];
     if (p.lin) for (u32 k = threadIdx.x; k <= p.nkeys; k += ST) s_base[k] = p.base[k];
+    // slot x of s_w holds row t0 - FIX_MAXRUN + x; a thread fetches slots x = tid and (the first 2 * FIX_MAXRUN threads)
+    // x = ST + tid -- for the NEXT tile while the current one is worked on (registers), so that a tile does not start with
+    // a memory round trip
+    static_assert(2 * FIX_MAXRUN <= ST, "halo slots are fetched by the first threads");
+    u64 na = 0, nb = 0;
+    auto fetch = [&](u64 t0) {
+        if (!FIX || t0 >= n) return;
+        const u64 g = t0 + threadIdx.x;
+        na = (g >= FIX_MAXRUN && g - FIX_MAXRUN < n) ? w0[g - FIX_MAXRUN] : 0;
+        if (threadIdx.x < 2 * FIX_MAXRUN) { const u64 g2 = g + ST; nb = (g2 - FIX_MAXRUN < n) ? w0[g2 - FIX_MAXRUN] : 0; }
+    };
+    fetch((u64)blockIdx.x * UNPACK_TILES * ST);
     // (UNPACK_TILES tiles per workgroup: the key table is staged once for all of them)
     for (u32 tile = 0; tile < UNPACK_TILES; tile++) {
         const u64 t0 = ((u64)blockIdx.x * UNPACK_TILES + tile) * ST;
@@ -208,12 +220,10 @@ __global__ __launch_bounds__(ST) void k_unpack1(const u64 *__restrict__ w0, cons
         u64 w = 0;
         if (FIX) {
             __syncthreads();                                            // (the previous tile's readers are done; first tile: s_base is written)
-            // slot x of s_w holds row t0 - FIX_MAXRUN + x
-            for (u32 x = threadIdx.x; x < ST + 2 * FIX_MAXRUN; x += ST) {
-                const u64 g = t0 + x;
-                s_w[FIX ? x : 0] = (g >= FIX_MAXRUN && g - FIX_MAXRUN < n) ? w0[g - FIX_MAXRUN] : 0;
-            }
+            s_w[FIX ? threadIdx.x : 0] = na;
+            if (threadIdx.x < 2 * FIX_MAXRUN) s_w[FIX ? ST + threadIdx.x : 0] = nb;
             __syncthreads();
+            if (tile + 1 < UNPACK_TILES) fetch(t0 + ST);
             w = s_w[FIX ? threadIdx.x + FIX_MAXRUN : 0];
         } else {
             if (tile == 0) __syncthreads();
