@@ -25,7 +25,8 @@ constexpr int RS_T = 1024;
 constexpr int RS_WAVES = RS_T / IVX_WAVE;       // 16
 constexpr int RS_HT = 256;                      // histogram kernel: threads (= digits)
 constexpr int RS_HWAVES = RS_HT / IVX_WAVE;
-constexpr u64 RS_CHUNK = 65536;                 // records per workgroup (histogram and scatter agree on it)
+constexpr u64 RS_CHUNK = 65536;                 // records per workgroup of a big sort (histogram and scatter agree on it; sort_impl
+                                                // takes fewer for inputs that would not fill the chip: whole tiles, at least one)
 template <int NW> struct Tile {
     static constexpr int I = NW == 3 ? 4 : NW == 1 ? 8 : 8;   // records per thread per tile: 8192-record tiles, 4096 for 24-byte records, 16384 for 8-byte ones (LDS)
     static constexpr int N = RS_T * I;
@@ -76,13 +77,13 @@ __global__ __launch_bounds__(RS_HT) void k_varbits(const u64 *__restrict__ w, u6
     }
 }
 
-__global__ __launch_bounds__(RS_HT) void k_hist(const u64 *__restrict__ w, u64 n, int shift, u32 nblk, u32 *__restrict__ hist)
+__global__ __launch_bounds__(RS_HT) void k_hist(const u64 *__restrict__ w, u64 n, int shift, u32 nblk, u32 *__restrict__ hist, u32 chunk)
 {
     __shared__ u32 cnt[RS_HWAVES][256];
     for (int i = threadIdx.x; i < RS_HWAVES * 256; i += RS_HT) (&cnt[0][0])[i] = 0;
     __syncthreads();
-    const u64 lo = (u64)blockIdx.x * RS_CHUNK;
-    const u64 hi = lo + RS_CHUNK < n ? lo + RS_CHUNK : n;
+    const u64 lo = (u64)blockIdx.x * chunk;
+    const u64 hi = lo + chunk < n ? lo + chunk : n;
     const u32 wv = threadIdx.x / IVX_WAVE;
     // four independent loads per thread in flight; per-wavefront LDS counters.  A digit shared by the whole
     // wavefront (sorted or clustered keys) is counted once by one lane, anything else by LDS atomics, which
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(RS_HT) void k_hist(const u64 *__restrict__ w, u64 n
 
 template <int NW, bool PAY>
 __global__ __launch_bounds__(RS_T) void k_scatter(CPtrs<NW> in, Ptrs<NW> out, u64 n, int word, int shift, u32 nblk,
-                                                 const u32 *__restrict__ offs)
+                                                 const u32 *__restrict__ offs, u32 chunk)
 {
     constexpr int RS_I = Tile<NW>::I, RS_TILE = Tile<NW>::N, RS_WTILE = Tile<NW>::WT;
     __shared__ u64 rec[NW][RS_TILE];
@@ -127,8 +128,8 @@ __global__ __launch_bounds__(RS_T) void k_scatter(CPtrs<NW> in, Ptrs<NW> out, u6
 
     const u32 tid = threadIdx.x, wv = tid / IVX_WAVE, ln = lane_id();
     if (tid < 256) gbase[tid] = offs[(u64)tid * nblk + blockIdx.x];
-    const u64 lo = (u64)blockIdx.x * RS_CHUNK;
-    const u64 hi = lo + RS_CHUNK < n ? lo + RS_CHUNK : n;
+    const u64 lo = (u64)blockIdx.x * chunk;
+    const u64 hi = lo + chunk < n ? lo + chunk : n;
 
     // 8-byte records: the next tile's records are loaded while this one goes through LDS (registers allow it)
     constexpr bool PREFETCH = NW == 1;
@@ -272,7 +273,16 @@ ivx_status sort_impl(ivx_ctx *ctx, u64 *const *a, u64 *const *b, u64 n, const iv
         IVX_HIP(ctx, hipStreamSynchronize(st));
     }
 
-    const u32 nblk = (u32)((n + RS_CHUNK - 1) / RS_CHUNK);
+    // records per workgroup: RS_CHUNK for big inputs; smaller ones are spread over ~4 workgroups per CU's worth of chunks
+    // (whole tiles), or a 1 M-row sort would run on 16 of the 256 CUs
+    u64 chunk = RS_CHUNK;
+    {
+        const u64 tile = (u64)Tile<NW>::N;
+        const u64 want = (n + 1023) / 1024;                            // ~1024 chunks
+        const u64 c = (want + tile - 1) / tile * tile;
+        if (c < chunk) chunk = c < tile ? tile : c;
+    }
+    const u32 nblk = (u32)((n + chunk - 1) / chunk);
     u32 *hist;
     IVX_TRY(ctx->get_scratch(WS_SORTHIST, (size_t)256 * nblk * sizeof(u32), (void **)&hist));
     int cur = 0;
@@ -287,9 +297,9 @@ ivx_status sort_impl(ivx_ctx *ctx, u64 *const *a, u64 *const *b, u64 n, const iv
             CPtrs<NW> ci; Ptrs<NW> po;
             for (int q = 0; q < NW; q++) { ci.w[q] = src[q]; po.w[q] = dst[q]; }
             ci.p = PAY ? pay[cur] : nullptr; po.p = PAY ? pay[cur ^ 1] : nullptr;
-            hipLaunchKernelGGL(k_hist, dim3(nblk), dim3(RS_HT), 0, st, (const u64 *)src[fields[f].word], n, sh, nblk, hist);
+            hipLaunchKernelGGL(k_hist, dim3(nblk), dim3(RS_HT), 0, st, (const u64 *)src[fields[f].word], n, sh, nblk, hist, (u32)chunk);
             IVX_TRY(ivx_scan_exclusive_u32(ctx, hist, (u64)256 * nblk));
-            hipLaunchKernelGGL((k_scatter<NW, PAY>), dim3(nblk), dim3(RS_T), 0, st, ci, po, n, fields[f].word, sh, nblk, (const u32 *)hist);
+            hipLaunchKernelGGL((k_scatter<NW, PAY>), dim3(nblk), dim3(RS_T), 0, st, ci, po, n, fields[f].word, sh, nblk, (const u32 *)hist, (u32)chunk);
             cur ^= 1;
         }
     }
