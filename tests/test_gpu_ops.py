@@ -339,6 +339,37 @@ def test_nearest_build_sort_forms(ctx, variant):
     ix.free()
 
 
+def test_rank_grids_over_clustered_coordinates(ctx):
+    # build rows in a few tight clusters far apart (and single rows in between): the sorted rank grids' cell tables have
+    # long stretches of empty cells, which a whole wavefront fills (k_grid_bounds); nearest, coverage and count_overlaps
+    # all read such grids
+    rng = np.random.default_rng(2024)
+    parts_k, parts_s = [], []
+    for k, centres in enumerate([[1_000, 120_000_000, 240_000_000], [50_000_000], [5, 9_999_999, 10_000_000, 200_000_000]]):
+        for c in centres:
+            m = int(rng.integers(1, 4000))
+            parts_k.append(np.full(m, k, np.uint32)); parts_s.append(c + rng.integers(0, 3000, m))
+    bk = np.concatenate(parts_k); bs = np.concatenate(parts_s).astype(np.int32)
+    be = (bs + rng.integers(0, 500, len(bs))).astype(np.int32)
+    o = rng.permutation(len(bk)); bk, bs, be = bk[o], bs[o], be[o]
+    npr = 60_000
+    pk = rng.integers(0, 4, npr).astype(np.uint32)
+    ps = np.where(rng.random(npr) < 0.5, rng.integers(0, 250_000_000, npr), rng.choice(bs, npr) + rng.integers(-5000, 5000, npr)).astype(np.int32)
+    pe = (ps + rng.integers(0, 2000, npr)).astype(np.int32)
+    ix = ctx.build(pyivx.KIND_NEAREST, bk, bs, be, n_keys=4)
+    for k, ovl in [(1, True), (1, False), (3, True)]:
+        gb, gp, gd = ctx.nearest(ix, pk, ps, pe, k=k, overlap=ovl)
+        wb, wp, wd = orc.nearest(bk, bs, be, pk, ps, pe, k=k, overlap=ovl)
+        assert len(gb) == len(wb) and (gb == wb).all() and (gp == wp).all() and (gd == wd).all(), (k, ovl)
+    ix.free()
+    ix = ctx.build(pyivx.KIND_COVERAGE, bk, bs, be, n_keys=4)
+    assert (ctx.coverage(ix, pk, ps, pe) == orc.coverage(bk, bs, be, pk, ps, pe)).all()
+    ix.free()
+    ix = ctx.build(pyivx.KIND_COUNT, bk, bs, be, n_keys=4)
+    assert (ctx.count_overlaps(ix, pk, ps, pe) == orc.count_overlaps(bk, bs, be, pk, ps, pe)).all()
+    ix.free()
+
+
 def test_nearest_empty_build_and_k0(ctx):
     e = np.empty(0, np.int32)
     ix = ctx.build(pyivx.KIND_NEAREST, np.empty(0, np.uint32), e, e, n_keys=3)
