@@ -518,7 +518,9 @@ static ivx_status overlap_fill_host_chunked(ivx_ctx *ctx, const ivx_index *ix, c
         if (e != hipSuccess) { rc = ctx->fail_hip("hipMemcpyAsync(chunk)", e); break; }
         u64 tot = 0;
         if (!over) {
+            ctx->fill_hint = (u64)((double)cap * (double)nc / (double)n) + 1;    // (the chunk's share of the pairs the caller expects: cap - cum would read as a dense join)
             rc = overlap_common(ctx, ix, IVX_MEM_DEVICE, JP_FILL, dk[b], ds[b], de[b], nc, nullptr, nullptr, d_b + cum, d_p + cum, cap - cum, &tot);
+            ctx->fill_hint = 0;
             if (rc == IVX_ERR_CAPACITY) { over = true; rc = IVX_OK; need = cum + tot; continue; }
             if (rc != IVX_OK) break;
             if (tot && c0) hipLaunchKernelGGL(k_add_base, dim3(1024), dim3(256), 0, st, d_p + cum, tot, (u32)c0);

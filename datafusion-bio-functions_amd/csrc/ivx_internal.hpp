@@ -75,6 +75,7 @@ struct ivx_ctx {
     ivx_join_plan join_plan;
     ivx_metrics metrics{};              // BuildProbeJoinMetrics, see ivx.h
     u64 mem_limit = 0;                  // device bytes of scratch + the index being built (0 = unlimited)
+    u64 fill_hint = 0;                  // pairs a fill call should expect instead of its cap (a chunk of a host-resident batch writes into the whole batch's buffers)
     u64 scratch_bytes = 0, building_bytes = 0;
 
     ivx_status fail(ivx_status st, const std::string &msg) { err = msg; return st; }

@@ -1860,7 +1860,7 @@ ivx_status probe_two_level(ivx_ctx *ctx, const JoinIndexView &jv, int mode, u32 
     }
     }
     unsigned long long *cur = (unsigned long long *)d_cursor;
-    const u64 hint = planned && pl.total < cap ? pl.total : cap;
+    const u64 hint = ctx->fill_hint ? ctx->fill_hint : (planned && pl.total < cap ? pl.total : cap);
     if (mode == JP_FILL && dense_fill_wanted(hint, n))
         return dense_fill(ctx, jv, nreg, (const void *)pse2, (const void *)prow2, 1u, s, e, (const u32 *)rfirst, 1u, (const u32 *)unsorted, n, ob, op, cap, d_cursor);
     if (mode == JP_FILL) {
@@ -1957,7 +1957,7 @@ ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nre
         }
         unsigned long long *cur = (unsigned long long *)d_cursor;
         // the rows the probe walks are the routed ones: the density hint is pairs per INPUT row, as the caller sized it
-        const u64 hint = planned && pl.total < cap ? pl.total : cap;
+        const u64 hint = ctx->fill_hint ? ctx->fill_hint : (planned && pl.total < cap ? pl.total : cap);
         if (mode == JP_FILL && dense_fill_wanted(hint, n))
             return dense_fill(ctx, jv, nreg, (const void *)pool_se, (const void *)pool_row, 1u, s, e, rfirst, 1u, nullptr, n, ob, op, cap, d_cursor, &pt, packed, rowbits);
         if (mode == JP_FILL) {
@@ -2014,7 +2014,7 @@ ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nre
     }
     unsigned long long *cur = (unsigned long long *)d_cursor;
     // how dense the matches are: from the caller's capacity, or -- planned -- from what the count call found
-    const u64 hint = planned && pl.total < cap ? pl.total : cap;
+    const u64 hint = ctx->fill_hint ? ctx->fill_hint : (planned && pl.total < cap ? pl.total : cap);
     if (mode == JP_FILL && dense_fill_wanted(hint, n)) {
         return dense_fill(ctx, jv, nreg, (const void *)pse, (const void *)prow, 1u, s, e, (const u32 *)hist, nblk, (const u32 *)unsorted, n, ob, op, cap, d_cursor);
     } else if (mode == JP_FILL) {   // single walk: pairs staged per wavefront, one output reservation per workgroup and round
