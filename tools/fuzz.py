@@ -49,10 +49,11 @@ for it in range(iters):
     else: os.environ.pop("IVX_DENSE", None)
     # round-2 knobs of the region path: two-pass partition, 12-byte routed rows, occupancy bitmap never / always / by the rule
     part, pack, filt = str(rng.choice(["", "", "two"])), str(rng.choice(["", "", "0"])), str(rng.choice(["", "force", "force", "0"]))
-    for name, val in (("IVX_PART", part), ("IVX_PACK", pack), ("IVX_FILTER", filt)):
+    chunks = str(rng.choice(["", "", "2", "3"]))                  # host-resident fill / count / coverage calls cut into chunks
+    for name, val in (("IVX_PART", part), ("IVX_PACK", pack), ("IVX_FILTER", filt), ("IVX_HOST_CHUNKS", chunks)):
         if val: os.environ[name] = val
         else: os.environ.pop(name, None)
-    tag = f"it={it} nk={nk} span={span} nb={nb} np={npr} bmean={bmean} sorted={srt} strict={strict} path={path} dense={dense!r} part={part!r} pack={pack!r} filter={filt!r}"
+    tag = f"it={it} nk={nk} span={span} nb={nb} np={npr} bmean={bmean} sorted={srt} strict={strict} path={path} dense={dense!r} part={part!r} pack={pack!r} filter={filt!r} chunks={chunks!r}"
     try:
         # ---- join: count, per-row, exists, fill
         ix = ctx.build(pyivx.KIND_OVERLAP, bk, bs, be, n_keys=nk)
