@@ -441,7 +441,7 @@ struct HostCopier {
     {
         const hipError_t e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
         if (e != hipSuccess) return e;
-        started = true;
+        try {
         th = std::thread([this, device]() {
             (void)hipSetDevice(device);
             for (;;) {
@@ -454,6 +454,8 @@ struct HostCopier {
                 cv_done.notify_all();
             }
         });
+        } catch (...) { (void)hipStreamDestroy(cs); cs = nullptr; return hipErrorOutOfMemory; }     // (no thread to be had: the caller reports it)
+        started = true;
         return hipSuccess;
     }
     // an event recorded on `st` now; the copies pushed with it run after everything enqueued on `st` so far
