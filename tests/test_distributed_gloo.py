@@ -26,12 +26,11 @@ def test_lpt_balances_human_contigs():
     assert sorted(set(r.tolist())) == list(range(8))
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, nk=7):
     sys.path.insert(0, ROOT)
     from oracle import oracle as orc
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    nk = 7
     bk, bs, be = synth(4000, 5, nkeys=nk, mean_len=800, span=300_000)
     pk, ps, pe = synth(30000, 6, nkeys=nk, mean_len=150, span=300_000)
     w = np.bincount(bk, minlength=nk) + np.bincount(pk, minlength=nk)
@@ -54,6 +53,15 @@ def test_sharded_join_allgatherv_world2():
     with mp.Manager() as m:
         ret = m.dict()
         mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+        assert ret.get("ok") is True
+
+
+def test_sharded_join_allgatherv_world3_with_an_idle_rank():
+    # fewer contigs than ranks: one rank owns no key, joins nothing and contributes an empty slice to the exchange
+    port = 31500 + os.getpid() % 2000
+    with mp.Manager() as m:
+        ret = m.dict()
+        mp.spawn(_worker, args=(3, port, ret, 2), nprocs=3, join=True)
         assert ret.get("ok") is True
 
 
