@@ -124,6 +124,10 @@ class Session:
         self._chk(lib().brh_session_metrics(self.h, C.byref(m)))
         return {f: getattr(m, f) for f, _ in pyivx.Metrics._fields_}
 
+    def set_strict_null_contigs(self, on=True):
+        """refuse batches with NULL contigs instead of treating them as the reference does (bio_ranges_host.h)"""
+        self._chk(lib().brh_session_set_strict_null_contigs(self.h, C.c_int(int(on))))
+
     def set_memory_limit(self, nbytes):
         """device bytes the session may reserve (MemoryReservation, interval_join.rs:614-639); 0 = no limit"""
         self._chk(lib().brh_session_set_memory_limit(self.h, C.c_uint64(int(nbytes))))
@@ -365,7 +369,8 @@ def check_position_column(table, column, as_i64=False):
 
 
 def check_contig_column(table, column):
-    """ContigArray checks alone (no GPU): Utf8 / LargeUtf8 / Utf8View, no NULL contigs; returns None or the error text."""
+    """ContigArray checks alone (no GPU): Utf8 / LargeUtf8 / Utf8View (NULL contigs only fail under
+    BIO_STRICT_NULL_CONTIGS=1 / a strict session); returns None or the error text."""
     T = _Exported(table)
     buf = C.create_string_buffer(512)
     try:

@@ -23,7 +23,7 @@ ivx_status ivx_ctx::get_scratch(int slot, size_t bytes, void **out)
     if (b.cap < bytes) {
         size_t want = bytes + bytes / 8;
         if (mem_limit) {
-            const u64 others = scratch_bytes - b.cap + building_bytes;
+            const u64 others = reserved() - b.cap;
             if (others + bytes > mem_limit)
                 return fail(IVX_ERR_OOM, "Resources exhausted: failed to reserve " + std::to_string(bytes) + " bytes of device scratch (" +
                                          std::to_string(others) + " bytes reserved, limit " + std::to_string(mem_limit) + ")");
@@ -87,14 +87,26 @@ void pool_give(int device, void *p, size_t cap)
     }
     if (drop) (void)hipFree(drop);
 }
+
+void pool_drop(int device)
+{
+    std::vector<void *> drop;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        for (size_t i = 0; i < g_pool.size();)
+            if (g_pool[i].device == device) { drop.push_back(g_pool[i].p); g_pool.erase(g_pool.begin() + i); }
+            else i++;
+    }
+    for (void *p : drop) (void)hipFree(p);
+}
 }  // namespace
 
 ivx_status ivx_index_alloc(ivx_ctx *ctx, ivx_index *ix, size_t bytes, void **out)
 {
     if (bytes < 256) bytes = 256;
-    if (ctx->mem_limit && ctx->scratch_bytes + ctx->building_bytes + bytes > ctx->mem_limit)
+    if (ctx->mem_limit && ctx->reserved() + bytes > ctx->mem_limit)
         return ctx->fail(IVX_ERR_OOM, "Resources exhausted: failed to reserve " + std::to_string(bytes) + " bytes for the index (" +
-                                      std::to_string(ctx->scratch_bytes + ctx->building_bytes) + " bytes reserved, limit " + std::to_string(ctx->mem_limit) + ")");
+                                      std::to_string(ctx->reserved()) + " bytes reserved, limit " + std::to_string(ctx->mem_limit) + ")");
     ctx->building_bytes += bytes;
     size_t cap = bytes;
     void *p = pool_take(ctx->device, bytes, &cap);
@@ -271,6 +283,29 @@ extern "C" ivx_status ivx_ctx_set_memory_limit(ivx_ctx *c, uint64_t bytes)
     return IVX_OK;
 }
 
+extern "C" uint64_t ivx_ctx_reserved_bytes(const ivx_ctx *c) { return c ? c->reserved() : 0; }
+
+// Scratch back to the device: the reference's build-side reservation is returned when the stream ends
+// (interval_join.rs:614-639); a context that served a 10^9-row call would otherwise keep ~100 GB for good.
+extern "C" ivx_status ivx_ctx_trim(ivx_ctx *c, uint64_t keep_bytes)
+{
+    if (!c) return IVX_ERR_INVALID;
+    IVX_HIP(c, hipSetDevice(c->device));
+    IVX_HIP(c, hipStreamSynchronize(c->stream));
+    c->sub_plan.valid = false; c->join_plan.valid = false;      // both live in scratch slots
+    while (c->scratch_bytes > keep_bytes) {
+        int big = -1;
+        for (int i = 0; i < IVX_NSCRATCH; i++)
+            if (c->scratch[i].p && (big < 0 || c->scratch[i].cap > c->scratch[big].cap)) big = i;
+        if (big < 0) break;
+        IVX_HIP(c, hipFree(c->scratch[big].p));
+        c->scratch_bytes -= c->scratch[big].cap;
+        c->scratch[big] = ivx_buf{};
+    }
+    pool_drop(c->device);                                       // recycled index buffers of freed indexes on this device, too
+    return IVX_OK;
+}
+
 extern "C" double ivx_ctx_last_kernel_ms(const ivx_ctx *cc)
 {
     ivx_ctx *c = const_cast<ivx_ctx *>(cc);
@@ -323,8 +358,12 @@ extern "C" ivx_status ivx_index_build(ivx_ctx *ctx, int kind, int mem, const uin
         }
     }
     if (st == IVX_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = ctx->fail(IVX_ERR_HIP, "index build failed on device");
-    ctx->building_bytes = 0;                                     // (the index is the caller's now; the limit covers scratch + a build in progress)
+    ctx->building_bytes = 0;
     if (st != IVX_OK) { ivx_index_free(ix); return st; }
+    // the finished index stays reserved against the context's limit until ivx_index_free (the reference holds the
+    // build side's MemoryReservation until the join stream ends, interval_join.rs:614-639)
+    ix->owner_bytes = ctx->live_index_bytes;
+    ix->owner_bytes->fetch_add(ix->bytes, std::memory_order_relaxed);
     ctx->metrics.build_mem_used += ix->bytes;
     *out = ix;
     return IVX_OK;
@@ -336,6 +375,7 @@ extern "C" void ivx_index_free(ivx_index *ix)
     // the caller guarantees no probe on this index is still running (same contract as dropping
     // Arc<JoinLeftData>); buffers go back to the pool, to be reused only by later builds
     for (size_t i = 0; i < ix->allocs.size(); i++) pool_give(ix->device, ix->allocs[i], ix->alloc_caps[i]);
+    if (ix->owner_bytes) ix->owner_bytes->fetch_sub(ix->bytes, std::memory_order_relaxed);
     delete ix;
 }
 
@@ -920,6 +960,31 @@ extern "C" ivx_status ivx_take_fixed(ivx_ctx *ctx, int mem, const void *src, uin
     }
     IVX_TRY(copy_out(ctx, mem, (u8 *)out, dout, n * width));
     IVX_TRY(copy_out(ctx, mem, out_valid, dov, n));
+    if (mem == IVX_MEM_HOST) IVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return IVX_OK;
+}
+
+ivx_status ivx_scatter_fixed_device(ivx_ctx *ctx, const void *src, u32 width, const u32 *idx, u64 n, void *out, u64 n_out);
+
+extern "C" ivx_status ivx_scatter_fixed(ivx_ctx *ctx, int mem, const void *src, uint32_t width, const uint32_t *idx, uint64_t n,
+                                        void *out, uint64_t n_out)
+{
+    if (!ctx) return IVX_ERR_INVALID;
+    if (mem != IVX_MEM_HOST && mem != IVX_MEM_DEVICE) return ctx->fail(IVX_ERR_INVALID, "bad mem");
+    if (n && (!idx || !src || !out)) return ctx->fail(IVX_ERR_INVALID, "scatter: null src, idx or out");
+    if (width == 0 || width > 32 || (width & (width - 1))) return ctx->fail(IVX_ERR_UNSUPPORTED, "scatter: fixed width must be 1, 2, 4, 8, 16 or 32 bytes");
+    IVX_HIP(ctx, hipSetDevice(ctx->device));
+    const u8 *dsrc; const u32 *didx; u8 *dout;
+    IVX_TRY(stage_in(ctx, mem, WS_IN_KEY, (const u8 *)src, n * width, &dsrc));
+    IVX_TRY(stage_in(ctx, mem, WS_IN_END, idx, n, &didx));
+    IVX_TRY(stage_out(ctx, mem, WS_OUT_A, (u8 *)out, n_out * width, &dout));
+    // host mode: rows that no index names keep what the caller's buffer holds
+    if (mem == IVX_MEM_HOST && n_out) IVX_HIP(ctx, hipMemcpyAsync(dout, out, (size_t)n_out * width, hipMemcpyHostToDevice, ctx->stream));
+    {
+        KernelTimer t(ctx);
+        IVX_TRY(ivx_scatter_fixed_device(ctx, dsrc, width, didx, n, dout, n_out));
+    }
+    IVX_TRY(copy_out(ctx, mem, (u8 *)out, dout, n_out * width));
     if (mem == IVX_MEM_HOST) IVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return IVX_OK;
 }

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
+#include <memory>
 #include <string>
 #include <vector>
 #include "../../include/ivx.h"
@@ -77,6 +79,10 @@ struct ivx_ctx {
     u64 mem_limit = 0;                  // device bytes of scratch + the index being built (0 = unlimited)
     u64 fill_hint = 0;                  // pairs a fill call should expect instead of its cap (a chunk of a host-resident batch writes into the whole batch's buffers)
     u64 scratch_bytes = 0, building_bytes = 0;
+    // device bytes of the indexes this context built that are still alive (shared with those indexes: ivx_index_free
+    // gives the bytes back whichever thread calls it, also after the context is gone)
+    std::shared_ptr<std::atomic<u64>> live_index_bytes = std::make_shared<std::atomic<u64>>(0);
+    u64 reserved() const { return scratch_bytes + building_bytes + live_index_bytes->load(std::memory_order_relaxed); }
 
     ivx_status fail(ivx_status st, const std::string &msg) { err = msg; return st; }
     ivx_status fail_hip(const char *what, hipError_t e)
@@ -198,6 +204,7 @@ struct ivx_index {
     u64 n = 0;
     u32 nkeys = 0;
     size_t bytes = 0;
+    std::shared_ptr<std::atomic<u64>> owner_bytes;   // the building context's live_index_bytes (null until the build succeeded)
     std::vector<void *> allocs;
     std::vector<size_t> alloc_caps;
     JoinIndexView jv{};

@@ -38,6 +38,18 @@ __global__ __launch_bounds__(TK) void k_take_fixed(const V *__restrict__ src, u6
 
 struct alignas(16) B32 { uint4 a, b; };
 
+// the inverse of take: out[idx[i]] = src[i].  Puts a per-row column computed on a shard of the rows (idx = the rows'
+// numbers in the whole job) back in input order; the value stream is read coalesced, the stores are a scatter.
+template <typename V>
+__global__ __launch_bounds__(TK) void k_scatter_fixed(const V *__restrict__ src, const u32 *__restrict__ idx, u64 n, V *__restrict__ out, u64 n_out, u32 *bad)
+{
+    for (u64 i = (u64)blockIdx.x * TK + threadIdx.x; i < n; i += (u64)gridDim.x * TK) {
+        const u32 j = idx[i];
+        if (j >= n_out) { *bad = 1; continue; }
+        out[j] = src[i];
+    }
+}
+
 // Boolean columns are bitmaps: one thread packs eight output bits into one byte
 __global__ __launch_bounds__(TK) void k_take_bits(const u8 *__restrict__ src, u64 n_src, const u8 *__restrict__ src_valid,
                                                   const u32 *__restrict__ idx, u64 n, u8 *__restrict__ out, u8 *__restrict__ out_valid, u32 *bad)
@@ -162,11 +174,11 @@ __global__ __launch_bounds__(TK) void k_view_copy(const View16 *__restrict__ vie
 
 u32 take_grid(u64 n) { return ivx_stream_grid(n, TK * 4, 256 * 16); }
 
-ivx_status take_flag(ivx_ctx *ctx)
+ivx_status take_flag(ivx_ctx *ctx, const char *what = "take: index out of bounds")
 {
     IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 8, ctx->d_scalars + 8, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
     IVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (*(u32 *)(ctx->h_scalars + 8)) return ctx->fail(IVX_ERR_INVALID, "take: index out of bounds");
+    if (*(u32 *)(ctx->h_scalars + 8)) return ctx->fail(IVX_ERR_INVALID, what);
     return IVX_OK;
 }
 
@@ -194,6 +206,29 @@ ivx_status ivx_take_fixed_device(ivx_ctx *ctx, const void *src, u32 width, u64 n
         IVX_HIP(ctx, hipGetLastError());
     }
     return take_flag(ctx);
+}
+
+ivx_status ivx_scatter_fixed_device(ivx_ctx *ctx, const void *src, u32 width, const u32 *idx, u64 n, void *out, u64 n_out)
+{
+    hipStream_t st = ctx->stream;
+    IVX_HIP(ctx, hipMemsetAsync(ctx->d_scalars + 8, 0, sizeof(u64), st));
+    u32 *bad = (u32 *)(ctx->d_scalars + 8);
+    if (n) {
+        const u32 grid = take_grid(n);
+#define IVX_SCAT(V) hipLaunchKernelGGL(k_scatter_fixed<V>, dim3(grid), dim3(TK), 0, st, (const V *)src, idx, n, (V *)out, n_out, bad)
+        switch (width) {
+        case 1: IVX_SCAT(u8); break;
+        case 2: IVX_SCAT(unsigned short); break;
+        case 4: IVX_SCAT(u32); break;
+        case 8: IVX_SCAT(u64); break;
+        case 16: IVX_SCAT(uint4); break;
+        case 32: IVX_SCAT(B32); break;
+        default: return ctx->fail(IVX_ERR_UNSUPPORTED, "scatter: fixed width must be 1, 2, 4, 8, 16 or 32 bytes");
+        }
+#undef IVX_SCAT
+        IVX_HIP(ctx, hipGetLastError());
+    }
+    return take_flag(ctx, "scatter: index out of bounds");
 }
 
 ivx_status ivx_take_bits_device(ivx_ctx *ctx, const u8 *src_bits, u64 n_src, const u8 *src_valid, const u32 *idx, u64 n, u8 *out_bits, u8 *out_valid)

@@ -17,6 +17,9 @@
 struct brh_session {
     ivx_ctx *ctx = nullptr;
     std::string err;
+    // NULL contigs: 0 = as the reference treats them (see get_contig), 1 = refuse the batch (opt-in; BIO_STRICT_NULL_CONTIGS=1
+    // makes it the default of new sessions)
+    int strict_null_contigs = [] { const char *e = std::getenv("BIO_STRICT_NULL_CONTIGS"); return e && *e && *e != '0' ? 1 : 0; }();
 };
 
 namespace {
@@ -59,6 +62,14 @@ int64_t null_count(const ArrowArray *a)
 struct StrCol {
     int kind = 0;               // 0 Utf8, 1 LargeUtf8, 2 Utf8View
     const ArrowArray *a = nullptr;
+    bool has_nulls = false;
+    bool null_at(int64_t i) const
+    {
+        if (!has_nulls) return false;
+        const uint8_t *v = (const uint8_t *)a->buffers[0];
+        const int64_t j = i + a->offset;
+        return !((v[j >> 3] >> (j & 7)) & 1);
+    }
     std::string_view at(int64_t i) const
     {
         const int64_t j = i + a->offset;
@@ -82,13 +93,16 @@ int get_contig(brh_session *s, brh_batch t, const char *name, StrCol *out)
     else if (!std::strcmp(f, "U")) out->kind = 1;
     else if (!std::strcmp(f, "vu")) out->kind = 2;
     else return fail(s, "unsupported data type " + std::string(f) + " for contig column '" + name + "'; expected Utf8, LargeUtf8, or Utf8View");
-    // A NULL contig has no defined bytes (Arrow lets its offsets span anything): the reference hashes it as a key of its
-    // own in the join and reads whatever value(i) holds in the table functions; here it is refused outright rather than
-    // silently keyed as "" (parity with the reference on NULL contigs is not pinned by any of its tests).
-    if (null_count(out->a) > 0) {
-        const uint8_t *v = (const uint8_t *)out->a->buffers[0];
+    // NULL contigs.  The reference never looks at the validity bitmap of a contig column: the table functions read
+    // `value(i)` (whatever bytes the slot's offsets span: "" for arrays made by the Arrow builders), and the join hashes the
+    // key columns with create_hashes, where a NULL is a key of its own that equals only other NULLs (the reference compares
+    // hashes, never values: interval_join.rs:857, :922-928).  That is what happens here by default (the callers of
+    // build_keys say which of the two); none of the reference's tests pins either, so a session can refuse such batches
+    // instead (brh_session_set_strict_null_contigs / BIO_STRICT_NULL_CONTIGS=1).
+    out->has_nulls = null_count(out->a) > 0 && out->a->n_buffers >= 1 && out->a->buffers[0];
+    if (out->has_nulls && s && s->strict_null_contigs) {
         int64_t row = 0;
-        for (int64_t i = 0; i < out->a->length; i++) { const int64_t j = i + out->a->offset; if (!((v[j >> 3] >> (j & 7)) & 1)) { row = i; break; } }
+        for (int64_t i = 0; i < out->a->length; i++) if (out->null_at(i)) { row = i; break; }
         return fail(s, "contig column '" + std::string(name) + "' contains a NULL at row " + std::to_string(row) + "; NULL contigs are not supported");
     }
     return 0;
@@ -162,7 +176,10 @@ struct KeyDict {
     std::vector<std::vector<uint32_t>> ids;         // per table: row -> id
 };
 
-int build_keys(brh_session *s, const std::vector<std::pair<brh_batch, brh_columns>> &tables, KeyDict *kd)
+// what a NULL slot of a key column contributes to the key in the JOIN (a key of its own): a byte string no contig name holds
+const std::string_view NULL_KEY("\x1e\x00NULL", 6);
+
+int build_keys(brh_session *s, const std::vector<std::pair<brh_batch, brh_columns>> &tables, KeyDict *kd, bool null_as_key = false)
 {
     std::vector<std::vector<std::string>> composite(tables.size());
     std::vector<std::vector<StrCol>> cols(tables.size());
@@ -175,10 +192,13 @@ int build_keys(brh_session *s, const std::vector<std::pair<brh_batch, brh_column
     }
     std::unordered_map<std::string_view, uint32_t> seen;
     std::vector<std::string_view> uniq;
+    auto part = [&](size_t t, size_t k, int64_t i) -> std::string_view {
+        return null_as_key && cols[t][k].null_at(i) ? NULL_KEY : cols[t][k].at(i);
+    };
     auto key_of = [&](size_t t, int64_t i, std::string &scratch) -> std::string_view {
-        if (cols[t].size() == 1) return cols[t][0].at(i);
+        if (cols[t].size() == 1) return part(t, 0, i);
         scratch.clear();
-        for (size_t k = 0; k < cols[t].size(); k++) { if (k) scratch.push_back('\x1f'); scratch.append(cols[t][k].at(i)); }
+        for (size_t k = 0; k < cols[t].size(); k++) { if (k) scratch.push_back('\x1f'); scratch.append(part(t, k, i)); }
         return scratch;
     };
     // pass 1: unique keys (composite keys are materialised once per table).  Rows of one contig come in runs in
@@ -192,7 +212,7 @@ int build_keys(brh_session *s, const std::vector<std::pair<brh_batch, brh_column
         }
         std::string_view last; bool have = false;
         for (int64_t i = 0; i < n; i++) {
-            std::string_view k = cols[t].size() > 1 ? std::string_view(composite[t][i]) : cols[t][0].at(i);
+            std::string_view k = cols[t].size() > 1 ? std::string_view(composite[t][i]) : part(t, 0, i);
             if (have && k == last) continue;
             last = k; have = true;
             if (seen.emplace(k, 0).second) uniq.push_back(k);
@@ -211,7 +231,7 @@ int build_keys(brh_session *s, const std::vector<std::pair<brh_batch, brh_column
         kd->ids[t].resize((size_t)n);
         std::string_view last; uint64_t last_packed = 0; uint32_t last_id = 0; bool have = false;
         for (int64_t i = 0; i < n; i++) {
-            std::string_view k = cols[t].size() > 1 ? std::string_view(composite[t][i]) : cols[t][0].at(i);
+            std::string_view k = cols[t].size() > 1 ? std::string_view(composite[t][i]) : part(t, 0, i);
             if (k.size() <= 7) {
                 const uint64_t w = pack(k);
                 if (w != last_packed) { last_id = short_ids.find(w)->second; last_packed = w; have = false; }
@@ -352,6 +372,13 @@ extern "C" int brh_session_metrics(brh_session *s, ivx_metrics *out)
     return ivx_ctx_metrics(s->ctx, out) == IVX_OK ? 0 : 1;
 }
 
+extern "C" int brh_session_set_strict_null_contigs(brh_session *s, int on)
+{
+    if (!s) return 1;
+    s->strict_null_contigs = on != 0;
+    return 0;
+}
+
 extern "C" int brh_session_set_memory_limit(brh_session *s, uint64_t bytes)
 {
     if (!s) return 1;
@@ -416,7 +443,7 @@ extern "C" int brh_interval_join(brh_session *s, brh_batch build, brh_columns bc
 {
     if (!s) return 1;
     KeyDict kd; Side32 B, P;
-    if (build_keys(s, {{build, bcols}, {probe, pcols}}, &kd) || load_side32(s, build, bcols, &B) || load_side32(s, probe, pcols, &P)) return 1;
+    if (build_keys(s, {{build, bcols}, {probe, pcols}}, &kd, true) || load_side32(s, build, bcols, &B) || load_side32(s, probe, pcols, &P)) return 1;
     if (strict_predicate) {                                       // `a.start < b.end AND a.end > b.start`: end - 1 on both sides
         for (auto &v : B.e) v = (int32_t)((uint32_t)v - 1u);
         for (auto &v : P.e) v = (int32_t)((uint32_t)v - 1u);
@@ -980,14 +1007,24 @@ extern "C" int brh_join_stream_open(brh_session *s, brh_batch build, brh_columns
     *out = nullptr;
     if (join_type < BRH_JOIN_INNER || join_type > BRH_JOIN_NEAREST) return fail(s, "join stream: unsupported join type");
     if (max_output_rows == BRH_MAX_OUTPUT_ENV) {                  // the reference's low-memory default (interval_join.rs:543-548)
+        // usize::from_str: an optional '+', then digits only, no overflow; anything else is the default.  A parsed 0 is kept by
+        // the reference (it then emits after every probe row); here 0 already means "regular mode", so 0 becomes 1: one
+        // output row per batch is the smallest budget there is.
         const char *e = std::getenv("BIO_MAX_OUTPUT_BATCH_SIZE");
-        char *end = nullptr;
-        const unsigned long long v = e ? std::strtoull(e, &end, 10) : 0;
-        max_output_rows = (e && end != e && *end == 0 && v > 0) ? v : 100000;
+        max_output_rows = 100000;
+        if (e) {
+            const char *p = e + (*e == '+');
+            unsigned long long v = 0; bool ok = *p != 0;
+            for (; ok && *p; p++) {
+                if (*p < '0' || *p > '9' || v > (~0ull - (unsigned)(*p - '0')) / 10) ok = false;
+                else v = v * 10 + (unsigned)(*p - '0');
+            }
+            if (ok) max_output_rows = v ? v : 1;
+        }
     }
     if (pcols.n_keys != bcols.n_keys || pcols.n_keys < 1) return fail(s, "both sides need the same number (>= 1) of key columns");
     KeyDict kd; Side32 B;
-    if (build_keys(s, {{build, bcols}}, &kd) || load_side32(s, build, bcols, &B)) return 1;
+    if (build_keys(s, {{build, bcols}}, &kd, true) || load_side32(s, build, bcols, &B)) return 1;
     if (strict_predicate) for (auto &v : B.e) v = (int32_t)((uint32_t)v - 1u);          // intervals.rs:85-115
     std::unique_ptr<brh_join_stream> js(new brh_join_stream());
     js->s = s; js->strict = strict_predicate != 0;
@@ -1026,8 +1063,8 @@ extern "C" int brh_join_stream_push(brh_join_stream *js, brh_batch probe, int *n
     std::string scratch, last; uint32_t last_id = 0; bool have_last = false; uint64_t last_packed = 0;
     for (int64_t i = 0; i < n; i++) {
         std::string_view k;
-        if (cols.size() == 1) k = cols[0].at(i);
-        else { scratch.clear(); for (size_t c = 0; c < cols.size(); c++) { if (c) scratch.push_back('\x1f'); scratch.append(cols[c].at(i)); } k = scratch; }
+        if (cols.size() == 1) k = cols[0].null_at(i) ? NULL_KEY : cols[0].at(i);
+        else { scratch.clear(); for (size_t c = 0; c < cols.size(); c++) { if (c) scratch.push_back('\x1f'); scratch.append(cols[c].null_at(i) ? NULL_KEY : cols[c].at(i)); } k = scratch; }
         if (k.size() <= 7) {
             uint64_t packed = 0;
             std::memcpy(&packed, k.data(), k.size());

@@ -26,7 +26,8 @@ SYMBOLS = [
     "ivx_index_device_bytes", "ivx_probe_overlap_count", "ivx_probe_overlap_fill", "ivx_probe_exists",
     "ivx_probe_count", "ivx_probe_coverage", "ivx_probe_nearest", "ivx_merge", "ivx_subtract",
     "ivx_cluster", "ivx_complement", "ivx_take_fixed", "ivx_take_utf8", "ivx_take_bits", "ivx_take_view",
-    "ivx_ctx_metrics", "ivx_ctx_reset_metrics", "ivx_ctx_set_memory_limit",
+    "ivx_ctx_metrics", "ivx_ctx_reset_metrics", "ivx_ctx_set_memory_limit", "ivx_ctx_trim", "ivx_scatter_fixed",
+    "ivx_ctx_reserved_bytes",
 ]
 
 
@@ -72,6 +73,7 @@ def lib():
         L.ivx_ctx_last_kernel_ms.restype = C.c_double
         L.ivx_index_rows.restype = C.c_uint64
         L.ivx_index_device_bytes.restype = C.c_uint64
+        L.ivx_ctx_reserved_bytes.restype = C.c_uint64
         _lib = L
     return _lib
 
@@ -151,19 +153,27 @@ class Ctx:
         except Exception:
             pass
 
-    def _chk(self, st):
+    acc_ms = None       # set to 0.0 to sum the device time (hipEvents) of every compute call made from here on
+
+    def _chk0(self, st):
         if st != OK:
             raise IvxError(st, lib().ivx_last_error(self.h).decode())
 
+    def _chk(self, st):
+        """status check of a COMPUTE call (one that brackets its kernels with the context's events)"""
+        self._chk0(st)
+        if self.acc_ms is not None:
+            self.acc_ms += self.last_kernel_ms()
+
     def set_stream(self, stream_ptr):
         """use this hipStream_t verbatim (0/None = HIP's default stream)"""
-        self._chk(lib().ivx_ctx_set_stream(self.h, C.c_void_p(stream_ptr or 0)))
+        self._chk0(lib().ivx_ctx_set_stream(self.h, C.c_void_p(stream_ptr or 0)))
 
     def use_own_stream(self):
-        self._chk(lib().ivx_ctx_use_own_stream(self.h))
+        self._chk0(lib().ivx_ctx_use_own_stream(self.h))
 
     def synchronize(self):
-        self._chk(lib().ivx_ctx_synchronize(self.h))
+        self._chk0(lib().ivx_ctx_synchronize(self.h))
 
     def last_kernel_ms(self):
         return lib().ivx_ctx_last_kernel_ms(self.h)
@@ -171,14 +181,21 @@ class Ctx:
     def metrics(self):
         """BuildProbeJoinMetrics under the reference's names (joins/utils.rs:399-453)."""
         m = Metrics()
-        self._chk(lib().ivx_ctx_metrics(self.h, C.byref(m)))
+        self._chk0(lib().ivx_ctx_metrics(self.h, C.byref(m)))
         return {f: getattr(m, f) for f, _ in Metrics._fields_}
 
     def reset_metrics(self):
         lib().ivx_ctx_reset_metrics(self.h)
 
     def set_memory_limit(self, nbytes):
-        self._chk(lib().ivx_ctx_set_memory_limit(self.h, C.c_uint64(int(nbytes))))
+        self._chk0(lib().ivx_ctx_set_memory_limit(self.h, C.c_uint64(int(nbytes))))
+
+    def reserved_bytes(self):
+        return lib().ivx_ctx_reserved_bytes(self.h)
+
+    def trim(self, keep_bytes=0):
+        """scratch (and the pool of recycled index buffers) back to the device"""
+        self._chk0(lib().ivx_ctx_trim(self.h, C.c_uint64(int(keep_bytes))))
 
     # ---- index ----
     def build(self, kind, key, start, end, n_keys=None):
@@ -427,6 +444,23 @@ class Ctx:
         self._chk(lib().ivx_take_fixed(self.h, C.c_int(MEM_DEVICE if dev else MEM_HOST), _ptr(src), C.c_uint32(width), C.c_uint64(n_src),
                                         _ptr(svb), _ptr(idx), C.c_uint64(n), _ptr(out), _ptr(valid)))
         return out, (valid[:n] if valid is not None else None)
+
+    def scatter_fixed(self, src, idx, out):
+        """out[idx[i]] = src[i] (idx: uint32 rows of `out`); -> out"""
+        dev = _is_torch(src)
+        if _is_torch(idx) != dev or _is_torch(out) != dev:
+            raise ValueError("mix of host and device buffers in one call")
+        if dev:
+            assert src.is_contiguous() and idx.is_contiguous() and out.is_contiguous() and src.dtype == out.dtype
+            width, n, n_out = src.element_size(), int(idx.numel()), int(out.numel())
+        else:
+            src = np.ascontiguousarray(src, out.dtype); idx = np.ascontiguousarray(idx, np.uint32)
+            assert out.flags.c_contiguous
+            width, n, n_out = out.dtype.itemsize, len(idx), len(out)
+        assert (int(src.numel()) if dev else len(src)) == n
+        self._chk(lib().ivx_scatter_fixed(self.h, C.c_int(MEM_DEVICE if dev else MEM_HOST), _ptr(src), C.c_uint32(width), _ptr(idx),
+                                           C.c_uint64(n), _ptr(out), C.c_uint64(n_out)))
+        return out
 
     def take_utf8(self, offsets, data, idx, src_valid_bits=None, want_valid=True):
         """offsets: int32 (Utf8/Binary) or int64 (LargeUtf8/LargeBinary) [n_src+1]; data: uint8 bytes.

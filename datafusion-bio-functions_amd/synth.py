@@ -83,3 +83,43 @@ def gen_numpy(n, mean, n_contigs, seed):
     ln = np.uint64(1) + u1 % np.uint64(2 * mean - 1)
     st = u2 % (lens[k] - ln + np.uint64(1))
     return k.astype(np.uint32), st.astype(np.int32), (st + ln - np.uint64(1)).astype(np.int32)
+
+
+def key_counts_torch(n, n_contigs, seed, device, chunk=1 << 24):
+    """rows per contig of gen_torch(n, ., n_contigs, seed) without materialising them (only the contig draw)"""
+    import torch
+    cum = torch.cumsum(torch.tensor(HG38[:n_contigs], dtype=torch.int64, device=device), 0)
+    total = int(cum[-1])
+    cnt = torch.zeros(n_contigs, dtype=torch.int64, device=device)
+    m63 = (1 << 63) - 1
+    for lo in range(0, n, chunk):
+        i = torch.arange(lo, min(n, lo + chunk), dtype=torch.int64, device=device)
+        k = torch.bucketize((splitmix64_torch(seed, 3 * i) & m63) % total, cum, right=True)
+        cnt += torch.bincount(k, minlength=n_contigs)
+    return cnt
+
+
+def gen_torch_sharded(n, mean, n_contigs, seed, device, keep=None, lo=0, hi=None, chunk=1 << 24):
+    """The rows of gen_torch(n, mean, n_contigs, seed) that one rank holds, generated chunk by chunk so that no rank
+    ever materialises the whole job: rows lo..hi whose contig has keep[contig] set (keep: bool [n_contigs] or None).
+    -> (key, start, end, rows) with rows = the kept rows' numbers in the whole job (int32)."""
+    import torch
+    hi = n if hi is None else hi
+    lens = torch.tensor(HG38[:n_contigs], dtype=torch.int64, device=device)
+    cum = torch.cumsum(lens, 0)
+    total = int(cum[-1])
+    m63 = (1 << 63) - 1
+    parts = []
+    for a in range(lo, hi, chunk):
+        i = torch.arange(a, min(hi, a + chunk), dtype=torch.int64, device=device)
+        k = torch.bucketize((splitmix64_torch(seed, 3 * i) & m63) % total, cum, right=True)
+        if keep is not None:
+            sel = keep[k]
+            i, k = i[sel], k[sel]
+        ln = 1 + (splitmix64_torch(seed, 3 * i + 1) & m63) % (2 * mean - 1)
+        st = (splitmix64_torch(seed, 3 * i + 2) & m63) % (lens[k] - ln + 1)
+        parts.append((k.to(torch.int32), st.to(torch.int32), (st + ln - 1).to(torch.int32), i.to(torch.int32)))
+    if not parts:
+        z = torch.zeros(0, dtype=torch.int32, device=device)
+        return z, z.clone(), z.clone(), z.clone()
+    return tuple(torch.cat([p[c] for p in parts]) for c in range(4))

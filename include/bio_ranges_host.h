@@ -173,9 +173,15 @@ void brh_join_stream_close(brh_join_stream *js);
  * 0 = fine, else the error text is set.  Used by the CPU-only tests. */
 int brh_check_position_column(brh_session *s_or_null, brh_batch table, const char *column, int as_i64,
                               char *errbuf, int errbuf_len);
-/* ... and a contig column like ContigArray (array_utils.rs:10-24, :178-229): Utf8 / LargeUtf8 / Utf8View; NULL contigs are
- * refused (the reference's behaviour on them is not pinned by its tests; keying them as "" would be a silent guess). */
+/* ... and a contig column like ContigArray (array_utils.rs:10-24, :178-229): Utf8 / LargeUtf8 / Utf8View.  NULL contigs
+ * pass unless the session (or, without one, BIO_STRICT_NULL_CONTIGS=1) is strict about them, see below. */
 int brh_check_contig_column(brh_session *s_or_null, brh_batch table, const char *column, char *errbuf, int errbuf_len);
+/* NULL contigs.  Default (on = 0), as the reference, which never reads a contig column's validity bitmap: the table
+ * functions key a NULL slot by the bytes its offsets span (`value(i)`: "" for builder-made arrays), the join treats NULL as a
+ * key of its own that matches only NULL (create_hashes; hashes are compared, never values: interval_join.rs:857, :922-928).
+ * None of the reference's tests pins this (parity unpinned).  on = 1: a batch with a NULL contig is refused with an error
+ * instead (the default of new sessions when BIO_STRICT_NULL_CONTIGS=1 is set). */
+int brh_session_set_strict_null_contigs(brh_session *s, int on);
 
 /* BuildProbeJoinMetrics of the session's context under the reference's names (joins/utils.rs:399-453), and the device
  * memory the session may reserve (MemoryReservation::try_grow, interval_join.rs:614-639): ivx.h ivx_ctx_metrics /

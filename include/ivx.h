@@ -108,10 +108,21 @@ typedef struct ivx_metrics {
 } ivx_metrics;
 ivx_status ivx_ctx_metrics(const ivx_ctx *ctx, ivx_metrics *out);
 void       ivx_ctx_reset_metrics(ivx_ctx *ctx);
-/* Device memory this context may hold at once in its scratch buffers plus any ONE index it is building (0 = no limit):
- * the reference reserves build-side memory against DataFusion's pool and fails with ResourcesExhausted
- * (interval_join.rs:614-639); a call that would go over the limit returns IVX_ERR_OOM and allocates nothing. */
+/* Device memory this context may hold at once (0 = no limit): its scratch buffers, the index it is building and every
+ * index it has built that is still alive -- an index stays reserved against the limit of the context that built it until
+ * ivx_index_free, as the reference holds the build side's MemoryReservation until the join stream ends
+ * (interval_join.rs:614-639; try_grow fails with ResourcesExhausted).  A call that would go over the limit returns
+ * IVX_ERR_OOM and allocates nothing.  Not counted: the caller's own buffers, and freed indexes' buffers waiting in the
+ * library's recycling pool (ivx_ctx_trim returns those to the device). */
 ivx_status ivx_ctx_set_memory_limit(ivx_ctx *ctx, uint64_t bytes);
+/* What counts against that limit right now (MemoryReservation::size): scratch + the live indexes this context built. */
+uint64_t   ivx_ctx_reserved_bytes(const ivx_ctx *ctx);
+/* Give scratch back to the device: waits for the context's stream, then frees scratch buffers, largest first, until
+ * at most keep_bytes remain (0 = all), and empties the device's pool of recycled index buffers.  Scratch is grow-only
+ * otherwise (a 10^9-row sweep leaves ~100 GB behind); the reference returns its reservation when the stream ends
+ * (interval_join.rs:614-639) -- call this where the Rust side drops a stream.  Drops the state a sizing / count call
+ * left for its fill call. */
+ivx_status ivx_ctx_trim(ivx_ctx *ctx, uint64_t keep_bytes);
 
 /* ---- index build: replaces collect_left_input's update_hashmap +
  *      IntervalJoinAlgorithm::new (interval_join.rs:584-668, :745-847, :903-931),
@@ -255,6 +266,14 @@ ivx_status ivx_complement(ivx_ctx *ctx, int mem,
 ivx_status ivx_take_fixed(ivx_ctx *ctx, int mem, const void *src, uint32_t width, uint64_t n_src,
                           const uint8_t *src_valid_bits, const uint32_t *idx, uint64_t n,
                           void *out, uint8_t *out_valid);
+
+/*      The inverse: out[idx[i]] = src[i] for i < n (idx[i] >= n_out is IVX_ERR_INVALID; rows no index names keep their
+ *      contents; equal indices: one of the values).  What puts a per-row result column (count_overlaps, coverage,
+ *      nearest) computed on a SHARD of the probe rows back in the order of the whole input -- the reference's partitioned
+ *      forms return their batches in stream order (count_overlaps.rs:143-153, R/tests/integration_test.rs:3783-3890);
+ *      with contigs sharded over GPUs the rows come back as (row, value) lists instead. */
+ivx_status ivx_scatter_fixed(ivx_ctx *ctx, int mem, const void *src, uint32_t width, const uint32_t *idx, uint64_t n,
+                             void *out, uint64_t n_out);
 
 /*      Boolean columns (bit-packed, LSB first): out_bits gets (n+7)/8 bytes. */
 ivx_status ivx_take_bits(ivx_ctx *ctx, int mem, const uint8_t *src_bits, uint64_t n_src, const uint8_t *src_valid_bits,

@@ -46,22 +46,92 @@ def test_product_path_does_not_touch_oracle():
                 assert "oracle" not in txt.lower(), os.path.join(dp, f)
 
 
-def test_rust_ffi_declarations_match_the_header():
-    # integration/rust/hip_ffi.rs cannot be compiled here (no Rust toolchain): at least every function it
-    # declares exists in include/ivx.h with the same number of parameters
+_C_SCALARS = {"int": "i32", "int32_t": "i32", "uint32_t": "u32", "uint64_t": "u64", "int64_t": "i64", "uint8_t": "u8", "double": "f64",
+              "ivx_status": "i32", "void": "c_void", "char": "c_char", "ivx_ctx": "IvxCtx", "ivx_index": "IvxIndex", "ivx_metrics": "IvxMetrics"}
+
+
+def _c_type_to_rust(decl, is_return=False):
+    """One C parameter declaration (or return type) -> the Rust FFI type a binding must use for it."""
     import re
+    decl = re.sub(r"/\*.*?\*/", "", decl, flags=re.S).strip()
+    toks = re.findall(r"\*|\w+", decl)
+    if not is_return and toks and toks[-1] != "*" and len([t for t in toks if t not in ("const", "*")]) > 1:
+        toks = toks[:-1]                                   # drop the parameter name
+    base = [t for t in toks if t not in ("const", "*")]
+    assert len(base) == 1, decl
+    rust = _C_SCALARS[base[0]]
+    # pointer levels, left to right; a `const` qualifies what is to its left (or the base type when it leads)
+    const_base = toks[0] == "const" or (len(toks) > 1 and toks[1] == "const" and toks[0] == base[0])
+    levels, i = [], 0
+    for j, t in enumerate(toks):
+        if t == "*":
+            levels.append("const" if (j + 1 < len(toks) and toks[j + 1] == "const") else "mut")
+    # the FIRST star points at the base type: its mutability is the base's constness; each later star points at the
+    # previous pointer, whose constness is the `const` written right after that previous star
+    out = rust
+    for n in range(len(levels)):
+        pointee_const = const_base if n == 0 else levels[n - 1] == "const"
+        out = ("*const " if pointee_const else "*mut ") + out
+    if is_return and out == "c_void" and not levels:
+        return None
+    return out
 
-    def sigs(text, pat):
-        out = {}
-        for m in re.finditer(pat, text, re.S):
-            args = re.sub(r"/\*.*?\*/", "", m.group(2), flags=re.S)
-            out[m.group(1)] = 0 if args.strip() in ("", "void") else args.count(",") + 1
-        return out
 
-    hdr = sigs(open(os.path.join(ROOT, "include", "ivx.h")).read(), r"\b(ivx_\w+)\s*\(([^;{]*?)\)\s*;")
-    rust = sigs(open(os.path.join(ROOT, "integration", "rust", "hip_ffi.rs")).read(), r"pub fn (ivx_\w+)\(([^;]*?)\)\s*(?:->\s*[\w\* ]+)?;")
-    assert len(rust) >= 19
-    assert {k: hdr.get(k) for k in rust} == rust
+def _c_protos(path, prefix):
+    import re
+    txt = re.sub(r"/\*.*?\*/", "", open(path).read(), flags=re.S)
+    out = {}
+    for m in re.finditer(r"([\w \*]+?)\b(" + prefix + r"\w+)\s*\(([^;{]*?)\)\s*;", txt, re.S):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        if "typedef" in ret:
+            continue
+        params = [] if args in ("", "void") else [_c_type_to_rust(a) for a in args.split(",")]
+        out[name] = (params, _c_type_to_rust(ret, is_return=True))
+    return out
+
+
+def _rust_protos(path, prefix):
+    import re
+    txt = re.sub(r"//[^\n]*", "", open(path).read())
+    out = {}
+    for m in re.finditer(r"pub fn (" + prefix + r"\w+)\(([^;]*?)\)\s*(?:->\s*([\w\* ]+?))?\s*;", txt, re.S):
+        args = m.group(2).strip()
+        params = [] if not args else [" ".join(a.split(":", 1)[1].split()) for a in args.split(",")]
+        out[m.group(1)] = (params, " ".join(m.group(3).split()) if m.group(3) else None)
+    return out
+
+
+def test_c_to_rust_type_map():
+    assert _c_type_to_rust("const uint32_t *key /* nullable */") == "*const u32"
+    assert _c_type_to_rust("ivx_ctx **out") == "*mut *mut IvxCtx"
+    assert _c_type_to_rust("const uint8_t *const *data_bufs") == "*const *const u8"
+    assert _c_type_to_rust("void *hip_stream") == "*mut c_void"
+    assert _c_type_to_rust("const char *", is_return=True) == "*const c_char"
+    assert _c_type_to_rust("void", is_return=True) is None
+    assert _c_type_to_rust("int64_t min_dist") == "i64" and _c_type_to_rust("int device_ordinal") == "i32"
+
+
+def test_rust_ffi_declarations_match_the_header():
+    # integration/rust/hip_ffi.rs cannot be compiled here (no Rust toolchain): every function of include/ivx.h must be
+    # declared there with the parameter TYPES and return type the C prototype maps to, in order
+    hdr = _c_protos(os.path.join(ROOT, "include", "ivx.h"), "ivx_")
+    rust = _rust_protos(os.path.join(ROOT, "integration", "rust", "hip_ffi.rs"), "ivx_")
+    assert len(hdr) >= 30
+    assert sorted(rust) == sorted(hdr)
+    for name in hdr:
+        assert rust[name] == hdr[name], (name, rust[name], hdr[name])
+    # the metrics struct: same field order and types as the C struct
+    import re
+    c_fields = re.search(r"typedef struct ivx_metrics \{(.*?)\}", open(os.path.join(ROOT, "include", "ivx.h")).read(), re.S).group(1)
+    c_list = []
+    for stmt in c_fields.split(";"):
+        stmt = stmt.strip()
+        if stmt:
+            ty, names = stmt.split(None, 1)
+            c_list += [(n.strip(), _C_SCALARS[ty]) for n in names.split(",")]
+    r_fields = re.search(r"pub struct IvxMetrics \{(.*?)\}", open(os.path.join(ROOT, "integration", "rust", "hip_ffi.rs")).read(), re.S).group(1)
+    r_list = [(n, t) for n, t in re.findall(r"pub (\w+): (\w+)", r_fields)]
+    assert r_list == c_list
 
 
 def test_rust_join_stream_declarations_match_the_header():

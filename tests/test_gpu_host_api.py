@@ -488,13 +488,36 @@ def test_join_stream_errors(ctx, golden):
     js.close()
 
 
-def test_null_contig_is_refused_by_the_operators(ctx, golden):
+def test_null_contig_is_refused_by_a_strict_session(golden):
     reads, targets = table(golden.tables["reads"]), table(golden.tables["targets"])
     bad = pa.table({"contig": pa.array(["chr1", None]), "pos_start": pa.array([1, 5], pa.int64()), "pos_end": pa.array([9, 8], pa.int64())})
-    for call in (lambda: ctx.count_overlaps(bad, targets), lambda: ctx.count_overlaps(reads, bad), lambda: ctx.interval_join(reads, bad),
-                 lambda: ctx.merge(bad), lambda: ctx.nearest(bad, targets)):
+    s = br.Session(0)
+    s.set_strict_null_contigs(True)
+    for call in (lambda: s.count_overlaps(bad, targets), lambda: s.count_overlaps(reads, bad), lambda: s.interval_join(reads, bad),
+                 lambda: s.merge(bad), lambda: s.nearest(bad, targets)):
         with pytest.raises(br.BioRangesError, match=r"contains a NULL at row 1; NULL contigs are not supported"):
             call()
+    s.close()
+
+
+def test_null_contigs_as_the_reference_treats_them(ctx):
+    """Default mode (parity unpinned by the reference's tests, bio_ranges_host.h): the table functions key a NULL slot by
+    the bytes its offsets span -- "" for arrays made by the Arrow builders --, the join treats NULL as a key of its own
+    that equals only NULL (create_hashes), also in the streamed form."""
+    i64 = pa.int64()
+    a = pa.table({"contig": pa.array(["chr1", None, "", None]), "pos_start": pa.array([1, 5, 5, 100], i64), "pos_end": pa.array([9, 8, 8, 200], i64)})
+    b = pa.table({"contig": pa.array([None, "", "chr1"]), "pos_start": pa.array([6, 6, 6], i64), "pos_end": pa.array([7, 7, 7], i64)})
+    # count_overlaps(b rows against a): NULL == "" there -> the NULL and the "" row of b each see a's rows 1 and 2
+    got = ctx.count_overlaps(a, b)
+    assert got.column("count").to_pylist() == [2, 2, 1]
+    # join: NULL matches NULL only (b row 0 <-> a row 1), "" matches "" (b row 1 <-> a row 2), chr1 <-> chr1
+    bi, pi = ctx.interval_join(a, b)
+    assert sorted(zip(bi.to_pylist(), pi.to_pylist())) == [(0, 2), (1, 0), (2, 1)]
+    js = ctx.join_stream(a, coalesce_rows=1)
+    res = js.push(b) + js.finish()
+    pairs = sorted((x, y) for r in res for x, y in zip(r["build_idx"].to_pylist(), r["probe_idx"].to_pylist()))
+    assert pairs == [(0, 2), (1, 0), (2, 1)]
+    js.close()
 
 
 def test_session_metrics_and_memory_limit(golden):

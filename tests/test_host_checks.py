@@ -55,14 +55,17 @@ def test_sliced_batches_respect_offsets():
     assert br.check_position_column(t, "p") is None
 
 
-def test_contig_column_types_and_null_contigs():
+def test_contig_column_types_and_null_contigs(monkeypatch):
     # ContigArray (array_utils.rs:10-24, :196-229): Utf8 / LargeUtf8 / Utf8View
     for ty in (pa.string(), pa.large_string(), pa.string_view()):
         assert br.check_contig_column(_t(c=pa.array(["chr1", "", "chrX"], ty)), "c") is None
     assert "expected Utf8, LargeUtf8, or Utf8View" in br.check_contig_column(_t(c=pa.array([1, 2])), "c")
     assert "contig column 'q' not found in batch with columns" in br.check_contig_column(_t(c=pa.array(["a"])), "q")
-    # a NULL contig is refused, not silently keyed as "" (sliced batches: the row is counted in the slice)
+    # NULL contigs pass by default (the reference never reads the validity bitmap: bio_ranges_host.h); a strict session --
+    # here, without a GPU, the BIO_STRICT_NULL_CONTIGS switch -- refuses them (sliced batches: the row is counted in the slice)
     t = _t(c=pa.array(["chr1", "chr2", None, "chr3"]))
+    assert br.check_contig_column(t, "c") is None
+    monkeypatch.setenv("BIO_STRICT_NULL_CONTIGS", "1")
     assert br.check_contig_column(t, "c") == "contig column 'c' contains a NULL at row 2; NULL contigs are not supported"
     assert br.check_contig_column(t.slice(1), "c") == "contig column 'c' contains a NULL at row 1; NULL contigs are not supported"
     assert br.check_contig_column(t.slice(3), "c") is None
