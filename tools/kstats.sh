@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 kernel-trace stats of one python command: tools/kstats.sh <tag> <script> [args..]  -> gpurun_out/ks_<tag>_kernel_stats.csv
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
 TAG=$1; shift
 OUT=$R/gpurun_out/ks_$TAG
 mkdir -p $OUT

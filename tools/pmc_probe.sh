@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC passes over tools/probe_only.py (one counter set per run; no trace domains mixed in)
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/pmc_$1
 shift
 [ $# -gt 0 ] && export "$@"
@@ -9,7 +9,7 @@ mkdir -p $OUT
 i=0
 while read -r set; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -- python3 $R/tools/probe_only.py > $OUT/p$i.log 2>&1 || echo "pass $i failed"
+  rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -- python3 $R/tools/probe_only.py </dev/null > $OUT/p$i.log 2>&1 || echo "pass $i failed"
 done <<SETS
 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY
 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_INSTS_VMEM_WR GRBM_GUI_ACTIVE

@@ -3,15 +3,15 @@
 #   tools/pmc_run.sh <tag> <script> [args..]   -> gpurun_out/pmc_<tag>/summary.txt
 # per kernel: launches, mean FETCH_SIZE / WRITE_SIZE (KB) and the HBM bytes per launch = 2 * FETCH + WRITE (the gfx950
 # correction of MI355X_MICROARCH.md "HBM": FETCH_SIZE tallies 64 B per 128-B request of a wide streaming read)
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
 TAG=$1; shift
 OUT=$R/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 i=0
 while read -r set; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -- python3 $R/"$@" > $OUT/p$i.log 2>&1 || echo "pass $i failed"
+  rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -- python3 $R/"$@" </dev/null > $OUT/p$i.log 2>&1 || echo "pass $i failed"
 done <<SETS
 FETCH_SIZE
 WRITE_SIZE
