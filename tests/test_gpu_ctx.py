@@ -93,11 +93,17 @@ def test_trim_gives_scratch_back_to_the_device():
     a.trim(1 << 20)
     assert a.reserved_bytes() <= 1 << 20
     a.set_memory_limit(held // 4)                                 # the trimmed context would have to reserve it all again
-    with pytest.raises(pyivx.IvxError) as ei:
-        a.merge(k, s64, e64, n_keys=24)
-    assert ei.value.status == pyivx.ERR_OOM
+    def status_of_merge():                                         # (no exception object kept: its traceback would hold the call's output buffers)
+        try:
+            a.merge(k, s64, e64, n_keys=24)
+        except pyivx.IvxError as ex:
+            return ex.status
+        return pyivx.OK
+    assert status_of_merge() == pyivx.ERR_OOM
     a.set_memory_limit(0)
     a.trim(0)
+    import gc
+    gc.collect()
     torch.cuda.empty_cache()
     assert free0 - torch.cuda.mem_get_info()[0] < held // 8       # the device has the bytes back
     b = _ctx()
