@@ -48,7 +48,7 @@ HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # HBM bytes per step measured with rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE, the gfx950 correction of
 # MI355X_MICROARCH.md "HBM"), summed over the step's kernels; valid only for the kernels named next to it, so the
 # figure is dropped from the line when the pipeline's kernels change (PIPELINE below is what the library runs today)
-PIPELINE = "k_part_onepass + k_probe_regions<fill, paged>"
+PIPELINE = "k_part_onepass + k_fill_fast + k_fill_rest"
 PMC_TRAFFIC = {"join_100Mx1M_24contigs": {"bytes": None, "source": None, "pipeline": PIPELINE}}
 for _name in ("r2_bench_traffic.json", "r3_bench_traffic.json"):
     _pmc = os.path.join(ROOT, "profiles", _name)

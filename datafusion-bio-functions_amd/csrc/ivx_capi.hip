@@ -429,7 +429,7 @@ static ivx_status overlap_common(ivx_ctx *ctx, const ivx_index *ix, int mem, int
         KernelTimer t(ctx);
         if (regions) {
             if (!planned) pl.valid = false;                 // whatever an earlier count call left is gone now
-            const ivx_status st = ivx_join_probe_regions(ctx, ix->jv, ix->jv_nreg, mode, dk, ds, de, n, d_b, d_p, cap, ctx->d_scalars, planned, ix->jv_filter, ix->jv_pk24);
+            const ivx_status st = ivx_join_probe_regions(ctx, ix->jv, ix->jv_nreg, mode, dk, ds, de, n, d_b, d_p, cap, ctx->d_scalars, planned, ix->jv_filter, ix->jv_pk24, ix->jv_fast);
             if (st != IVX_OK) { pl.valid = false; return st; }
             if (mode == JP_COUNT && pl.valid) { memcpy(pl.in, in, sizeof(in)); pl.mem = mem; pl.n = n; pl.ix = ix; pl.ix_serial = ix->serial; pl.stream = ctx->stream; }
         }

@@ -59,6 +59,7 @@ struct ivx_join_plan {
     // ptab = [region][page slot] -> page + 1
     bool paged = false, packed = false;   // packed: 8-byte routed rows (start in region | length | row), else (start,end) + row id
     const u32 *ptab = nullptr; u32 pstride = 0, lgpg = 0, rowbits = 32;
+    void *rest = nullptr;                 // the lean fill kernel's list of batches left to the generic walk (scratch, in `slots`)
     bool all_routed = false;              // no occupancy bitmap in use: every row was routed (the fill's rows-per-lane rule is then known on the host)
 };
 
@@ -132,7 +133,9 @@ struct ivx_ent { i32 s, e; u32 row; };          // 12-byte AoS entry of the over
 enum { HDR_SH0 = 0, HDR_NLEV = 1, HDR_NBINS = 2, HDR_CS = 3 /* log2(cells per region) or ~0u */, HDR_NREG = 4,
        HDR_RCELLS = 5 /* cells per region */, HDR_RMUL_LO = 6, HDR_RMUL_HI = 7 /* ceil(2^40 / cells per region) */, HDR_LEVCNT = 8 /* .. +IVX_MAXL */,
        HDR_FG = 8 + IVX_MAXL /* log2(block width) of the occupancy bitmap, or ~0u: no bitmap */, HDR_FBITS = 9 + IVX_MAXL /* its size in bits */,
-       HDR_PK24 = 10 + IVX_MAXL /* 1: a region spans at most 2^24 coordinates (routed rows pack into 8 bytes) */, HDR_WORDS = 11 + IVX_MAXL };
+       HDR_PK24 = 10 + IVX_MAXL /* 1: a region spans at most 2^24 coordinates (routed rows pack into 8 bytes) */,
+       HDR_SLOW = 11 + IVX_MAXL /* 0: every region is ONE LDS-resident level (all build rows in level 0, every slice fits): the lean fill probe applies */,
+       HDR_WORDS = 12 + IVX_MAXL };
 // Occupancy bitmap of the build side ("can a probe row match anything at all"): per key one bit per 2^g-wide block of
 // [origin, origin + span] plus one overflow block behind it; a bit is set when some build row touches the block.  Sized to
 // stay resident in an XCD's 4 MiB L2 next to the streamed probe rows.
@@ -211,6 +214,7 @@ struct ivx_index {
     u32 jv_nreg = 0;            // >0: the region-partitioned probe is available
     bool jv_filter = false;     // jv carries an occupancy bitmap (hdr[HDR_FG] != ~0u)
     bool jv_pk24 = false;       // hdr[HDR_PK24]
+    bool jv_fast = false;       // !hdr[HDR_SLOW]
     RankGridView gs{}, ge{};
     CoverageView cv{};
     NearestView nv{};
@@ -239,7 +243,8 @@ enum { JP_COUNT = 0, JP_PER_ROW = 1, JP_EXISTS = 2, JP_FILL = 3 };
 // join_regions.hip: partition the probe rows by index region, probe each region from LDS
 ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nreg, int mode,
                                   const u32 *key, const i32 *s, const i32 *e, u64 n,
-                                  u32 *ob, u32 *op, u64 cap, u64 *d_cursor, bool planned = false, bool has_filter = false, bool pk24 = false);
+                                  u32 *ob, u32 *op, u64 cap, u64 *d_cursor, bool planned = false, bool has_filter = false, bool pk24 = false,
+                                  bool fast = false);
 
 // per-row-output operators through the same partition (count_overlaps: jv over the build rows, no row with
 // end < start; coverage: jv over the merged nodes)

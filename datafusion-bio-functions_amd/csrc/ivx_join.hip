@@ -254,10 +254,15 @@ __global__ __launch_bounds__(1024) void k_join_layout(const i32 *kmin, const i32
 }
 
 // one thread per probe region: the level-0 cell window a workgroup stages for it and its entry range
-__global__ __launch_bounds__(256) void k_join_regdesc(const i32 *origin, const u32 *span, const u32 *lbase, const u32 *hdr,
+__global__ __launch_bounds__(256) void k_join_regdesc(const i32 *origin, const u32 *span, const u32 *lbase, u32 *hdr,
                                                       const u32 *kreg, const u32 *rkey, const u32 *binstart, ivx_regdesc *rdesc)
 {
     const u32 r = threadIdx.x + blockIdx.x * 256;
+    if (r == 0) {                                               // rows outside level 0: the regions are not one LDS-resident level
+        bool upper = hdr[HDR_LEVCNT] == 0;
+        for (u32 l = 1; l < hdr[HDR_NLEV]; l++) upper |= hdr[HDR_LEVCNT + l] != 0;
+        if (upper) hdr[HDR_SLOW] = 1u;
+    }
     if (r >= hdr[HDR_NREG]) return;
     const u32 sh0 = hdr[HDR_SH0];
     const u64 R = hdr[HDR_RCELLS];
@@ -273,6 +278,7 @@ __global__ __launch_bounds__(256) void k_join_regdesc(const i32 *origin, const u
     d.e0 = binstart[d.lb + d.slo];
     d.ne = binstart[d.lb + d.shi] - d.e0;
     d.rbase = (i32)((i64)d.origin + (i64)(rc0w << sh0));           // (rc0 < cells0: at most the key's largest start)
+    if (d.ne > IVX_RP_ECAP || d.shi - d.slo + 1u > 8192u + IVX_RP_HALO + 2u) hdr[HDR_SLOW] = 1u;   // the slice does not fit LDS (ivx_join_regions.hip)
     rdesc[r] = d;
 }
 
@@ -590,6 +596,7 @@ ivx_status ivx_join_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32
     ix->jv_nreg = ((const u32 *)(ctx->h_scalars + 32))[HDR_NREG];
     ix->jv_filter = ((const u32 *)(ctx->h_scalars + 32))[HDR_FG] != 0xFFFFFFFFu;
     ix->jv_pk24 = ((const u32 *)(ctx->h_scalars + 32))[HDR_PK24] != 0;
+    ix->jv_fast = ((const u32 *)(ctx->h_scalars + 32))[HDR_SLOW] == 0 && ix->jv_nreg > 0;
     if (want_route) ivx_route_view_ready(ctx, ix);
 
     ix->jv.origin = origin; ix->jv.span = span; ix->jv.kcnt = kcnt; ix->jv.lbase = lbase;

@@ -949,7 +949,7 @@ __global__ void k_pick_rows(const u32 *__restrict__ rfirst, u32 nreg, u64 hint, 
 {
     const u32 routed = rfirst[nreg];
     const float per_row = (float)((double)hint / (double)(routed ? routed : 1u));
-    *bsel = force ? force : per_row <= 0.45f ? 8u : per_row <= 0.9f ? 4u : per_row <= 1.8f ? 2u : 1u;
+    *bsel = force ? force : per_row <= 0.40f ? 8u : per_row <= 0.8f ? 4u : per_row <= 1.6f ? 2u : 1u;
 }
 
 template <int MODE, int B, bool IDENT, bool PAGED = false, bool PK = false>
@@ -1155,6 +1155,294 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
     if (FILL && round && !(dbg & 32)) round_copy_out(L, pend_mine, pend_start, round - 1, wv, ob, op, cap, dbg);
 }
 
+// ------------------------------------------------------------------ lean fill probe (round 3)
+// The headline's fill pass again, for the case it always meets: packed 8-byte rows in region pages (k_part_onepass) and an
+// index whose every region is one LDS-resident level (hdr[HDR_FAST]).  Same slices, same staging ring and round-level
+// output reservation as k_probe_regions<fill>; what differs is what a wavefront executes per row -- that kernel is bound
+// by the instructions it issues, 224 per 64 rows:
+//  * work is dealt in CHUNKS of 8192 routed rows that never straddle a pool page (chunk k of region r = its virtual rows
+//    [8192 k, 8192 (k + 1)); wavefront w owns rows [512 w, 512 (w + 1)) of it), so the rows of a wavefront batch are
+//    64 * B consecutive words behind ONE wave-uniform pointer: loads are `scalar base + lane offset + immediate`, with no
+//    per-row bounds test, page lookup or 64-bit address arithmetic (a third of the old kernel's instructions);
+//  * the walk is the 32-bit packed-row form only, staged as (slot, probe row): the slot -> build row lookup happens once per
+//    64 pairs in the copy-out, not per match inside the divergent loop; the cell offsets of all B rows are fetched before
+//    the first candidate loop runs;
+//  * rows the packed form cannot carry (escapes, rows reaching past the slice's halo) and batches that overflow the ring
+//    send their whole batch through the generic walk + direct write of k_probe_regions (cold code, out of line);
+//  * the last wavefront to arrive in a round leaves every wavefront's output position, not just the round's base.
+constexpr u32 FP_CHUNK = (u32)RP_W * IVX_WAVE * 8u;              // 8192 rows
+
+// first routed row (rfirst) and first chunk (cfirst) of every region; nreg <= IVX_MAXREG_WIDE
+__global__ __launch_bounds__(1024) void k_chunk_bounds(const u32 *__restrict__ rcur, u32 nreg, u32 *__restrict__ rfirst, u32 *__restrict__ cfirst)
+{
+    __shared__ u32 red[1024 / IVX_WAVE + 1];
+    const u32 t = threadIdx.x;
+    const u32 rows = t < nreg ? rcur[t] : 0u;
+    u32 tot;
+    const u32 ex = block_excl_scan<u32, 1024>(rows, red, &tot);
+    if (t < nreg) rfirst[t] = ex;
+    if (t == 0) rfirst[nreg] = tot;
+    __syncthreads();
+    const u32 ec = block_excl_scan<u32, 1024>((rows + FP_CHUNK - 1) / FP_CHUNK, red, &tot);
+    if (t < nreg) cfirst[t] = ec;
+    if (t == 0) cfirst[nreg] = tot;
+}
+
+// Rows the lean kernel does not take: region, first virtual row, rows -- ONE row the packed form cannot carry (an escape, or
+// a row that reaches past its slice's halo; listed by its lane, the rest of its batch goes the fast way), or a whole batch
+// that found more pairs than the ring holds (nothing of it stays staged).  k_fill_fast appends them to a list; k_fill_rest
+// walks the listed rows afterwards with the generic gather walk -- the lean kernel holds no generic code (and no scratch).
+struct FpRest { u32 r, first, cnt, pad; };
+// the two lists live in one scratch buffer: batches first (at most one per wavefront batch), then single rows (at most n)
+__host__ __device__ __forceinline__ u64 fp_max_batches(u64 n, u32 nreg) { return ((n >> 13) + nreg + 1) * (u64)(RP_W * 8); }
+
+template <int B>
+__global__ __launch_bounds__(RP_T) void k_fill_fast(JoinIndexView ix, const u64 *__restrict__ pool, const u32 *__restrict__ rcur,
+                                                    const u32 *__restrict__ cfirst, PageTab pt, u32 *__restrict__ ob, u32 *__restrict__ op, u64 cap,
+                                                    unsigned long long *cursor, const u32 *bsel, u32 rowbits, FpRest *__restrict__ rest, u64 *__restrict__ rest_rows, u32 *rest_n)
+{
+    if (bsel != nullptr && *bsel != (u32)B) return;                   // (every B is launched; k_pick_rows chose one)
+    constexpr u32 WB = IVX_WAVE * B;                                  // rows of a wavefront batch
+    constexpr u32 SUB = 8u / B;                                       // batches a wavefront makes of its 512 rows of a chunk
+    IVX_PROBE_LDS(true)
+    __shared__ u32 s_cfirst[IVX_MAXREG_WIDE + 2];
+    __shared__ u32 s_wat[RP_NSLOT][RP_W];                             // a wavefront's output position inside its round's range
+    const u32 wv = __builtin_amdgcn_readfirstlane(threadIdx.x / IVX_WAVE), ln = lane_id();
+    const u32 nreg = ix.hdr[HDR_NREG];
+    for (u32 t = threadIdx.x; t <= nreg; t += RP_T) s_cfirst[t] = cfirst[t];
+    __syncthreads();
+    const u32 nchunk = s_cfirst[nreg];
+    const u32 c_lo = (u32)((u64)nchunk * blockIdx.x / gridDim.x), c_hi = (u32)((u64)nchunk * (blockIdx.x + 1) / gridDim.x);
+    if (c_lo >= c_hi) return;
+    const u32 rowmask = rowbits >= 32 ? 0xFFFFFFFFu : (1u << rowbits) - 1u;
+    const u32 maxlen = pk_maxlen(rowbits);
+    const u32 pmask = (1u << pt.lgpg) - 1u;
+    Slice S;
+    slice_init(ix, S, L);
+    u32 r_next;                                                       // region of the batch in flight
+    {   // last region whose first chunk is <= c_lo
+        u32 a = 0, b = nreg;
+        while (a < b) { const u32 m = (a + b + 1) >> 1; if (s_cfirst[m] <= c_lo) a = m; else b = m - 1; }
+        r_next = a;
+    }
+    // batch i of this wavefront: its region, first virtual row and row count are wave-uniform, its rows 64 * B consecutive
+    // words of one pool page
+    const u32 nbatch = (c_hi - c_lo) * SUB;
+    u64 nx[B];
+    u32 ncnt = 0, nfirst = 0;
+    auto prefetch = [&](u32 i) {
+        const u32 c = c_lo + i / SUB, sb = i % SUB;
+        while (c >= s_cfirst[r_next + 1]) r_next++;
+        nfirst = (c - s_cfirst[r_next]) * FP_CHUNK + wv * (8u * IVX_WAVE) + sb * WB;
+        const u32 rows = rcur[r_next];
+        ncnt = rows > nfirst ? (rows - nfirst < WB ? rows - nfirst : WB) : 0u;
+        if (ncnt) {
+            const u32 pg = pt.ptab[(u64)r_next * pt.pstride + (nfirst >> pt.lgpg)] - 1u;
+            const u64 *src = pool + (((u64)pg << pt.lgpg) + (nfirst & pmask));
+#pragma unroll
+            for (int q = 0; q < B; q++) nx[q] = src[q * IVX_WAVE + ln];      // (inside the page whatever ncnt is: pages are whole)
+        }
+    };
+    prefetch(0);
+    u32 loaded_r = 0xFFFFFFFFu;
+    u32 round = 0;
+    u32 pend_mine = 0;                                                // pairs the previous round staged (in its half of the ring)
+    // The ring is two halves of RP_RING / 2 pairs; round r stages into half r & 1 from the half's start, so nothing a round
+    // does can touch the previous round's pairs (which wait in the other half for their copy-out) and the walk needs no
+    // per-pair room test: a round that finds more pairs than a half holds wraps over its own pairs, is recognised by its count
+    // and goes to the rest list.  The position inside the half is wave-private state in a scalar register (ranks by ballot: no
+    // LDS atomic, no wait per match); the candidate loops are wave-uniform -- every lane stays in until the longest list is
+    // done, its steps predicated -- so that the position is one value for the wavefront by construction.
+    constexpr u32 HALF = RP_RING / 2;
+    // copy this wavefront's staged pairs of round pr out: (slice slot as the LDS address of its entry, packed row word) ->
+    // (build row, probe row)
+    auto copy_out = [&](u32 pr) {
+        const u32 sl = pr % RP_NSLOT;
+        while (__hip_atomic_load(&L.s_ready[sl], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != pr + 1u) __builtin_amdgcn_s_sleep(1);
+        if (!pend_mine) return;
+        const u64 base = L.s_base[sl];
+        const u32 tot = s_wat[sl][RP_W - 1] + L.s_wcnt[sl][RP_W - 1];
+        if (base + tot > cap) return;                                 // the caller's buffers are too small: nothing of the round is written
+        const u64 g = base + s_wat[sl][wv];
+        u32 *ob_w = ob + g, *op_w = op + g;
+        const uint2 *half = (const uint2 *)L.s_q[wv] + (pr & 1u) * HALF;
+        for (u32 t = ln; t < pend_mine; t += IVX_WAVE) {
+            const uint2 x = half[t];
+            ob_w[t] = L.s_row[x.x]; op_w[t] = x.y & rowmask;
+        }
+    };
+    for (u32 i = 0; i < nbatch; i++) {
+        const u32 r = r_next, cnt = ncnt, first = nfirst;
+        if (r != loaded_r) {
+            // the ring holds slice slots: whatever is still staged leaves before the slice changes
+            if (round) { copy_out(round - 1u); pend_mine = 0; }
+            slice_load(ix, S, L, r, true);
+            loaded_r = r;
+        }
+        // ---- decode the batch in flight, start the next one
+        const bool full = cnt == WB;
+        u32 rel[B], len[B], roww[B];
+#pragma unroll
+        for (int q = 0; q < B; q++) {
+            const u32 lo32 = (u32)nx[q], hi32 = (u32)(nx[q] >> 32);
+            rel[q] = lo32 & 0xFFFFFFu;
+            len[q] = (lo32 >> 24) | ((rowbits < 32 ? (hi32 >> rowbits) & 0xFFu : 0u) << 8);
+            roww[q] = hi32;                                              // (the row id is masked out of it in the copy-out, 64 pairs at a time)
+        }
+        if (i + 1 < nbatch) prefetch(i + 1);
+        // ---- cells: of all B rows first (their LDS reads are in flight together), then the candidate loops
+        const u32 sh0 = S.sh0, off = S.off, cmax = S.cmax, ncm1 = S.ncm1;
+        const i32 rbase = S.rbase;
+        u32 ca[B], cb[B], slow = 0;
+#pragma unroll
+        for (int q = 0; q < B; q++) {
+            const u32 t = ((rel[q] + 1u) >> sh0) + off;                  // first cell a matching build row can start in: one cell back
+            const u32 bl0 = (t > 1u ? t : 1u) - 1u;
+            const u32 bh0 = ((rel[q] + len[q]) >> sh0) + off;
+            const u32 bh = bh0 < cmax ? bh0 : cmax;
+            bool bad = len[q] == maxlen || bh >= ncm1;                   // escape, or past the slice's halo: the rest list's
+            if (!full) {                                                 // (wave-uniform: only a region's last batch is short)
+                const bool ok = (u32)q * IVX_WAVE + ln < cnt;
+                if (ok && bad) slow |= 1u << q;
+                bad |= !ok;
+            } else if (bad) slow |= 1u << q;
+            // no row to walk: an empty range (twice the same offset); a row behind the key's last cell gets one by the clamp
+            const u32 e1 = bad ? 0u : bh + 1u;
+            const u32 bl = bl0 < e1 ? bl0 : e1;
+            ca[q] = L.s_off[bl];
+            cb[q] = L.s_off[e1];
+        }
+        u32 wpos = 0;                                                    // pairs of this round so far (scalar)
+        uint2 *half = (uint2 *)L.s_q[wv] + (round & 1u) * HALF;
+#ifndef IVX_FP_IL
+#define IVX_FP_IL 1
+#endif
+        constexpr int IL = B >= IVX_FP_IL ? IVX_FP_IL : B;
+#pragma unroll
+        for (int q0 = 0; q0 < B; q0 += IL) {
+            i32 qs[IL], qe[IL]; const u64 *pj[IL], *pe[IL];
+#pragma unroll
+            for (int u = 0; u < IL; u++) {
+                qs[u] = (i32)((u32)rbase + rel[q0 + u]); qe[u] = (i32)((u32)qs[u] + len[q0 + u]);
+                pj[u] = L.s_ent + ca[q0 + u];
+#if defined(IVX_FP_ABL) && IVX_FP_ABL >= 2
+                pe[u] = pj[u] + ((cb[q0 + u] ^ roww[q0 + u]) == 0x12345u ? 1u : 0u);     // (profiling: no candidate loop; the cell lookups stay live)
+#else
+                pe[u] = L.s_ent + cb[q0 + u];
+#endif
+            }
+            for (;;) {
+                bool act[IL], any = false;
+#pragma unroll
+                for (int u = 0; u < IL; u++) { act[u] = pj[u] < pe[u]; any |= act[u]; }
+                if (__builtin_amdgcn_ballot_w64(any) == 0) break;
+                u64 x[IL];
+#pragma unroll
+                for (int u = 0; u < IL; u++) x[u] = *pj[u];              // (a lane past its list reads on inside LDS; its result is not used)
+#pragma unroll
+                for (int u = 0; u < IL; u++) {
+                    const bool hit = act[u] && (i32)(u32)x[u] <= qe[u] && (i32)(u32)(x[u] >> 32) >= qs[u];
+                    const u64 mm = __builtin_amdgcn_ballot_w64(hit);
+#if defined(IVX_FP_ABL) && IVX_FP_ABL == 1
+                    wpos += (u32)__popcll(mm);
+#else
+                    if (mm != 0) {
+                        if (hit) half[(wpos + mask_rank(mm)) & (HALF - 1)] = make_uint2((u32)(pj[u] - L.s_ent), roww[q0 + u]);
+                        wpos += (u32)__popcll(mm);
+                    }
+#endif
+                    pj[u]++;
+                }
+            }
+        }
+        u32 got = wpos;
+        // more pairs than the half holds: nothing of this batch counts as staged
+        const bool skip = got > HALF;
+        if (__builtin_expect(skip, 0)) {
+            // (as 64-row pieces: each gets a wavefront of its own in k_fill_rest)
+            if (ln < B && ln * IVX_WAVE < cnt) rest[atomicAdd(rest_n, 1u)] = FpRest{r, first + ln * IVX_WAVE, cnt - ln * IVX_WAVE < IVX_WAVE ? cnt - ln * IVX_WAVE : (u32)IVX_WAVE, 0u};
+            got = 0;
+        } else if (__builtin_expect(slow != 0, 0)) {                     // this lane's slow rows, one by one (their cell ranges were empty)
+#pragma unroll
+            for (int q = 0; q < B; q++)
+                if ((slow >> q) & 1u) rest_rows[atomicAdd(rest_n + 1, 1u)] = (u64)(first + (u32)q * IVX_WAVE + ln) | ((u64)r << 32);
+        }
+        // ---- publish the round's count; the last wavefront to arrive reserves the round's output range
+#if defined(IVX_FP_ABL) && IVX_FP_ABL >= 3
+        if (got == 0x7654321u) ob[got] = got;
+        continue;
+#endif
+        if (ln == 0) {
+            const u32 sl = round % RP_NSLOT;
+            L.s_wcnt[sl][wv] = got;
+            const u32 before = __hip_atomic_fetch_add(&L.s_arrive[sl], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (before == RP_W - 1) {
+                u32 tot = 0;
+#pragma unroll
+                for (int w = 0; w < RP_W; w++) { s_wat[sl][w] = tot; tot += L.s_wcnt[sl][w]; }
+                L.s_base[sl] = tot ? atomicAdd(cursor, (unsigned long long)tot) : 0ull;
+                __hip_atomic_store(&L.s_arrive[sl], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_store(&L.s_ready[sl], round + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        if (round) copy_out(round - 1u);                              // the previous round's pairs: its base has long arrived
+        pend_mine = got; round++;
+    }
+    if (round) copy_out(round - 1u);
+}
+
+// What k_fill_fast left: single rows (one lane each) and whole batches (one wavefront each, 64 rows at a time); coordinates
+// from the packed word or -- escapes -- the input columns, the generic walk over the index in global memory (count, one
+// output reservation per 64 rows, write).
+__global__ __launch_bounds__(256) void k_fill_rest(JoinIndexView ix, const u64 *__restrict__ pool, PageTab pt, const FpRest *__restrict__ rest,
+                                                   const u64 *__restrict__ rest_rows, const u32 *__restrict__ rest_n, u32 *__restrict__ ob,
+                                                   u32 *__restrict__ op, u64 cap, unsigned long long *cursor, const i32 *__restrict__ ps_in,
+                                                   const i32 *__restrict__ pe_in, u32 rowbits)
+{
+    const u32 nbat = rest_n[0], nrow = rest_n[1];
+    if (nbat == 0 && nrow == 0) return;
+    const u32 wpb = blockDim.x / IVX_WAVE, ln = lane_id();
+    const u32 rowmask = rowbits >= 32 ? 0xFFFFFFFFu : (1u << rowbits) - 1u;
+    const u32 maxlen = pk_maxlen(rowbits);
+    const u32 pmask = (1u << pt.lgpg) - 1u;
+    const u32 sh0 = ix.hdr[HDR_SH0], nlev = ix.hdr[HDR_NLEV];
+    // 64 routed rows, one per lane: (region, virtual row) or nothing
+    auto rows64 = [&](bool ok, u32 r, u32 v) {
+        i32 qs = 0, qe = -1; u32 row = 0, k = 0;
+        if (ok) {
+            const u32 pg = pt.ptab[(u64)r * pt.pstride + (v >> pt.lgpg)] - 1u;
+            const u64 x = pool[((u64)pg << pt.lgpg) + (v & pmask)];
+            const u32 lo32 = (u32)x, hi32 = (u32)(x >> 32);
+            const u32 len = (lo32 >> 24) | ((rowbits < 32 ? (hi32 >> rowbits) & 0xFFu : 0u) << 8);
+            row = hi32 & rowmask;
+            k = ix.rkey[r];
+            if (len == maxlen) { qs = ps_in[row]; qe = pe_in[row]; }
+            else { qs = (i32)((u32)ix.rdesc[r].rbase + (lo32 & 0xFFFFFFu)); qe = (i32)((u32)qs + len); }
+        }
+        u32 m = 0;
+        if (ok) walk(ix, sh0, 0, nlev, k, qs, qe, [&](u32) { m++; });
+        const u32 inc = wave_incl_scan(m);
+        const u32 tot = __shfl(inc, IVX_WAVE - 1, IVX_WAVE);
+        if (tot == 0) return;
+        unsigned long long g = 0;
+        if (ln == 0) g = atomicAdd(cursor, (unsigned long long)tot);
+        g = __shfl(g, 0, IVX_WAVE);
+        if (g + tot > cap) return;                                       // (the count still tells the caller what it needs)
+        u64 at = g + inc - m;
+        if (m) walk(ix, sh0, 0, nlev, k, qs, qe, [&](u32 brow) { ob[at] = brow; op[at] = row; at++; });
+    };
+    const u32 wave = blockIdx.x * wpb + threadIdx.x / IVX_WAVE, nwave = gridDim.x * wpb;
+    for (u32 i0 = wave * IVX_WAVE; i0 < nrow; i0 += nwave * IVX_WAVE) {
+        const bool ok = i0 + ln < nrow;
+        const u64 e = ok ? rest_rows[i0 + ln] : 0ull;
+        rows64(ok, (u32)(e >> 32), (u32)e);
+    }
+    for (u32 b = wave; b < nbat; b += nwave) {
+        const FpRest w = rest[b];
+        for (u32 t0 = 0; t0 < w.cnt; t0 += IVX_WAVE) rows64(t0 + ln < w.cnt, w.r, w.first + t0 + ln);
+    }
+}
+
 // ------------------------------------------------------------------ match-dense fill: count, scan, write
 // With several pairs per probe row the staging ring holds only one 64-row batch per wavefront and the 16
 // wavefronts of a workgroup end up in lock step, round after round.  For such joins the pairs are written in two
@@ -1345,7 +1633,8 @@ static inline int fill_rows_per_lane(u64 cap, u64 n)
 {
     if (const char *f = getenv("IVX_RP_ROWS")) return atoi(f);             // experiments
     const double per_row = (double)cap / (double)n;
-    return per_row <= 0.45 ? 8 : per_row <= 0.9 ? 4 : per_row <= 1.8 ? 2 : 1;
+    // (a round's pairs must fit half a staging ring: 64 * rows per lane * pairs per row <= ~205 of its 256, four sigma below it)
+    return per_row <= 0.40 ? 8 : per_row <= 0.8 ? 4 : per_row <= 1.6 ? 2 : 1;
 }
 
 // rows one partition workgroup takes: 1, 2 or 4 tiles, so that mid-size batches still spread over all CUs
@@ -1882,7 +2171,7 @@ ivx_status probe_two_level(ivx_ctx *ctx, const JoinIndexView &jv, int mode, u32 
 
 ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nreg, int mode,
                                   const u32 *key, const i32 *s, const i32 *e, u64 n,
-                                  u32 *ob, u32 *op, u64 cap, u64 *d_cursor, bool planned, bool has_filter, bool pk24)
+                                  u32 *ob, u32 *op, u64 cap, u64 *d_cursor, bool planned, bool has_filter, bool pk24, bool fast)
 {
     if (n == 0) return IVX_OK;
     ivx_join_plan &pl = ctx->join_plan;
@@ -1899,6 +2188,8 @@ ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nre
     if ((planned && pl.paged) || (!planned && !two_pass)) {
         const bool wide = nreg > IVX_MAXREG;
         PageTab pt; const u32 *rfirst; const u64 *pool_se; const u32 *pool_row;
+        u32 *ctl;                                                       // rcur[1024] | pool_next, rest_n | rfirst[<= 1025] | cfirst[<= 1025]
+        void *rest_buf = nullptr;                                       // batches the lean fill kernel leaves to the generic walk (FpRest)
         bool all_routed = false;
         // 8-byte routed rows whenever a region's coordinates fit 24 bits (IVX_PACK=0: the 12-byte form, for A/B runs and tests)
         const bool pack_off = getenv("IVX_PACK") && !strcmp(getenv("IVX_PACK"), "0");
@@ -1909,17 +2200,19 @@ ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nre
             rowbits = pl.rowbits;
             pt = PageTab{const_cast<u32 *>(pl.ptab), pl.pstride, pl.lgpg};
             rfirst = pl.hist; pool_se = pl.pse; pool_row = pl.prow; packed = pl.packed; all_routed = pl.all_routed;
+            ctl = const_cast<u32 *>(pl.hist) - 1032; rest_buf = pl.rest;
             s = pl.ds; e = pl.de;                                       // (the columns the count call read: packed rows refer to them)
         } else {
             u32 lgpg = 14;                                              // a page holds at least a tile; at most ~4096 pages per region
             while (lgpg < 31 && (n >> lgpg) > 4096) lgpg++;
             const u64 pstride = (n >> lgpg) + 2;
             const u64 npages = (n >> lgpg) + nreg + 1;
-            u32 *ctl, *ptab; u64 *pse; u32 *prow = nullptr;
-            IVX_TRY(ctx->get_scratch(WS_SORTHIST, (1024 + 8 + 1032) * sizeof(u32), (void **)&ctl));   // rcur[1024] | pool_next | .. | rfirst[<= 1025]
+            u32 *ptab; u64 *pse; u32 *prow = nullptr;
+            IVX_TRY(ctx->get_scratch(WS_SORTHIST, (1024 + 8 + 1032 + 1032) * sizeof(u32), (void **)&ctl));
             IVX_TRY(ctx->get_scratch(WS_T2, (size_t)nreg * pstride * sizeof(u32), (void **)&ptab));
             IVX_TRY(ctx->get_scratch(WS_T0, (size_t)(npages << lgpg) * sizeof(u64), (void **)&pse));
             if (!packed) IVX_TRY(ctx->get_scratch(WS_T1, (size_t)(npages << lgpg) * sizeof(u32), (void **)&prow));
+            else if (fast) IVX_TRY(ctx->get_scratch(WS_T1, (size_t)fp_max_batches(n, nreg) * sizeof(FpRest) + (size_t)(n + 64) * sizeof(u64), &rest_buf));
             IVX_HIP(ctx, hipMemsetAsync(ctl, 0, (1024 + 8) * sizeof(u32), st));
             IVX_HIP(ctx, hipMemsetAsync(ptab, 0, (size_t)nreg * pstride * sizeof(u32), st));
             pt = PageTab{ptab, (u32)pstride, lgpg};
@@ -1946,11 +2239,11 @@ ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nre
 #undef IVX_ONEPASS3
 #undef IVX_ONEPASS4
 #undef IVX_ONEPASS
-            hipLaunchKernelGGL(k_page_bounds, dim3(1), dim3(1024), 0, st, (const u32 *)rcur, nreg, rf);
+            hipLaunchKernelGGL(k_chunk_bounds, dim3(1), dim3(1024), 0, st, (const u32 *)rcur, nreg, rf, rf + 1032);
             rfirst = rf; pool_se = pse; pool_row = prow;
             if (mode == JP_COUNT) {
                 pl.hist = rf; pl.pse = pse; pl.prow = prow; pl.ds = s; pl.de = e; pl.chunk = 0; pl.nblk = 1;
-                pl.paged = true; pl.packed = packed; pl.rowbits = rowbits; pl.ptab = ptab; pl.pstride = (u32)pstride; pl.lgpg = lgpg; pl.all_routed = all_routed;
+                pl.paged = true; pl.packed = packed; pl.rest = rest_buf; pl.rowbits = rowbits; pl.ptab = ptab; pl.pstride = (u32)pstride; pl.lgpg = lgpg; pl.all_routed = all_routed;
                 pl.slots = (1ull << WS_SORTHIST) | (1ull << WS_T0) | (1ull << WS_T1) | (1ull << WS_T2) | (1ull << WS_IN_START) | (1ull << WS_IN_END);
                 pl.valid = true;
             }
@@ -1966,6 +2259,24 @@ ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nre
             u32 *bsel = all_routed ? nullptr : (u32 *)(ctx->d_scalars + 11);
             const u32 force = getenv("IVX_RP_ROWS") ? (u32)atoi(getenv("IVX_RP_ROWS")) : 0u;
             if (bsel) hipLaunchKernelGGL(k_pick_rows, dim3(1), dim3(1), 0, st, rfirst, nreg, hint, force, bsel);
+            // packed rows over an index whose every region is one LDS-resident level: the lean kernel, then whatever batches it
+            // left to the generic walk (IVX_FILL=old: the general kernel, for A/B runs and the tests that pin both)
+            const bool lean_off = getenv("IVX_FILL") && !strcmp(getenv("IVX_FILL"), "old");
+            if (packed && fast && !lean_off && pt.lgpg >= 13 && rest_buf != nullptr) {
+                u32 *rest_n = ctl + 1024 + 4;                           // batches, rows
+                FpRest *rest = (FpRest *)rest_buf;
+                u64 *rest_rows = (u64 *)(rest + fp_max_batches(n, nreg));
+                {
+                    IVX_HIP(ctx, hipMemsetAsync(rest_n, 0, 2 * sizeof(u32), st));
+#define IVX_FILLF(B_) hipLaunchKernelGGL((k_fill_fast<B_>), dim3(RP_GRID), dim3(RP_T), 0, st, jv, pool_se, (const u32 *)ctl, (const u32 *)(rfirst + 1032), pt, ob, op, cap, cur, (const u32 *)bsel, rowbits, rest, rest_rows, rest_n)
+                    if (bsel) { IVX_FILLF(8); IVX_FILLF(4); IVX_FILLF(2); IVX_FILLF(1); }
+                    else switch (fill_rows_per_lane(hint, n)) { case 1: IVX_FILLF(1); break; case 2: IVX_FILLF(2); break; case 4: IVX_FILLF(4); break; default: IVX_FILLF(8); }
+#undef IVX_FILLF
+                    hipLaunchKernelGGL(k_fill_rest, dim3(512), dim3(256), 0, st, jv, pool_se, pt, (const FpRest *)rest, (const u64 *)rest_rows, (const u32 *)rest_n, ob, op, cap, cur, s, e, rowbits);
+                    IVX_HIP(ctx, hipGetLastError());
+                    return IVX_OK;
+                }
+            }
 #define IVX_FILLP2(B_, P_) hipLaunchKernelGGL((k_probe_regions<1, B_, false, true, P_>), dim3(RP_GRID), dim3(RP_T), 0, st, jv, (const void *)pool_se, (const void *)pool_row, rfirst, 1u, RP_VGRID / RP_GRID, ob, op, cap, cur, 1u, 0u, (const u32 *)nullptr, dbg, pt, (const u32 *)bsel, s, e, rowbits)
 #define IVX_FILLP(B_) do { if (packed) IVX_FILLP2(B_, true); else IVX_FILLP2(B_, false); } while (0)
             if (bsel) { IVX_FILLP(8); IVX_FILLP(4); IVX_FILLP(2); IVX_FILLP(1); }

@@ -37,8 +37,10 @@ def _check_join(ctx, bk, bs, be, pk, ps, pe, nkeys):
     # both partitions (one pass into region pages, "two": histogram + scatter) and the bitmap-filtered routing
     # "routed": rle_right / exists over probe rows routed by coordinate region, gathers from the index (big build sides)
     # "nopack": the 12-byte routed rows ((start,end) + row id) instead of the packed 8-byte ones
-    for path in ("direct", "regions", "regions-dense", "regions-nopack", "regions-nopack-dense", "regions-two", "regions-two-dense",
-                 "regions-filter", "regions-filter-dense", "routed"):
+    # "old": the general fill kernel where the lean one (k_fill_fast + k_fill_rest) would run; "ring8": eight rows per lane
+    # whatever the match density, so that match-dense batches overflow the staging ring and take the kernels' slow routes
+    for path in ("direct", "regions", "regions-dense", "regions-old", "regions-ring8", "regions-old-ring8", "regions-nopack", "regions-nopack-dense",
+                 "regions-two", "regions-two-dense", "regions-filter", "regions-filter-old", "regions-filter-dense", "routed"):
         os.environ["IVX_JOIN_PATH"] = path.split("-")[0]
         if path.startswith("regions"):
             os.environ["IVX_DENSE"] = "1" if path.endswith("dense") else "0"
@@ -46,6 +48,10 @@ def _check_join(ctx, bk, bs, be, pk, ps, pe, nkeys):
                 os.environ["IVX_PART"] = "two"
             if "-nopack" in path:
                 os.environ["IVX_PACK"] = "0"
+            if "-old" in path:
+                os.environ["IVX_FILL"] = "old"
+            if "-ring8" in path:
+                os.environ["IVX_RP_ROWS"] = "8"
         x = ixf if "-filter" in path else ix
         try:
             assert ctx.overlap_count(x, pk, ps, pe) == total, path
@@ -58,6 +64,8 @@ def _check_join(ctx, bk, bs, be, pk, ps, pe, nkeys):
             os.environ.pop("IVX_DENSE", None)
             os.environ.pop("IVX_PART", None)
             os.environ.pop("IVX_PACK", None)
+            os.environ.pop("IVX_FILL", None)
+            os.environ.pop("IVX_RP_ROWS", None)
         assert len(ob) == total and len(ob2) == total, path
         assert (pair_set(ob, op) == pair_set(want_b, want_p)).all(), path
         assert (pair_set(ob2, op2) == pair_set(want_b, want_p)).all(), path

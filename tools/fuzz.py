@@ -50,10 +50,11 @@ for it in range(iters):
     # round-2 knobs of the region path: two-pass partition, 12-byte routed rows, occupancy bitmap never / always / by the rule
     part, pack, filt = str(rng.choice(["", "", "two"])), str(rng.choice(["", "", "0"])), str(rng.choice(["", "force", "force", "0"]))
     chunks = str(rng.choice(["", "", "2", "3"]))                  # host-resident fill / count / coverage calls cut into chunks
-    for name, val in (("IVX_PART", part), ("IVX_PACK", pack), ("IVX_FILTER", filt), ("IVX_HOST_CHUNKS", chunks)):
+    fill, rpr = str(rng.choice(["", "", "old"])), str(rng.choice(["", "", "8", "2"]))   # lean / general fill kernel; rows per lane forced (ring overflow routes)
+    for name, val in (("IVX_PART", part), ("IVX_PACK", pack), ("IVX_FILTER", filt), ("IVX_HOST_CHUNKS", chunks), ("IVX_FILL", fill), ("IVX_RP_ROWS", rpr)):
         if val: os.environ[name] = val
         else: os.environ.pop(name, None)
-    tag = f"it={it} nk={nk} span={span} nb={nb} np={npr} bmean={bmean} sorted={srt} strict={strict} path={path} dense={dense!r} part={part!r} pack={pack!r} filter={filt!r} chunks={chunks!r}"
+    tag = f"it={it} nk={nk} span={span} nb={nb} np={npr} bmean={bmean} sorted={srt} strict={strict} path={path} dense={dense!r} part={part!r} pack={pack!r} filter={filt!r} chunks={chunks!r} fill={fill!r} rows={rpr!r}"
     try:
         # ---- join: count, per-row, exists, fill
         ix = ctx.build(pyivx.KIND_OVERLAP, bk, bs, be, n_keys=nk)

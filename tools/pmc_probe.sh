@@ -24,7 +24,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "k_probe" not in k and "k_part" not in k: continue
+        if "k_probe" not in k and "k_part" not in k and "k_fill" not in k: continue
         k = k.replace("(anonymous namespace)::", "").replace("void ", "")
         agg[k.split("(")[0][-40:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open("$OUT/summary.txt", "w") as o:
