@@ -424,7 +424,7 @@ static ivx_status overlap_common(ivx_ctx *ctx, const ivx_index *ix, int mem, int
     IVX_TRY(stage_out(ctx, mem, WS_OUT_B, exists, n, &d_ex));
     IVX_TRY(stage_out(ctx, mem, WS_OUT_C, bidx, cap, &d_b));
     IVX_TRY(stage_out(ctx, mem, WS_OUT_D, pidx, cap, &d_p));
-    IVX_HIP(ctx, hipMemsetAsync(ctx->d_scalars, 0, sizeof(u64), ctx->stream));
+    IVX_HIP(ctx, hipMemsetAsync(ctx->d_scalars, 0, 2 * sizeof(u64), ctx->stream));   // pair cursor | probe fault flags
     {
         KernelTimer t(ctx);
         if (regions) {
@@ -440,7 +440,14 @@ static ivx_status overlap_common(ivx_ctx *ctx, const ivx_index *ix, int mem, int
         else IVX_TRY(ivx_join_probe(ctx, ix->jv, mode, dk, ds, de, n, d_row, d_ex, d_b, d_p, cap, ctx->d_scalars));
     }
     u64 tot = 0;
-    if (mode != JP_EXISTS) IVX_TRY(read_scalar(ctx, 0, &tot));
+    if (mode != JP_EXISTS) {
+        IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars, 2 * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+        IVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        tot = ctx->h_scalars[0];
+        // a probe kernel met a routed-row page that the partition never published (it substituted a valid page, so nothing
+        // was read out of bounds): an internal error, reported instead of returning wrong pairs
+        if (ctx->h_scalars[1]) { ctx->join_plan.valid = false; return ctx->fail(IVX_ERR_HIP, "internal error: the probe met an unpublished page of routed rows"); }
+    }
     if (mode == JP_COUNT && regions && pl.valid) pl.total = tot;
     if (total) *total = tot;
     if (mode == JP_FILL && tot > cap) return ctx->fail(IVX_ERR_CAPACITY, "pair buffers too small");   // (a plan survives this: the retry with bigger buffers reuses it)

@@ -995,7 +995,14 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
         const u64 lim = (rf + ((u64)(pg_first + RP_NPG) << pt.lgpg)) & ~63ull;   // (a cut falls between two 64-row granules)
         if (c_hi > lim) c_hi = lim;
         const u32 npg = ((u32)(c_hi - 1 - rf) >> pt.lgpg) - pg_first + 1u;
-        if (threadIdx.x < npg) s_pg[threadIdx.x] = pt.ptab[(u64)r * pt.pstride + pg_first + threadIdx.x];
+        if (threadIdx.x < npg) {
+            u32 v = pt.ptab[(u64)r * pt.pstride + pg_first + threadIdx.x];
+            // 0 = the partition never published this page (cannot happen once k_part_onepass has completed; it did in a
+            // profiling build whose switch skipped the publication, and the page "0 - 1" then was a wild address: round 2's
+            // fault).  Read page 0 instead and tell the host.
+            if (v == 0u) { v = 1u; if (cursor != nullptr) atomicOr((unsigned int *)(cursor + 1), 1u); }
+            s_pg[threadIdx.x] = v;
+        }
         __syncthreads();
     };
     auto row_se = [&](u64 i) -> u64 {
@@ -1237,7 +1244,9 @@ __global__ __launch_bounds__(RP_T) void k_fill_fast(JoinIndexView ix, const u64 
         const u32 rows = rcur[r_next];
         ncnt = rows > nfirst ? (rows - nfirst < WB ? rows - nfirst : WB) : 0u;
         if (ncnt) {
-            const u32 pg = pt.ptab[(u64)r_next * pt.pstride + (nfirst >> pt.lgpg)] - 1u;
+            u32 pg = pt.ptab[(u64)r_next * pt.pstride + (nfirst >> pt.lgpg)];
+            if (pg == 0u) { pg = 1u; if (ln == 0) atomicOr((unsigned int *)(cursor + 1), 1u); }     // never published (see pages_load): page 0, and the host is told
+            pg -= 1u;
             const u64 *src = pool + (((u64)pg << pt.lgpg) + (nfirst & pmask));
 #pragma unroll
             for (int q = 0; q < B; q++) nx[q] = src[q * IVX_WAVE + ln];      // (inside the page whatever ncnt is: pages are whole)
@@ -1338,7 +1347,14 @@ __global__ __launch_bounds__(RP_T) void k_fill_fast(JoinIndexView ix, const u64 
                 if (__builtin_amdgcn_ballot_w64(any) == 0) break;
                 u64 x[IL];
 #pragma unroll
+#if defined(IVX_FP_BCAST)
+                for (int u = 0; u < IL; u++) x[u] = L.s_ent[__builtin_amdgcn_readfirstlane((u32)(pj[u] - L.s_ent)) & 4095u];   // (profiling: one address per wavefront, no bank conflicts)
+#else
                 for (int u = 0; u < IL; u++) x[u] = *pj[u];              // (a lane past its list reads on inside LDS; its result is not used)
+#if defined(IVX_FP_DUP)
+                for (int u = 0; u < IL; u++) { u64 y = *(const volatile u64 *)(pj[u] + 1); asm volatile("" :: "v"(y)); }   // (profiling: every slice read twice)
+#endif
+#endif
 #pragma unroll
                 for (int u = 0; u < IL; u++) {
                     const bool hit = act[u] && (i32)(u32)x[u] <= qe[u] && (i32)(u32)(x[u] >> 32) >= qs[u];
@@ -1410,7 +1426,9 @@ __global__ __launch_bounds__(256) void k_fill_rest(JoinIndexView ix, const u64 *
     auto rows64 = [&](bool ok, u32 r, u32 v) {
         i32 qs = 0, qe = -1; u32 row = 0, k = 0;
         if (ok) {
-            const u32 pg = pt.ptab[(u64)r * pt.pstride + (v >> pt.lgpg)] - 1u;
+            u32 pg = pt.ptab[(u64)r * pt.pstride + (v >> pt.lgpg)];
+            if (pg == 0u) { pg = 1u; atomicOr((unsigned int *)(cursor + 1), 1u); }     // never published (see pages_load)
+            pg -= 1u;
             const u64 x = pool[((u64)pg << pt.lgpg) + (v & pmask)];
             const u32 lo32 = (u32)x, hi32 = (u32)(x >> 32);
             const u32 len = (lo32 >> 24) | ((rowbits < 32 ? (hi32 >> rowbits) & 0xFFu : 0u) << 8);
@@ -1484,7 +1502,14 @@ __global__ __launch_bounds__(RP_T) void k_probe_dense(JoinIndexView ix, const vo
         const u64 lim = (rf + ((u64)(pg_first + RP_NPG) << pt.lgpg)) & ~63ull;   // (a cut falls between two 64-row granules)
         if (c_hi > lim) c_hi = lim;
         const u32 npg = ((u32)(c_hi - 1 - rf) >> pt.lgpg) - pg_first + 1u;
-        if (threadIdx.x < npg) s_pg[threadIdx.x] = pt.ptab[(u64)r * pt.pstride + pg_first + threadIdx.x];
+        if (threadIdx.x < npg) {
+            u32 v = pt.ptab[(u64)r * pt.pstride + pg_first + threadIdx.x];
+            // 0 = the partition never published this page (cannot happen once k_part_onepass has completed; it did in a
+            // profiling build whose switch skipped the publication, and the page "0 - 1" then was a wild address: round 2's
+            // fault).  Read page 0 instead and tell the host.
+            if (v == 0u) v = 1u;                                    // (this kernel has no error word in reach: stay in bounds)
+            s_pg[threadIdx.x] = v;
+        }
         __syncthreads();
     };
     auto row_se = [&](u64 i) -> u64 {
