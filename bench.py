@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--no-ops", action="store_true", help="skip the per-operator block (count / coverage / nearest / merge / subtract / cluster / complement)")
     ap.add_argument("--ops-only", action="store_true", help="print the per-operator block alone (no join line)")
     ap.add_argument("--ops", default="count,coverage,nearest,merge,subtract,cluster,complement,big", help="operators of the block")
+    ap.add_argument("--no-build-overlap", action="store_true", help="build the index synchronously (default: ivx_ctx_set_build_overlap -- the build's tail runs beside the probe's routing pass; the build columns stay alive for the whole step, as the contract asks)")
     ap.add_argument("--check-union", action="store_true", help="strong + gather: rank 0 checks the exchanged result against a single-rank run of the whole job (rehearsals)")
     args = ap.parse_args()
 
@@ -132,6 +133,7 @@ def main():
 
     ctx = pyivx.Ctx(local_rank)                                # raises if the HIP library / gfx950 is missing
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    ctx.set_build_overlap(not args.no_build_overlap)
     gather = (args.gather or args.scaling == "strong") and not args.no_gather
     cores = min(16, len(os.sched_getaffinity(0)))              # the 1-GPU box's CPU share
 
@@ -562,7 +564,7 @@ def main():
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": args.workload, "probe_rows_per_gpu": n_probe, "build_rows_per_gpu": n_build,
                        "contigs": n_contigs, "pairs_per_gpu": pairs, "parallelism": f"partition-per-gpu x{world}" if args.scaling == "weak" else f"contigs sharded by LPT over {world} ranks",
-                       "gather": bool(gather and world > 1)},
+                       "gather": bool(gather and world > 1), "build_overlap": not args.no_build_overlap},
             # the dominant cost is the probe pipeline; the fraction is taken over build + probe device time, the metric's
             # definition; probe_only_* are the same figures without the index build
             "roofline": {"bound": "hbm", "kernel": f"index build (7 kernels) + {PIPELINE}", "achieved": achieved, "peak": HBM_PEAK_GBPS,

@@ -14,8 +14,19 @@
 
 // ------------------------------------------------------------- ctx helpers
 
+void ivx_ctx::join_tail()
+{
+    if (!tail_pending) return;
+    (void)hipStreamWaitEvent(stream, tail_ev, 0);
+    tail_pending = false;
+}
+
 ivx_status ivx_ctx::get_scratch(int slot, size_t bytes, void **out)
 {
+    // a build tail still running on the aux stream uses the build's scratch (cell ids, ranks, scan partials): whoever asks
+    // for scratch is ordered behind it first -- except for the slots a probe's routing pass takes, which the tail never
+    // touches: that pass is what runs beside the tail
+    if (tail_pending && slot != WS_SORTHIST && slot != WS_T0 && slot != WS_T1 && slot != WS_T2) join_tail();
     ivx_buf &b = scratch[slot];
     if (sub_plan.valid && ((sub_plan.slots >> slot) & 1)) sub_plan.valid = false;
     if (join_plan.valid && ((join_plan.slots >> slot) & 1)) join_plan.valid = false;
@@ -29,7 +40,7 @@ ivx_status ivx_ctx::get_scratch(int slot, size_t bytes, void **out)
                                          std::to_string(others) + " bytes reserved, limit " + std::to_string(mem_limit) + ")");
             if (others + want > mem_limit) want = bytes;
         }
-        if (b.p) { (void)hipStreamSynchronize(stream); (void)hipFree(b.p); b.p = nullptr; scratch_bytes -= b.cap; b.cap = 0; }
+        if (b.p) { (void)hipStreamSynchronize(stream); if (aux) (void)hipStreamSynchronize(aux); (void)hipFree(b.p); b.p = nullptr; scratch_bytes -= b.cap; b.cap = 0; }
         hipError_t e = hipMalloc(&b.p, want);
         if (e != hipSuccess) { want = bytes; e = hipMalloc(&b.p, want); }
         if (e != hipSuccess) { b.p = nullptr; return fail_hip("hipMalloc(scratch)", e); }
@@ -164,7 +175,7 @@ ivx_status read_scalar(ivx_ctx *ctx, int word, u64 *out)
     return IVX_OK;
 }
 
-ivx_status check_probe_args(ivx_ctx *ctx, const ivx_index *ix, int kind, int mem, const void *s, const void *e, u64 n)
+ivx_status check_probe_args(ivx_ctx *ctx, const ivx_index *ix, int kind, int mem, const void *s, const void *e, u64 n, bool defer_ready = false)
 {
     if (!ctx) return IVX_ERR_INVALID;
     if (!ix) return ctx->fail(IVX_ERR_INVALID, "null index");
@@ -174,6 +185,9 @@ ivx_status check_probe_args(ivx_ctx *ctx, const ivx_index *ix, int kind, int mem
     if (n && (!s || !e)) return ctx->fail(IVX_ERR_INVALID, "null coordinate column");
     if (n > 0xFFFFFFFFull) return ctx->fail(IVX_ERR_INVALID, "probe batch exceeds UInt32 index capacity");
     IVX_HIP(ctx, hipSetDevice(ctx->device));
+    // an index whose build tail ran beside other work is complete behind its `ready` event: this context's stream is
+    // ordered behind it here, unless the caller takes care of that itself (the region path: after its routing pass)
+    if (ix->ready != nullptr && !defer_ready) IVX_HIP(ctx, hipStreamWaitEvent(ctx->stream, ix->ready, 0));
     return IVX_OK;
 }
 
@@ -205,6 +219,15 @@ struct KernelTimer {
 
 extern "C" const char *ivx_version(void) { return "ivx-hip 0.1 (gfx950)"; }
 
+// the build tail's stream: highest priority, so that its short kernels take the workgroup slots a long routing kernel frees
+// first and are done long before that kernel is
+static bool create_aux_stream(hipStream_t *out)
+{
+    int lo = 0, hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hipStreamCreateWithPriority(out, hipStreamNonBlocking, hi) == hipSuccess) return true;
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking) == hipSuccess;
+}
+
 extern "C" ivx_status ivx_ctx_create(int device_ordinal, ivx_ctx **out)
 {
     if (!out) return IVX_ERR_INVALID;
@@ -220,11 +243,15 @@ extern "C" ivx_status ivx_ctx_create(int device_ordinal, ivx_ctx **out)
     c->device = device_ordinal;
     bool ok = hipSetDevice(device_ordinal) == hipSuccess &&
               hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) == hipSuccess &&
+              create_aux_stream(&c->aux) &&
+              hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&c->tail_ev, hipEventDisableTiming) == hipSuccess &&
               hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
               hipMalloc((void **)&c->d_scalars, 64 * sizeof(u64)) == hipSuccess &&
               hipHostMalloc((void **)&c->h_scalars, 64 * sizeof(u64), hipHostMallocDefault) == hipSuccess;
     if (!ok) { ivx_ctx_free(c); return IVX_ERR_HIP; }
     c->stream = c->own_stream;
+    if (const char *e = getenv("IVX_BUILD_OVERLAP")) c->overlap = e[0] == '1';
     *out = c;
     return IVX_OK;
 }
@@ -234,6 +261,7 @@ extern "C" void ivx_ctx_free(ivx_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->aux) (void)hipStreamSynchronize(c->aux);
     for (auto &b : c->scratch) if (b.p) (void)hipFree(b.p);
     for (auto &b : c->pinned) if (b.p) (void)hipHostFree(b.p);
     if (c->d_scalars) (void)hipFree(c->d_scalars);
@@ -241,6 +269,9 @@ extern "C" void ivx_ctx_free(ivx_ctx *c)
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    if (c->aux) (void)hipStreamDestroy(c->aux);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->tail_ev) (void)hipEventDestroy(c->tail_ev);
     delete c;
 }
 
@@ -249,6 +280,7 @@ extern "C" const char *ivx_last_error(const ivx_ctx *c) { return c ? c->err.c_st
 extern "C" ivx_status ivx_ctx_set_stream(ivx_ctx *c, void *hip_stream)
 {
     if (!c) return IVX_ERR_INVALID;
+    if (c->tail_pending) { (void)hipStreamSynchronize(c->aux); c->tail_pending = false; }
     c->stream = (hipStream_t)hip_stream;
     return IVX_OK;
 }
@@ -256,13 +288,22 @@ extern "C" ivx_status ivx_ctx_set_stream(ivx_ctx *c, void *hip_stream)
 extern "C" ivx_status ivx_ctx_use_own_stream(ivx_ctx *c)
 {
     if (!c) return IVX_ERR_INVALID;
+    if (c->tail_pending) { (void)hipStreamSynchronize(c->aux); c->tail_pending = false; }
     c->stream = c->own_stream;
+    return IVX_OK;
+}
+
+extern "C" ivx_status ivx_ctx_set_build_overlap(ivx_ctx *c, int on)
+{
+    if (!c) return IVX_ERR_INVALID;
+    c->overlap = on != 0;
     return IVX_OK;
 }
 
 extern "C" ivx_status ivx_ctx_synchronize(ivx_ctx *c)
 {
     if (!c) return IVX_ERR_INVALID;
+    if (c->tail_pending) { IVX_HIP(c, hipStreamSynchronize(c->aux)); c->tail_pending = false; }
     IVX_HIP(c, hipStreamSynchronize(c->stream));
     return IVX_OK;
 }
@@ -292,6 +333,7 @@ extern "C" ivx_status ivx_ctx_trim(ivx_ctx *c, uint64_t keep_bytes)
     if (!c) return IVX_ERR_INVALID;
     IVX_HIP(c, hipSetDevice(c->device));
     IVX_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->aux) { IVX_HIP(c, hipStreamSynchronize(c->aux)); c->tail_pending = false; }
     c->sub_plan.valid = false; c->join_plan.valid = false;      // both live in scratch slots
     while (c->scratch_bytes > keep_bytes) {
         int big = -1;
@@ -351,7 +393,8 @@ extern "C" ivx_status ivx_index_build(ivx_ctx *ctx, int kind, int mem, const uin
     if (st == IVX_OK) {
         KernelTimer t(ctx);
         switch (kind) {
-        case IVX_KIND_OVERLAP: st = ivx_join_build(ctx, ix, dk, ds, de, n); break;
+        // (overlapped tail: device-resident columns only -- staged host columns live in scratch the next call reuses)
+        case IVX_KIND_OVERLAP: st = ivx_join_build(ctx, ix, dk, ds, de, n, mem == IVX_MEM_DEVICE); break;
         case IVX_KIND_COUNT: st = ivx_count_build(ctx, ix, dk, ds, de, n); break;
         case IVX_KIND_COVERAGE: st = ivx_coverage_build(ctx, ix, dk, ds, de, n); break;
         default: st = ivx_nearest_build(ctx, ix, dk, ds, de, n); break;
@@ -374,6 +417,7 @@ extern "C" void ivx_index_free(ivx_index *ix)
     if (!ix) return;
     // the caller guarantees no probe on this index is still running (same contract as dropping
     // Arc<JoinLeftData>); buffers go back to the pool, to be reused only by later builds
+    if (ix->ready) { (void)hipEventSynchronize(ix->ready); (void)hipEventDestroy(ix->ready); }   // (its build tail may still be writing)
     for (size_t i = 0; i < ix->allocs.size(); i++) pool_give(ix->device, ix->allocs[i], ix->alloc_caps[i]);
     if (ix->owner_bytes) ix->owner_bytes->fetch_sub(ix->bytes, std::memory_order_relaxed);
     delete ix;
@@ -394,7 +438,7 @@ static ivx_status overlap_common(ivx_ctx *ctx, const ivx_index *ix, int mem, int
                                  const u32 *key, const i32 *start, const i32 *end, u64 n,
                                  u32 *per_row, u8 *exists, u32 *bidx, u32 *pidx, u64 cap, u64 *total)
 {
-    IVX_TRY(check_probe_args(ctx, ix, IVX_KIND_OVERLAP, mem, start, end, n));
+    IVX_TRY(check_probe_args(ctx, ix, IVX_KIND_OVERLAP, mem, start, end, n, true));
     CallMetrics cm(ctx, false, n);
     const u32 *dk = nullptr; const i32 *ds = nullptr, *de = nullptr;
     // large COUNT/FILL batches: partition the probe rows by index region and probe from LDS;
@@ -414,6 +458,8 @@ static ivx_status overlap_common(ivx_ctx *ctx, const ivx_index *ix, int mem, int
     ivx_join_plan &pl = ctx->join_plan;
     const bool planned = regions && mode == JP_FILL && pl.valid && !getenv("IVX_NO_PLAN") && pl.mem == mem && memcmp(pl.in, in, sizeof(in)) == 0 && pl.n == n &&
                          pl.ix == (const void *)ix && pl.ix_serial == ix->serial && pl.stream == ctx->stream;
+    // (the region path orders itself behind the index's build tail after its routing pass; everything else here)
+    if (ix->ready != nullptr && !(regions && !planned)) IVX_HIP(ctx, hipStreamWaitEvent(ctx->stream, ix->ready, 0));
     if (!planned) {
         IVX_TRY(stage_in(ctx, mem, WS_IN_KEY, key, n, &dk));
         IVX_TRY(stage_in(ctx, mem, WS_IN_START, start, n, &ds));
@@ -429,7 +475,8 @@ static ivx_status overlap_common(ivx_ctx *ctx, const ivx_index *ix, int mem, int
         KernelTimer t(ctx);
         if (regions) {
             if (!planned) pl.valid = false;                 // whatever an earlier count call left is gone now
-            const ivx_status st = ivx_join_probe_regions(ctx, ix->jv, ix->jv_nreg, mode, dk, ds, de, n, d_b, d_p, cap, ctx->d_scalars, planned, ix->jv_filter, ix->jv_pk24, ix->jv_fast);
+            const ivx_status st = ivx_join_probe_regions(ctx, ix->jv, ix->jv_nreg, mode, dk, ds, de, n, d_b, d_p, cap, ctx->d_scalars, planned, ix->jv_filter, ix->jv_pk24,
+                                                         ix->jv_fast_unknown ? 2 : (ix->jv_fast ? 1 : 0), planned ? nullptr : ix->ready);
             if (st != IVX_OK) { pl.valid = false; return st; }
             if (mode == JP_COUNT && pl.valid) { memcpy(pl.in, in, sizeof(in)); pl.mem = mem; pl.n = n; pl.ix = ix; pl.ix_serial = ix->serial; pl.stream = ctx->stream; }
         }

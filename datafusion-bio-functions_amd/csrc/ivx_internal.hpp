@@ -80,6 +80,14 @@ struct ivx_ctx {
     u64 mem_limit = 0;                  // device bytes of scratch + the index being built (0 = unlimited)
     u64 fill_hint = 0;                  // pairs a fill call should expect instead of its cap (a chunk of a host-resident batch writes into the whole batch's buffers)
     u64 scratch_bytes = 0, building_bytes = 0;
+    // Build overlap (ivx_ctx_set_build_overlap): an overlap index build returns once the per-key tables and the region layout
+    // are final -- all a probe's routing pass reads -- and leaves the rest (cell count, scan, scatter, region descriptors) running
+    // on `aux`; `tail_ev` marks its end.  A probe's routing then runs beside it and only its probe kernel waits for the
+    // index's `ready` event; anything else that could touch what the tail still uses waits first (get_scratch, join_tail).
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_fork = nullptr, tail_ev = nullptr;
+    bool overlap = false, tail_pending = false;
+    void join_tail();                   // order this context's stream behind a pending build tail
     // device bytes of the indexes this context built that are still alive (shared with those indexes: ivx_index_free
     // gives the bytes back whichever thread calls it, also after the context is gone)
     std::shared_ptr<std::atomic<u64>> live_index_bytes = std::make_shared<std::atomic<u64>>(0);
@@ -215,6 +223,8 @@ struct ivx_index {
     bool jv_filter = false;     // jv carries an occupancy bitmap (hdr[HDR_FG] != ~0u)
     bool jv_pk24 = false;       // hdr[HDR_PK24]
     bool jv_fast = false;       // !hdr[HDR_SLOW]
+    bool jv_fast_unknown = false;   // built with the tail overlapped: hdr[HDR_SLOW] is final only behind `ready` (kernels test it themselves)
+    hipEvent_t ready = nullptr; // set when the build's tail ran on the aux stream: everything but the routing tables is valid behind it
     RankGridView gs{}, ge{};
     CoverageView cv{};
     NearestView nv{};
@@ -235,7 +245,7 @@ ivx_status ivx_scan_exclusive_u32(ivx_ctx *ctx, u32 *data, u64 n);      // in pl
 ivx_status ivx_scan_exclusive_u64(ivx_ctx *ctx, u64 *data, u64 n);
 
 // join.hip
-ivx_status ivx_join_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32 *s, const i32 *e, u64 n);
+ivx_status ivx_join_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32 *s, const i32 *e, u64 n, bool overlap = false);
 ivx_status ivx_join_probe(ivx_ctx *ctx, const JoinIndexView &jv, int mode,
                           const u32 *key, const i32 *s, const i32 *e, u64 n,
                           u32 *per_row, u8 *exists, u32 *ob, u32 *op, u64 cap, u64 *d_cursor);
@@ -244,7 +254,7 @@ enum { JP_COUNT = 0, JP_PER_ROW = 1, JP_EXISTS = 2, JP_FILL = 3 };
 ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nreg, int mode,
                                   const u32 *key, const i32 *s, const i32 *e, u64 n,
                                   u32 *ob, u32 *op, u64 cap, u64 *d_cursor, bool planned = false, bool has_filter = false, bool pk24 = false,
-                                  bool fast = false);
+                                  int fast = 0 /* 0 no, 1 yes, 2 the kernels test hdr[HDR_SLOW] themselves */, hipEvent_t ready = nullptr);
 
 // per-row-output operators through the same partition (count_overlaps: jv over the build rows, no row with
 // end < start; coverage: jv over the merged nodes)

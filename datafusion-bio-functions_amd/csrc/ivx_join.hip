@@ -531,7 +531,7 @@ ivx_status ivx_join_rowval_routed(ivx_ctx *ctx, const ivx_index *ix, int mode, c
     return IVX_OK;
 }
 
-ivx_status ivx_join_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32 *s, const i32 *e, u64 n)
+ivx_status ivx_join_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32 *s, const i32 *e, u64 n, bool overlap)
 {
     const u32 nkeys = ix->nkeys;
     hipStream_t st = ctx->stream;
@@ -578,17 +578,42 @@ ivx_status ivx_join_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32
     const u32 grid = ivx_stream_grid(n, BT * 2, 16384);
     hipLaunchKernelGGL(k_join_layout, dim3(1), dim3(1024), 0, st, kmin, kmax, kcnt, nkeys, n, origin, span, lbase, hdr, maxcells, kreg, rkey, (const u32 *)lenhist, (u32)(regcap - 1), fbase, filter_mode);
     if (filter_mode) hipLaunchKernelGGL(k_join_filter, dim3(grid), dim3(BT), 0, st, key, s, e, n, nkeys, (const i32 *)origin, (const u32 *)span, (const u32 *)fbase, (const u32 *)hdr, fbits);
-    hipLaunchKernelGGL(k_join_count, dim3(grid), dim3(BT), 0, st, key, s, e, n, nkeys, origin, lbase, hdr, binstart, cellid, rank);
-    IVX_TRY(ivx_scan_exclusive_u32(ctx, binstart, maxcells + 1));
-    hipLaunchKernelGGL(k_join_scatter, dim3(grid), dim3(BT), 0, st, s, e, n, (const u32 *)binstart, (const u32 *)cellid, (const u32 *)rank, ent);
-    hipLaunchKernelGGL(k_join_regdesc, dim3((u32)((regcap + 255) / 256)), dim3(256), 0, st, origin, span, lbase, hdr, kreg, rkey, binstart, rdesc);
-    IVX_HIP(ctx, hipGetLastError());
     // routing regions for the per-row modes of build sides that outgrow the LDS-slice pipeline (more than 1023 regions
     // takes > 5 M rows); count / coverage / nearest indexes route on their rank grids
     const bool want_route = ix->kind == IVX_KIND_OVERLAP && n >= (4u << 20);
+    // What follows -- cell count, scan, scatter, region descriptors -- writes binstart / ent / rdesc and two header flags;
+    // the per-key tables, the region layout and the occupancy bitmap are final here.  With the build overlap on it goes to
+    // the aux stream and the caller gets its index back as soon as the layout has reached the host.
+    overlap = overlap && ctx->overlap && ctx->aux != nullptr && !want_route && n >= (1u << 16);
+    hipStream_t tail_st = st;
+    if (overlap) {
+        ctx->join_tail();                                       // (an earlier tail may still read the scratch this one is about to write)
+        IVX_HIP(ctx, hipEventRecord(ctx->ev_fork, st));
+        IVX_HIP(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
+        tail_st = ctx->aux;
+    }
+    hipLaunchKernelGGL(k_join_count, dim3(grid), dim3(BT), 0, tail_st, key, s, e, n, nkeys, origin, lbase, hdr, binstart, cellid, rank);
+    {
+        const hipStream_t keep = ctx->stream;
+        ctx->stream = tail_st;                                  // (the scan launches on the context's stream)
+        const ivx_status sst = ivx_scan_exclusive_u32(ctx, binstart, maxcells + 1);
+        ctx->stream = keep;
+        IVX_TRY(sst);
+    }
+    hipLaunchKernelGGL(k_join_scatter, dim3(grid), dim3(BT), 0, tail_st, s, e, n, (const u32 *)binstart, (const u32 *)cellid, (const u32 *)rank, ent);
+    hipLaunchKernelGGL(k_join_regdesc, dim3((u32)((regcap + 255) / 256)), dim3(256), 0, tail_st, origin, span, lbase, hdr, kreg, rkey, binstart, rdesc);
+    IVX_HIP(ctx, hipGetLastError());
+    if (overlap) {
+        if (ix->ready == nullptr) IVX_HIP(ctx, hipEventCreateWithFlags(&ix->ready, hipEventDisableTiming));
+        IVX_HIP(ctx, hipEventRecord(ix->ready, ctx->aux));
+        IVX_HIP(ctx, hipEventRecord(ctx->tail_ev, ctx->aux));    // (the context's own event: the index, and its event, may be freed first)
+        ctx->tail_pending = true;
+        ix->jv_fast_unknown = true;
+    }
     if (want_route) IVX_TRY(ivx_route_view_build(ctx, ix, origin, span, kcnt));
 
-    // key ids are validated on the device; surface the flag (one small D2H)
+    // key ids are validated on the device; surface the flag (one small D2H).  (With the tail overlapped the header copy
+    // carries the layout's words -- regions, bitmap, packed rows -- but not yet the two flags the tail sets.)
     IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 8, errflag, sizeof(u32), hipMemcpyDeviceToHost, st));
     IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 32, hdr, HDR_WORDS * sizeof(u32), hipMemcpyDeviceToHost, st));
     IVX_HIP(ctx, hipStreamSynchronize(st));

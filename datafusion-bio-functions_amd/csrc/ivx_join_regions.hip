@@ -959,9 +959,10 @@ __global__ __launch_bounds__(RP_T) void k_probe_regions(JoinIndexView ix, const 
                                                         unsigned long long *cursor, u32 prow_stride, u32 adj,
                                                         const u32 *unsorted, int dbg, PageTab pt = PageTab{nullptr, 0u, 0u},
                                                         const u32 *bsel = nullptr, const i32 *__restrict__ ps_in = nullptr, const i32 *__restrict__ pe_in = nullptr,
-                                                        u32 rowbits = 32)
+                                                        u32 rowbits = 32, const u32 *only_if_set = nullptr)
 {
     constexpr bool FILL = MODE == 1;
+    if (only_if_set != nullptr && *only_if_set == 0u) return;         // (the lean fill kernel took this index: see ivx_join_probe_regions)
     const u32 rowmask = rowbits >= 32 ? 0xFFFFFFFFu : (1u << rowbits) - 1u;
     const u32 maxlen = pk_maxlen(rowbits);
     static_assert(!PK || PAGED, "packed rows come from the one-pass partition");
@@ -1209,6 +1210,7 @@ __global__ __launch_bounds__(RP_T) void k_fill_fast(JoinIndexView ix, const u64 
                                                     unsigned long long *cursor, const u32 *bsel, u32 rowbits, FpRest *__restrict__ rest, u64 *__restrict__ rest_rows, u32 *rest_n)
 {
     if (bsel != nullptr && *bsel != (u32)B) return;                   // (every B is launched; k_pick_rows chose one)
+    if (ix.hdr[HDR_SLOW] != 0u) return;                               // not every region is one LDS-resident level: the general kernel's
     constexpr u32 WB = IVX_WAVE * B;                                  // rows of a wavefront batch
     constexpr u32 SUB = 8u / B;                                       // batches a wavefront makes of its 512 rows of a chunk
     IVX_PROBE_LDS(true)
@@ -2196,12 +2198,15 @@ ivx_status probe_two_level(ivx_ctx *ctx, const JoinIndexView &jv, int mode, u32 
 
 ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nreg, int mode,
                                   const u32 *key, const i32 *s, const i32 *e, u64 n,
-                                  u32 *ob, u32 *op, u64 cap, u64 *d_cursor, bool planned, bool has_filter, bool pk24, bool fast)
+                                  u32 *ob, u32 *op, u64 cap, u64 *d_cursor, bool planned, bool has_filter, bool pk24, int fast, hipEvent_t ready)
 {
-    if (n == 0) return IVX_OK;
+    if (n == 0) { if (ready) IVX_HIP(ctx, hipStreamWaitEvent(ctx->stream, ready, 0)); return IVX_OK; }
     ivx_join_plan &pl = ctx->join_plan;
-    if (nreg > IVX_MAXREG_WIDE) return probe_two_level(ctx, jv, mode, nreg, key, s, e, n, ob, op, cap, d_cursor, planned);
     hipStream_t st = ctx->stream;
+    // `ready` (an index whose build tail may still run on another stream): the routing pass reads only what was final
+    // before that tail started; the probe kernels come behind the event
+    auto wait_ready = [&]() -> ivx_status { if (ready) { IVX_HIP(ctx, hipStreamWaitEvent(st, ready, 0)); ready = nullptr; } return IVX_OK; };
+    if (nreg > IVX_MAXREG_WIDE) { IVX_TRY(wait_ready()); return probe_two_level(ctx, jv, mode, nreg, key, s, e, n, ob, op, cap, d_cursor, planned); }
 #ifdef IVX_ABLATE          // profiling builds only (tools/variant.sh <name> -DIVX_ABLATE; tools/ablate.sh): IVX_DBG bit switches
     const int dbg = getenv("IVX_DBG") ? atoi(getenv("IVX_DBG")) : 0;
 #else
@@ -2266,6 +2271,7 @@ ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nre
 #undef IVX_ONEPASS
             hipLaunchKernelGGL(k_chunk_bounds, dim3(1), dim3(1024), 0, st, (const u32 *)rcur, nreg, rf, rf + 1032);
             rfirst = rf; pool_se = pse; pool_row = prow;
+            IVX_TRY(wait_ready());
             if (mode == JP_COUNT) {
                 pl.hist = rf; pl.pse = pse; pl.prow = prow; pl.ds = s; pl.de = e; pl.chunk = 0; pl.nblk = 1;
                 pl.paged = true; pl.packed = packed; pl.rest = rest_buf; pl.rowbits = rowbits; pl.ptab = ptab; pl.pstride = (u32)pstride; pl.lgpg = lgpg; pl.all_routed = all_routed;
@@ -2273,11 +2279,13 @@ ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nre
                 pl.valid = true;
             }
         }
+        IVX_TRY(wait_ready());
         unsigned long long *cur = (unsigned long long *)d_cursor;
         // the rows the probe walks are the routed ones: the density hint is pairs per INPUT row, as the caller sized it
         const u64 hint = ctx->fill_hint ? ctx->fill_hint : (planned && pl.total < cap ? pl.total : cap);
         if (mode == JP_FILL && dense_fill_wanted(hint, n))
             return dense_fill(ctx, jv, nreg, (const void *)pool_se, (const void *)pool_row, 1u, s, e, rfirst, 1u, nullptr, n, ob, op, cap, d_cursor, &pt, packed, rowbits);
+        const u32 *slow_gate = nullptr;
         if (mode == JP_FILL) {
             // rows per lane follow from the pairs per ROUTED row: known here when every row was routed; with the occupancy
             // bitmap in use the count sits on the device, k_pick_rows decides there and every variant is launched (three exit)
@@ -2287,7 +2295,7 @@ ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nre
             // packed rows over an index whose every region is one LDS-resident level: the lean kernel, then whatever batches it
             // left to the generic walk (IVX_FILL=old: the general kernel, for A/B runs and the tests that pin both)
             const bool lean_off = getenv("IVX_FILL") && !strcmp(getenv("IVX_FILL"), "old");
-            if (packed && fast && !lean_off && pt.lgpg >= 13 && rest_buf != nullptr) {
+            if (packed && fast != 0 && !lean_off && pt.lgpg >= 13 && rest_buf != nullptr) {
                 u32 *rest_n = ctl + 1024 + 4;                           // batches, rows
                 FpRest *rest = (FpRest *)rest_buf;
                 u64 *rest_rows = (u64 *)(rest + fp_max_batches(n, nreg));
@@ -2299,10 +2307,14 @@ ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nre
 #undef IVX_FILLF
                     hipLaunchKernelGGL(k_fill_rest, dim3(512), dim3(256), 0, st, jv, pool_se, pt, (const FpRest *)rest, (const u64 *)rest_rows, (const u32 *)rest_n, ob, op, cap, cur, s, e, rowbits);
                     IVX_HIP(ctx, hipGetLastError());
-                    return IVX_OK;
+                    if (fast == 1) return IVX_OK;
+                    // fast == 2: whether every region is one LDS-resident level is known on the device only (the index's build
+                    // tail set hdr[HDR_SLOW] after the host had its copy): k_fill_fast has left at once if not, and the
+                    // general kernel below leaves at once if so
+                    slow_gate = jv.hdr + HDR_SLOW;
                 }
             }
-#define IVX_FILLP2(B_, P_) hipLaunchKernelGGL((k_probe_regions<1, B_, false, true, P_>), dim3(RP_GRID), dim3(RP_T), 0, st, jv, (const void *)pool_se, (const void *)pool_row, rfirst, 1u, RP_VGRID / RP_GRID, ob, op, cap, cur, 1u, 0u, (const u32 *)nullptr, dbg, pt, (const u32 *)bsel, s, e, rowbits)
+#define IVX_FILLP2(B_, P_) hipLaunchKernelGGL((k_probe_regions<1, B_, false, true, P_>), dim3(RP_GRID), dim3(RP_T), 0, st, jv, (const void *)pool_se, (const void *)pool_row, rfirst, 1u, RP_VGRID / RP_GRID, ob, op, cap, cur, 1u, 0u, (const u32 *)nullptr, dbg, pt, (const u32 *)bsel, s, e, rowbits, slow_gate)
 #define IVX_FILLP(B_) do { if (packed) IVX_FILLP2(B_, true); else IVX_FILLP2(B_, false); } while (0)
             if (bsel) { IVX_FILLP(8); IVX_FILLP(4); IVX_FILLP(2); IVX_FILLP(1); }
             else switch (fill_rows_per_lane(hint, n)) { case 1: IVX_FILLP(1); break; case 2: IVX_FILLP(2); break; case 4: IVX_FILLP(4); break; default: IVX_FILLP(8); }
@@ -2316,6 +2328,7 @@ ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nre
         IVX_HIP(ctx, hipGetLastError());
         return IVX_OK;
     }
+    IVX_TRY(wait_ready());                                              // (the two-pass partition's histogram kernel may leave the rows in place: no overlap here)
     u32 *unsorted = (u32 *)(ctx->d_scalars + 10);                       // stays 0 if the rows already come in region order
     u32 chunk, nblk; u32 *hist; u64 *pse; u32 *prow;
     if (planned) {

@@ -27,7 +27,7 @@ SYMBOLS = [
     "ivx_probe_count", "ivx_probe_coverage", "ivx_probe_nearest", "ivx_merge", "ivx_subtract",
     "ivx_cluster", "ivx_complement", "ivx_take_fixed", "ivx_take_utf8", "ivx_take_bits", "ivx_take_view",
     "ivx_ctx_metrics", "ivx_ctx_reset_metrics", "ivx_ctx_set_memory_limit", "ivx_ctx_trim", "ivx_scatter_fixed",
-    "ivx_ctx_reserved_bytes",
+    "ivx_ctx_reserved_bytes", "ivx_ctx_set_build_overlap",
 ]
 
 
@@ -189,6 +189,11 @@ class Ctx:
 
     def set_memory_limit(self, nbytes):
         self._chk0(lib().ivx_ctx_set_memory_limit(self.h, C.c_uint64(int(nbytes))))
+
+    def set_build_overlap(self, on=True):
+        """an overlap index build returns once the routing tables are final; its tail runs beside the next probe's routing
+        pass (include/ivx.h: the build columns must then outlive the index's first probe call)"""
+        self._chk0(lib().ivx_ctx_set_build_overlap(self.h, C.c_int(int(on))))
 
     def reserved_bytes(self):
         return lib().ivx_ctx_reserved_bytes(self.h)

@@ -93,6 +93,16 @@ const char *ivx_last_error(const ivx_ctx *ctx);
 ivx_status ivx_ctx_set_stream(ivx_ctx *ctx, void *hip_stream);
 ivx_status ivx_ctx_use_own_stream(ivx_ctx *ctx);
 ivx_status ivx_ctx_synchronize(ivx_ctx *ctx);
+/* Build overlap (off by default; IVX_BUILD_OVERLAP=1 turns it on for new contexts).  With it on, ivx_index_build of an
+ * IVX_KIND_OVERLAP index from IVX_MEM_DEVICE columns returns as soon as the per-key tables and the region layout are final --
+ * all that the routing pass of a big probe batch reads -- and lets the rest of the build (cell count, scan, scatter, region
+ * descriptors) run on a second stream of the context.  The next big ivx_probe_overlap_count / _fill call routes its rows
+ * beside that tail and only its probe kernel waits for it; every other use of the index (any context) and every other call
+ * on this context is ordered behind the tail first, so results never change.  What changes is the caller's side of the
+ * IVX_MEM_DEVICE contract: the build columns must stay unchanged until the index's first probe call has returned, or
+ * ivx_ctx_synchronize (which waits for the tail too) -- as IntervalJoinExec keeps the build batches alive in JoinLeftData
+ * for the whole join (interval_join.rs:466-480).  ivx_index_free waits for the tail by itself. */
+ivx_status ivx_ctx_set_build_overlap(ivx_ctx *ctx, int on);
 /* device time (ms, hipEvent) of the kernels of the last call on this ctx */
 double     ivx_ctx_last_kernel_ms(const ivx_ctx *ctx);
 const char *ivx_version(void);

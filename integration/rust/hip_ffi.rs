@@ -40,6 +40,7 @@ extern "C" {
     pub fn ivx_ctx_set_stream(ctx: *mut IvxCtx, hip_stream: *mut c_void) -> i32;
     pub fn ivx_ctx_use_own_stream(ctx: *mut IvxCtx) -> i32;
     pub fn ivx_ctx_synchronize(ctx: *mut IvxCtx) -> i32;
+    pub fn ivx_ctx_set_build_overlap(ctx: *mut IvxCtx, on: i32) -> i32;
     pub fn ivx_ctx_last_kernel_ms(ctx: *const IvxCtx) -> f64;
     pub fn ivx_version() -> *const c_char;
     pub fn ivx_ctx_metrics(ctx: *const IvxCtx, out: *mut IvxMetrics) -> i32;

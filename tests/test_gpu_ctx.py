@@ -111,3 +111,38 @@ def test_trim_gives_scratch_back_to_the_device():
     b.close()
     assert a.merge(k, s64, e64, n_keys=24)[0].numel() == m1       # grows its scratch again on demand
     a.close()
+
+
+def test_build_overlap_gives_the_same_pairs():
+    """ivx_ctx_set_build_overlap: the build returns before its tail (cell count, scan, scatter, region descriptors) has run,
+    the next probe's routing pass runs beside it; pairs, counts and every other use of the index are what they are without
+    it -- also when the index is freed at once, probed from a second context, or followed by an unrelated call."""
+    sys.path.insert(0, ROOT)
+    from oracle import oracle as orc
+    dev = torch.device(DEV)
+    bk, bs, be = synth.gen_torch(300_000, 1000, 24, 21, dev)
+    pk, ps, pe = synth.gen_torch(6_000_000, 150, 24, 22, dev)
+    hb = (bk.cpu().numpy().view(np.uint32), bs.cpu().numpy(), be.cpu().numpy())
+    hp = (pk.cpu().numpy().view(np.uint32), ps.cpu().numpy(), pe.cpu().numpy())
+    want = orc.pair_keys(*orc.join_single(*hb, *hp, threads=8))
+    keys = lambda b, p: torch.sort((b.long() << 32) | p.long()).values.cpu().numpy().view(np.uint64)
+    a, other = _ctx(), _ctx()
+    a.set_build_overlap(True)
+    for rep in range(3):
+        ix = a.build(pyivx.KIND_OVERLAP, bk, bs, be, n_keys=24)
+        if rep == 0:                                             # fill straight away: routing beside the build's tail
+            b, p = a.overlap_fill(ix, pk, ps, pe, cap=len(want))
+        elif rep == 1:                                           # count (leaves a plan), then the planned fill
+            assert a.overlap_count(ix, pk, ps, pe) == len(want)
+            b, p = a.overlap_fill(ix, pk, ps, pe, cap=len(want))
+        else:                                                    # another context probes the index first; an unrelated call on the builder
+            b, p = other.overlap_fill(ix, pk, ps, pe, cap=len(want))
+            assert a.merge(bk[:1000], bs[:1000].long(), be[:1000].long() + 1, n_keys=24)[0].numel() > 0
+        assert np.array_equal(keys(b, p), want)
+        # the small-batch path and the per-row modes wait for the tail themselves
+        assert a.overlap_count(ix, pk[:5000], ps[:5000], pe[:5000]) == int((want & np.uint64(0xFFFFFFFF)).astype(np.int64).__lt__(5000).sum())
+        a.synchronize(); other.synchronize()
+        ix.free()
+    ix = a.build(pyivx.KIND_OVERLAP, bk, bs, be, n_keys=24)
+    ix.free()                                                    # freed with its tail possibly still running
+    a.close(); other.close()
