@@ -1325,52 +1325,38 @@ __global__ __launch_bounds__(RP_T) void k_fill_fast(JoinIndexView ix, const u64 
         }
         u32 wpos = 0;                                                    // pairs of this round so far (scalar)
         uint2 *half = (uint2 *)L.s_q[wv] + (round & 1u) * HALF;
-#ifndef IVX_FP_IL
-#define IVX_FP_IL 1
-#endif
-        constexpr int IL = B >= IVX_FP_IL ? IVX_FP_IL : B;
 #pragma unroll
-        for (int q0 = 0; q0 < B; q0 += IL) {
-            i32 qs[IL], qe[IL]; const u64 *pj[IL], *pe[IL];
-#pragma unroll
-            for (int u = 0; u < IL; u++) {
-                qs[u] = (i32)((u32)rbase + rel[q0 + u]); qe[u] = (i32)((u32)qs[u] + len[q0 + u]);
-                pj[u] = L.s_ent + ca[q0 + u];
+        for (int q = 0; q < B; q++) {
+            const i32 qs = (i32)((u32)rbase + rel[q]), qe = (i32)((u32)qs + len[q]);
+            const u64 *pj = L.s_ent + ca[q];
 #if defined(IVX_FP_ABL) && IVX_FP_ABL >= 2
-                pe[u] = pj[u] + ((cb[q0 + u] ^ roww[q0 + u]) == 0x12345u ? 1u : 0u);     // (profiling: no candidate loop; the cell lookups stay live)
+            const u64 *pe = pj + ((cb[q] ^ roww[q]) == 0x12345u ? 1u : 0u);     // (profiling: no candidate loop; the cell lookups stay live)
 #else
-                pe[u] = L.s_ent + cb[q0 + u];
+            const u64 *pe = L.s_ent + cb[q];
 #endif
-            }
-            for (;;) {
-                bool act[IL], any = false;
-#pragma unroll
-                for (int u = 0; u < IL; u++) { act[u] = pj[u] < pe[u]; any |= act[u]; }
-                if (__builtin_amdgcn_ballot_w64(any) == 0) break;
-                u64 x[IL];
-#pragma unroll
+            // (walking two or four rows' lists side by side -- their slice reads in flight together, one wait for all -- was
+            //  measured: no change.  The walk is bound by the instructions it issues, not by those waits.)
+            while (__builtin_amdgcn_ballot_w64(pj < pe) != 0) {
+                const bool act = pj < pe;
 #if defined(IVX_FP_BCAST)
-                for (int u = 0; u < IL; u++) x[u] = L.s_ent[__builtin_amdgcn_readfirstlane((u32)(pj[u] - L.s_ent)) & 4095u];   // (profiling: one address per wavefront, no bank conflicts)
+                const u64 x = L.s_ent[__builtin_amdgcn_readfirstlane((u32)(pj - L.s_ent)) & 4095u];   // (profiling: one address per wavefront, no bank conflicts)
 #else
-                for (int u = 0; u < IL; u++) x[u] = *pj[u];              // (a lane past its list reads on inside LDS; its result is not used)
+                const u64 x = *pj;                                       // (a lane past its list reads on inside LDS; its result is not used)
+#endif
 #if defined(IVX_FP_DUP)
-                for (int u = 0; u < IL; u++) { u64 y = *(const volatile u64 *)(pj[u] + 1); asm volatile("" :: "v"(y)); }   // (profiling: every slice read twice)
+                { u64 y = *(const volatile u64 *)(pj + 1); asm volatile("" :: "v"(y)); }              // (profiling: every slice read twice)
 #endif
-#endif
-#pragma unroll
-                for (int u = 0; u < IL; u++) {
-                    const bool hit = act[u] && (i32)(u32)x[u] <= qe[u] && (i32)(u32)(x[u] >> 32) >= qs[u];
-                    const u64 mm = __builtin_amdgcn_ballot_w64(hit);
+                const bool hit = act && (i32)(u32)x <= qe && (i32)(u32)(x >> 32) >= qs;
+                const u64 mm = __builtin_amdgcn_ballot_w64(hit);
 #if defined(IVX_FP_ABL) && IVX_FP_ABL == 1
-                    wpos += (u32)__popcll(mm);
+                wpos += (u32)__popcll(mm);
 #else
-                    if (mm != 0) {
-                        if (hit) half[(wpos + mask_rank(mm)) & (HALF - 1)] = make_uint2((u32)(pj[u] - L.s_ent), roww[q0 + u]);
-                        wpos += (u32)__popcll(mm);
-                    }
-#endif
-                    pj[u]++;
+                if (mm != 0) {
+                    if (hit) half[(wpos + mask_rank(mm)) & (HALF - 1)] = make_uint2((u32)(pj - L.s_ent), roww[q]);
+                    wpos += (u32)__popcll(mm);
                 }
+#endif
+                pj++;
             }
         }
         u32 got = wpos;

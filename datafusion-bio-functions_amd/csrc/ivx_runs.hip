@@ -69,11 +69,13 @@ __device__ __forceinline__ bool merges(i64 s, i64 cur_end, i64 d, int strict)
 
 // element i of the cur_end scan: the transfer function of row i (computed from the sorted columns, never stored)
 struct StateIn {
-    const u32 *ks; const i64 *ss, *es; i64 d; int strict;
-    __device__ MState operator()(u64 i) const
+    SortedRows r; i64 d; int strict;
+    __device__ MState operator()(u64 i) const { i64 s; return at(i, s); }
+    // ... and the row's start, for callers that test the row against cur_end themselves
+    __device__ MState at(u64 i, i64 &s) const
     {
-        const bool first = i == 0 || ks[i] != ks[i - 1];
-        const i64 s = ss[i], e = es[i];
+        u32 k; i64 e; bool first;
+        r.get(i, k, s, e, first);
         MState t; t.pad = 0;
         if (first || (strict && s == INT64_MAX)) {          // strict: s < anything never holds at i64::MAX
             t.konst = 1; t.M = 0; t.c = e;
@@ -86,16 +88,26 @@ struct StateIn {
     }
 };
 // after the inclusive scan the state of row i is a constant function: its value is cur_end after row i
+// (cur_end is always some row's end: with narrow rows it is kept as a 32-bit offset from min_e as well)
+struct CurEnd {
+    i64 *wide; u32 *narrow; i64 min_e;
+    __device__ __forceinline__ i64 at(u64 i) const { return narrow ? (i64)((u64)min_e + narrow[i]) : wide[i]; }
+};
 struct CurEndOut {
-    i64 *cur_end;
-    __device__ void operator()(u64 i, const MState &t) const { cur_end[i] = t.c; }
+    CurEnd ce;
+    __device__ void operator()(u64 i, const MState &t) const
+    {
+        if (ce.narrow) ce.narrow[i] = (u32)((u64)t.c - (u64)ce.min_e); else ce.wide[i] = t.c;
+    }
 };
 // element i of the run-head scan: does row i start a run (merge.rs:291-296 against cur_end after row i-1)
 struct HeadIn {
-    const u32 *ks; const i64 *ss, *cur_end; i64 d; int strict;
+    SortedRows r; CurEnd cur_end; i64 d; int strict;
     __device__ HeadAcc operator()(u64 i) const
     {
-        const bool head = i == 0 || ks[i] != ks[i - 1] || !merges(ss[i], cur_end[i - 1], d, strict);
+        u32 k; i64 s, e; bool first;
+        r.get(i, k, s, e, first);
+        const bool head = first || !merges(s, cur_end.at(i - 1), d, strict);
         HeadAcc h; h.heads = head ? 1u : 0u; h.last_head = head ? (u32)i : 0u;
         return h;
     }
@@ -105,16 +117,23 @@ struct HeadIn {
 // cluster()
 struct HeadEmitOut {
     HeadAcc *ha;
-    const u32 *ks; const i64 *ss, *cur_end; i64 d; int strict; u64 n; ivx_runs_out out; u64 *m;
+    SortedRows r; CurEnd cur_end; i64 d; int strict; u64 n; ivx_runs_out out; u64 *m;
     __device__ void operator()(u64 i, const HeadAcc &h) const
     {
         if (ha) ha[i] = h;
-        const bool last = i + 1 == n || ks[i + 1] != ks[i] || !merges(ss[i + 1], cur_end[i], d, strict);
+        bool last = i + 1 == n;
+        if (!last) {
+            u32 k1; i64 s1, e1; bool first1;
+            r.get(i + 1, k1, s1, e1, first1);
+            last = first1 || !merges(s1, cur_end.at(i), d, strict);
+        }
         if (last) {
             const u32 id = h.heads - 1;
-            if (out.key) out.key[id] = ks[i];
-            if (out.start) out.start[id] = ss[h.last_head];
-            if (out.end) out.end[id] = cur_end[i];
+            u32 kh; i64 sh, eh; bool fh;
+            r.get(h.last_head, kh, sh, eh, fh);               // the run's first row: its key is the run's, its start the run's
+            if (out.key) out.key[id] = kh;
+            if (out.start) out.start[id] = sh;
+            if (out.end) out.end[id] = cur_end.at(i);
             if (out.count) out.count[id] = (i64)(i - h.last_head + 1);
         }
         if (i + 1 == n) *m = h.heads;
@@ -132,9 +151,10 @@ __global__ __launch_bounds__(ivxscan::T_) void k_merge_apply(StateIn in, CurEndO
     __shared__ HeadAcc hl[T_ / IVX_WAVE + 1];
     const u64 base = (u64)blockIdx.x * TILE_ + (u64)threadIdx.x * I_;
     MState v[I_];
+    i64 rs[I_];
     MState s = MergeOp::identity();
 #pragma unroll
-    for (int i = 0; i < I_; i++) { v[i] = base + i < n ? in(base + i) : MergeOp::identity(); s = MergeOp::combine(s, v[i]); }
+    for (int i = 0; i < I_; i++) { rs[i] = 0; v[i] = base + i < n ? in.at(base + i, rs[i]) : MergeOp::identity(); s = MergeOp::combine(s, v[i]); }
     MState tot;
     MState inc = block_incl<MergeOp>(s, lds, &tot);
     MState run = offs ? offs[blockIdx.x] : MergeOp::identity();
@@ -151,7 +171,7 @@ __global__ __launch_bounds__(ivxscan::T_) void k_merge_apply(StateIn in, CurEndO
         if (idx < n) {
             // (a key's first row -- and a strict row at i64::MAX -- is a constant state: a head; otherwise `run` covers row 0,
             //  hence is constant, and run.c is cur_end after row idx - 1)
-            const bool head = v[i].konst || !merges(in.ss[idx], run.c, in.d, in.strict);
+            const bool head = v[i].konst || !merges(rs[i], run.c, in.d, in.strict);
             HeadAcc h; h.heads = head ? 1u : 0u; h.last_head = head ? (u32)idx : 0u;
             hacc = HeadOp::combine(hacc, h);
             run = MergeOp::combine(run, v[i]);
@@ -191,7 +211,7 @@ __global__ __launch_bounds__(ivxscan::T_) void k_head_apply(HeadIn in, HeadEmitO
 // one's second pass doubles as the second one's first, and the runs are emitted by the last pass itself: 68 bytes of
 // traffic per row (232 with a materialised state array, 108 with two separate scans and an emit pass).  Leaves cur_end
 // (n entries) in WS_T5 and, if want_ha, the per-row head counts in WS_T6.
-static ivx_status sweep(ivx_ctx *ctx, const u32 *ks, const i64 *ss, const i64 *es, u64 n,
+static ivx_status sweep(ivx_ctx *ctx, const SortedRows &rows, u64 n,
                         i64 min_dist, int strict, const ivx_runs_out &out, const HeadAcc **ha_out, u64 *m, bool want_ha)
 {
     using namespace ivxscan;
@@ -203,16 +223,18 @@ static ivx_status sweep(ivx_ctx *ctx, const u32 *ks, const i64 *ss, const i64 *e
     MState *sums; HeadAcc *hsums;
     IVX_TRY(ctx->get_scratch(WS_SCAN0, nblk * sizeof(MState), (void **)&sums));
     IVX_TRY(ctx->get_scratch(WS_SCAN2, nblk * sizeof(HeadAcc), (void **)&hsums));
-    const StateIn in{ks, ss, es, min_dist, strict};
+    const StateIn in{rows, min_dist, strict};
     if (nblk > 1) {
         hipLaunchKernelGGL((k_reduce_f<MergeOp, StateIn>), dim3((u32)nblk), dim3(T_), 0, stq, in, n, sums);
         IVX_TRY((scan_rec<MergeOp, false>(ctx, sums, nblk, 1, WS_SCAN0)));
     }
-    hipLaunchKernelGGL(k_merge_apply, dim3((u32)nblk), dim3(T_), 0, stq, in, CurEndOut{cur_end}, n, nblk > 1 ? (const MState *)sums : (const MState *)nullptr, hsums);
+    // (want_ha: cluster() reads cur_end's successor table, the run ends, as i64 -- only the plain merge narrows)
+    const CurEnd ce{cur_end, (rows.s32 != nullptr && !want_ha) ? (u32 *)cur_end : nullptr, rows.min_e};
+    hipLaunchKernelGGL(k_merge_apply, dim3((u32)nblk), dim3(T_), 0, stq, in, CurEndOut{ce}, n, nblk > 1 ? (const MState *)sums : (const MState *)nullptr, hsums);
     if (nblk > 1) IVX_TRY((scan_rec<HeadOp, false>(ctx, hsums, nblk, 1, WS_SCAN0)));
     u64 *d_m = ctx->d_scalars + 2;
-    const HeadIn hin{ks, ss, cur_end, min_dist, strict};
-    const HeadEmitOut hout{ha, ks, ss, cur_end, min_dist, strict, n, out, d_m};
+    const HeadIn hin{rows, ce, min_dist, strict};
+    const HeadEmitOut hout{ha, rows, ce, min_dist, strict, n, out, d_m};
     hipLaunchKernelGGL(k_head_apply, dim3((u32)nblk), dim3(T_), 0, stq, hin, hout, n, nblk > 1 ? (const HeadAcc *)hsums : (const HeadAcc *)nullptr);
     IVX_HIP(ctx, hipGetLastError());
     IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 2, d_m, sizeof(u64), hipMemcpyDeviceToHost, stq));
@@ -224,10 +246,16 @@ static ivx_status sweep(ivx_ctx *ctx, const u32 *ks, const i64 *ss, const i64 *e
 ivx_status ivx_merge_runs(ivx_ctx *ctx, const u32 *ks, const i64 *ss, const i64 *es, u64 n,
                           i64 min_dist, int strict, const ivx_runs_out &out, u64 *m)
 {
+    SortedRows rows{}; rows.ks = ks; rows.ss = ss; rows.es = es;
+    return ivx_merge_runs_rows(ctx, rows, n, min_dist, strict, out, m);
+}
+
+ivx_status ivx_merge_runs_rows(ivx_ctx *ctx, const SortedRows &rows, u64 n, i64 min_dist, int strict, const ivx_runs_out &out, u64 *m)
+{
     *m = 0;
     if (n == 0) return IVX_OK;
     const HeadAcc *ha;
-    IVX_TRY(sweep(ctx, ks, ss, es, n, min_dist, strict, out, &ha, m, false));
+    IVX_TRY(sweep(ctx, rows, n, min_dist, strict, out, &ha, m, false));
     IVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *m = ctx->h_scalars[2];
     return IVX_OK;
@@ -286,7 +314,8 @@ ivx_status ivx_cluster_rows(ivx_ctx *ctx, const u32 *ks, const i64 *ss, const i6
         IVX_TRY(ctx->get_scratch(WS_T7, n * sizeof(i64), (void **)&run_end));
         const HeadAcc *ha;
         const ivx_runs_out ro{nullptr, nullptr, run_end, nullptr};
-        IVX_TRY(sweep(ctx, ks, ss, es, n, min_dist, strict, ro, &ha, m, true));
+        SortedRows rows{}; rows.ks = ks; rows.ss = ss; rows.es = es;
+        IVX_TRY(sweep(ctx, rows, n, min_dist, strict, ro, &ha, m, true));
         const u32 grid = (u32)((n + RT - 1) / RT);
         hipLaunchKernelGGL(k_key_runs, dim3(grid), dim3(RT), 0, stq, ks, ha, n, nkeys, kfirst, klast);
         hipLaunchKernelGGL(k_cluster_rows, dim3(grid), dim3(RT), 0, stq, ks, ss, ha, (const i64 *)run_end, n, nkeys,

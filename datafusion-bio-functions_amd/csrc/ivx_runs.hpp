@@ -16,6 +16,32 @@
 #pragma once
 #include "ivx_internal.hpp"
 
+// How the sweeps' sort packs a row into ONE 64-bit word (ivx_sweep.hip sort64): the end in the low bits_e bits (minus
+// min_e), above it either key ‖ (start - min_s) -- bits_s bits of start -- or, lin, the (key, start) pair's number in key-major
+// order: base[key] + (start - kmin[key]).
+struct Pack64 { i64 min_s, min_e; u32 bits_s, bits_e; const u64 *base; const long long *kmin; u32 lin, nkeys; };
+
+// Rows sorted by (key, start, end) as the merge sweep reads them: three columns -- wide (u32 key, i64 start, i64 end: 20 bytes
+// per row in every pass of the sweep) or, s32 != nullptr, narrow (start and end as 32-bit offsets from min_s / min_e: 12
+// bytes), which the sort's unpack pass writes whenever the coordinates' ranges fit, i.e. for any genome.
+// (Reading the sort's packed 8-byte words directly was built and measured too: merge of 200 M rows 12.4 -> 13.0 ms.  The
+// unpack pass got cheaper, but every pass of the sweep then decodes (key, start) from a linearised position -- a key lookup
+// and variable 64-bit shifts per row -- and the striped run-head pass doubled its time.)
+struct SortedRows {
+    const u32 *ks; const i64 *ss, *es;
+    const u32 *s32, *e32; i64 min_s, min_e;
+#ifdef __HIPCC__
+    // row i: its key, start, end and whether it is the first row of its key
+    __device__ __forceinline__ void get(u64 i, u32 &k, i64 &s, i64 &e, bool &first) const
+    {
+        k = ks[i];
+        first = i == 0 || ks[i - 1] != k;
+        if (s32 != nullptr) { s = (i64)((u64)min_s + s32[i]); e = (i64)((u64)min_e + e32[i]); }
+        else { s = ss[i]; e = es[i]; }
+    }
+#endif
+};
+
 struct ivx_runs_out {
     u32 *key; i64 *start; i64 *end; i64 *count;     // device buffers, capacity n (any may be nullptr)
 };
@@ -25,6 +51,8 @@ struct ivx_runs_out {
 // Uses scratch WS_T5..WS_T7 and WS_SCAN*.
 ivx_status ivx_merge_runs(ivx_ctx *ctx, const u32 *ks, const i64 *ss, const i64 *es, u64 n,
                           i64 min_dist, int strict, const ivx_runs_out &out, u64 *m);
+// the same over either form of sorted rows
+ivx_status ivx_merge_runs_rows(ivx_ctx *ctx, const SortedRows &rows, u64 n, i64 min_dist, int strict, const ivx_runs_out &out, u64 *m);
 
 // cluster(): the same sweep, but every sorted row gets the id and the extent of its run
 // (cluster.rs:598-661).  Ids count runs in order from 0, or from key_base[key] for the first run

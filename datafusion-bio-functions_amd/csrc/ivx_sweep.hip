@@ -162,7 +162,7 @@ __global__ __launch_bounds__(1024) void k_lin_layout64(const long long *kmin, co
 // lin: the word's upper part is base[key] + (start - kmin[key]) -- bits_s bits, no separate key bits -- instead of
 // key ‖ (start - min_s): a human genome's (contig, position) pairs number 3.1e9 = 32 bits = four radix digits, where
 // 5 key bits + 28 position bits take five
-struct Pack64 { i64 min_s, min_e; u32 bits_s, bits_e; const u64 *base; const long long *kmin; u32 lin, nkeys; };
+// (Pack64: ivx_runs.hpp)
 __device__ __forceinline__ u32 lin_key64(const u64 *base, u32 nkeys, u64 lin)
 {
     u32 a = 0, b = nkeys;                                              // first k with base[k + 1] > lin (keys without rows are skipped)
@@ -191,7 +191,9 @@ __global__ __launch_bounds__(ST) void k_pack1(const u32 *__restrict__ key, const
 // raises *toolong and the host falls back to the full-width sort.
 constexpr u32 FIX_MAXRUN = 64;
 constexpr u32 UNPACK_TILES = 8;
-template <bool FIX>
+// NARROW: start and end leave as 32-bit offsets from p.min_s / p.min_e (the columns' storage is used as u32 arrays): 12
+// instead of 20 bytes per row here and in every pass of the merge sweep behind it (SortedRows, ivx_runs.hpp)
+template <bool FIX, bool NARROW = false>
 __global__ __launch_bounds__(ST) void k_unpack1(const u64 *__restrict__ w0, const u32 *__restrict__ w1, u64 n, Pack64 p,
                                                 u32 *ks, i64 *ss, i64 *es, u32 *rows, u32 lo_bits, u32 *toolong)
 {
@@ -246,16 +248,18 @@ __global__ __launch_bounds__(ST) void k_unpack1(const u64 *__restrict__ w0, cons
                 pos = t0 + h + below - FIX_MAXRUN;
             }
         }
+        u64 so;                                                         // start - p.min_s
         if (p.lin) {
             const u64 lin = shr64(w, p.bits_e);
             const u32 k = lin_key64(s_base, p.nkeys, lin);
             ks[pos] = k;
-            ss[pos] = (i64)((u64)p.kmin[k] + (lin - s_base[k]));
+            so = (u64)p.kmin[k] + (lin - s_base[k]) - (u64)p.min_s;
         } else {
             ks[pos] = (u32)shr64(w, p.bits_s + p.bits_e);
-            ss[pos] = (i64)(low64(shr64(w, p.bits_e), p.bits_s) + (u64)p.min_s);
+            so = low64(shr64(w, p.bits_e), p.bits_s);
         }
-        es[pos] = (i64)(low64(w, p.bits_e) + (u64)p.min_e);
+        if (NARROW) { ((u32 *)ss)[pos] = (u32)so; ((u32 *)es)[pos] = (u32)low64(w, p.bits_e); }
+        else { ss[pos] = (i64)(so + (u64)p.min_s); es[pos] = (i64)(low64(w, p.bits_e) + (u64)p.min_e); }
         if (rows && w1) rows[pos] = w1[i];
     }
 }
@@ -273,10 +277,14 @@ __global__ __launch_bounds__(ST) void k_copy_sorted(const u32 *__restrict__ key,
 u32 bits_of(u64 x) { u32 b = 0; while (x) { b++; x >>= 1; } return b; }
 
 // sort (key,start,end,row) ascending; rows of equal (key,start,end) keep input order = ascending row
+// sw (nullable; needs rows == nullptr): the caller reads the sorted rows through a SortedRows -- narrow columns (32-bit
+// offsets, stored in ss / es as u32 arrays) whenever the one-word form applies and both ranges fit 32 bits, else the wide ones.
 ivx_status sort64(ivx_ctx *ctx, int slot_a, int slot_b, const u32 *key, const i64 *s, const i64 *e, u64 n, u32 nkeys,
-                  u32 *ks, i64 *ss, i64 *es, u32 *rows)
+                  u32 *ks, i64 *ss, i64 *es, u32 *rows, SortedRows *sw = nullptr)
 {
+    if (sw) { *sw = SortedRows{}; sw->ks = ks; sw->ss = ss; sw->es = es; }
     if (n == 0) return IVX_OK;
+    bool narrow = sw != nullptr && rows == nullptr && !getenv("IVX_NO_NARROW_SWEEP");
     hipStream_t st = ctx->stream;
     u32 *flags = (u32 *)(ctx->d_scalars + 8);
     Range64 *d_rng = (Range64 *)(ctx->d_scalars + 24);
@@ -322,6 +330,8 @@ ivx_status sort64(ivx_ctx *ctx, int slot_a, int slot_b, const u32 *key, const i6
     // packed: one 64-bit sort word, plus the row ids -- a 32-bit payload -- only when the caller wants them back (merge /
     // complement / the right side of subtract do not: equal words are equal rows, and the record is 8 bytes instead of 12)
     const int nw = total <= 64 ? 1 : 3;
+    narrow = narrow && nw == 1 && (u64)r.max_s - (u64)r.min_s <= 0xFFFFFFFFull && (u64)r.max_e - (u64)r.min_e <= 0xFFFFFFFFull;
+    if (narrow) { sw->s32 = (const u32 *)ss; sw->e32 = (const u32 *)es; sw->min_s = r.min_s; sw->min_e = r.min_e; }
     for (int q = 0; q < nw; q++) {
         IVX_TRY(ctx->get_scratch(slot_a + q, n * sizeof(u64), (void **)&a[q]));
         IVX_TRY(ctx->get_scratch(slot_b + q, n * sizeof(u64), (void **)&b[q]));
@@ -347,6 +357,10 @@ ivx_status sort64(ivx_ctx *ctx, int slot_a, int slot_b, const u32 *key, const i6
             IVX_TRY(ivx_radix_sort(ctx, 1, a, b, n, f, 1, &in_b, true, with_rows ? pay : nullptr));
             o = in_b ? b : a;
             u32 *toolong = flags + 1;                                   // (upper half of the key-flag word; zeroed by the caller)
+            if (narrow)
+            hipLaunchKernelGGL((k_unpack1<true, true>), dim3((grid1(n) + UNPACK_TILES - 1) / UNPACK_TILES), dim3(ST), 0, st, (const u64 *)o[0], (const u32 *)pay[in_b], n, p, ks, ss, es, rows,
+                               p.bits_e, toolong);
+            else
             hipLaunchKernelGGL((k_unpack1<true>), dim3((grid1(n) + UNPACK_TILES - 1) / UNPACK_TILES), dim3(ST), 0, st, (const u64 *)o[0], (const u32 *)pay[in_b], n, p, ks, ss, es, rows,
                                p.bits_e, toolong);
             IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 8, flags, sizeof(u64), hipMemcpyDeviceToHost, st));
@@ -361,6 +375,10 @@ ivx_status sort64(ivx_ctx *ctx, int slot_a, int slot_b, const u32 *key, const i6
             const ivx_sort_field f[1] = {{0, 0, (int)((total + 7) / 8 * 8)}};
             IVX_TRY(ivx_radix_sort(ctx, 1, a, b, n, f, 1, &in_b, true, with_rows ? pay : nullptr));
             o = in_b ? b : a;
+            if (narrow)
+            hipLaunchKernelGGL((k_unpack1<false, true>), dim3((grid1(n) + UNPACK_TILES - 1) / UNPACK_TILES), dim3(ST), 0, st, (const u64 *)o[0], (const u32 *)pay[in_b], n, p, ks, ss, es, rows,
+                               0u, (u32 *)nullptr);
+            else
             hipLaunchKernelGGL((k_unpack1<false>), dim3((grid1(n) + UNPACK_TILES - 1) / UNPACK_TILES), dim3(ST), 0, st, (const u64 *)o[0], (const u32 *)pay[in_b], n, p, ks, ss, es, rows,
                                0u, (u32 *)nullptr);
         }
@@ -827,9 +845,10 @@ ivx_status ivx_merge_device(ivx_ctx *ctx, const u32 *key, const i64 *s, const i6
     IVX_TRY(ctx->get_scratch(WS_T0, n * sizeof(u32), (void **)&ks));
     IVX_TRY(ctx->get_scratch(WS_T1, n * sizeof(i64), (void **)&ss));
     IVX_TRY(ctx->get_scratch(WS_T2, n * sizeof(i64), (void **)&es));
-    IVX_TRY(sort64(ctx, WS_SA0, WS_SB0, key, s, e, n, nkeys, ks, ss, es, nullptr));
+    SortedRows rows;
+    IVX_TRY(sort64(ctx, WS_SA0, WS_SB0, key, s, e, n, nkeys, ks, ss, es, nullptr, &rows));
     ivx_runs_out ro{ok, os, oe, on};
-    IVX_TRY(ivx_merge_runs(ctx, ks, ss, es, n, min_dist, strict, ro, m));
+    IVX_TRY(ivx_merge_runs_rows(ctx, rows, n, min_dist, strict, ro, m));
     return keyflag(ctx, "merge: key id >= n_keys");
 }
 
@@ -976,9 +995,10 @@ ivx_status ivx_complement_device(ivx_ctx *ctx, const u32 *key, const i64 *s, con
         IVX_TRY(ctx->get_scratch(WS_T0, n * sizeof(u32), (void **)&ks));
         IVX_TRY(ctx->get_scratch(WS_T1, n * sizeof(i64), (void **)&ss));
         IVX_TRY(ctx->get_scratch(WS_T2, n * sizeof(i64), (void **)&es));
-        IVX_TRY(sort64(ctx, WS_SA0, WS_SB0, key, s, e, n, nkeys, ks, ss, es, nullptr));
+        SortedRows rows;
+        IVX_TRY(sort64(ctx, WS_SA0, WS_SB0, key, s, e, n, nkeys, ks, ss, es, nullptr, &rows));
         const ivx_runs_out ro{mk, ms, me, nullptr};
-        IVX_TRY(ivx_merge_runs(ctx, ks, ss, es, n, 0, strict, ro, &m));
+        IVX_TRY(ivx_merge_runs_rows(ctx, rows, n, 0, strict, ro, &m));
     }
     u32 *G, *cg;
     IVX_TRY(ctx->get_scratch(WS_T5, (m + 1) * sizeof(u32), (void **)&G));       // the sweep's scratch is free again
