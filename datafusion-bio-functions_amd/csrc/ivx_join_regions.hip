@@ -107,6 +107,28 @@ __device__ __forceinline__ u32 lds_count_up(u32 *cnt, u32 d, bool active)
     return active ? atomicAdd(&cnt[d], 1u) : 0u;
 }
 
+// The same for the FOUR consecutive rows a lane loads in one go (lane l of a wavefront holds rows 4l .. 4l + 3 of a 256-row
+// stretch of the input): coordinate-sorted input puts the whole stretch into one region, and then one lane bumps the
+// counter by 256 and every row's rank follows from its place in the stretch; anything else takes four plain LDS atomics per
+// lane.  ONE test and one branch per four rows (lds_count_up spends two ballots, a shuffle and two or three branches on
+// every row, and the partition is bound by the instructions it issues).
+__device__ __forceinline__ void lds_count_up4(u32 *cnt, const u32 (&d)[4], u32 (&rank)[4])
+{
+    const u32 d0 = __builtin_amdgcn_readfirstlane(d[0]);
+    const bool uni = d[0] == d0 && d[1] == d0 && d[2] == d0 && d[3] == d0 && d0 != NO_REGION;
+    if (__builtin_amdgcn_ballot_w64(!uni) == 0) {
+        u32 base = 0;
+        const u32 ln = lane_id();
+        if (ln == 0) base = atomicAdd(&cnt[d0], 4u * IVX_WAVE);
+        base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+        for (int k = 0; k < 4; k++) rank[k] = base + ln * 4u + (u32)k;
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) rank[k] = d[k] != NO_REGION ? atomicAdd(&cnt[d[k]], 1u) : 0u;
+}
+
 // four consecutive probe rows per lane: 16-byte loads when the columns are 16-byte aligned
 template <bool VEC>
 __device__ __forceinline__ void load4(const u32 *__restrict__ pkey, const i32 *__restrict__ ps, const i32 *__restrict__ pe,
@@ -509,10 +531,16 @@ __global__ __launch_bounds__(T, 4) void k_part_onepass(JoinIndexView ix, const u
                 for (int k = 0; k < CH; k++) dig[c0 + k] = route_test(fpos[k], win[k]) ? dig[c0 + k] : NO_REGION;
             }
 #pragma unroll
-            for (int k = 0; k < CH; k++) {                      // region and rank share a register from here on (10 + 14 bits)
-                const u32 lr = lds_count_up(dstart, dig[c0 + k], dig[c0 + k] != NO_REGION);
-                const u32 lhi = (PK && !FILT) ? fpos[k] << 24 : 0u;
-                dig[c0 + k] = dig[c0 + k] == NO_REGION ? NO_REGION : (dig[c0 + k] | (lr << 10) | lhi);
+            for (int v = 0; v < CH / 4; v++) {                  // region and rank share a register from here on (10 + 14 bits)
+                const u32 d4[4] = {dig[c0 + v * 4], dig[c0 + v * 4 + 1], dig[c0 + v * 4 + 2], dig[c0 + v * 4 + 3]};
+                u32 lr[4];
+                lds_count_up4(dstart, d4, lr);
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int k = v * 4 + u;
+                    const u32 lhi = (PK && !FILT) ? fpos[k] << 24 : 0u;
+                    dig[c0 + k] = dig[c0 + k] == NO_REGION ? NO_REGION : (dig[c0 + k] | (lr[u] << 10) | lhi);
+                }
             }
             if (CH != I) asm volatile("" ::: "memory");         // (keeps the next chunk's loads from being hoisted above this chunk's work)
         }
@@ -1305,58 +1333,62 @@ __global__ __launch_bounds__(RP_T) void k_fill_fast(JoinIndexView ix, const u64 
         const u32 sh0 = S.sh0, off = S.off, cmax = S.cmax, ncm1 = S.ncm1;
         const i32 rbase = S.rbase;
         u32 ca[B], cb[B], slow = 0;
+        // (two copies of the block, chosen once per batch: a per-row choice between "every lane holds B rows" and "test the
+        //  lane's row number" was two branches per row)
+        auto cells = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-        for (int q = 0; q < B; q++) {
-            const u32 t = ((rel[q] + 1u) >> sh0) + off;                  // first cell a matching build row can start in: one cell back
-            const u32 bl0 = (t > 1u ? t : 1u) - 1u;
-            const u32 bh0 = ((rel[q] + len[q]) >> sh0) + off;
-            const u32 bh = bh0 < cmax ? bh0 : cmax;
-            bool bad = len[q] == maxlen || bh >= ncm1;                   // escape, or past the slice's halo: the rest list's
-            if (!full) {                                                 // (wave-uniform: only a region's last batch is short)
-                const bool ok = (u32)q * IVX_WAVE + ln < cnt;
+            for (int q = 0; q < B; q++) {
+                const u32 t = ((rel[q] + 1u) >> sh0) + off;              // first cell a matching build row can start in: one cell back
+                const u32 bl0 = (t > 1u ? t : 1u) - 1u;
+                const u32 bh0 = ((rel[q] + len[q]) >> sh0) + off;
+                const u32 bh = bh0 < cmax ? bh0 : cmax;
+                bool bad = len[q] == maxlen || bh >= ncm1;               // escape, or past the slice's halo: the rest list's
+                const bool ok = FULL || (u32)q * IVX_WAVE + ln < cnt;    // (only a region's last batch is short)
                 if (ok && bad) slow |= 1u << q;
                 bad |= !ok;
-            } else if (bad) slow |= 1u << q;
-            // no row to walk: an empty range (twice the same offset); a row behind the key's last cell gets one by the clamp
-            const u32 e1 = bad ? 0u : bh + 1u;
-            const u32 bl = bl0 < e1 ? bl0 : e1;
-            ca[q] = L.s_off[bl];
-            cb[q] = L.s_off[e1];
-        }
+                // no row to walk: an empty range (twice the same offset); a row behind the key's last cell gets one by the clamp
+                const u32 e1 = bad ? 0u : bh + 1u;
+                const u32 bl = bl0 < e1 ? bl0 : e1;
+                ca[q] = L.s_off[bl];
+                cb[q] = L.s_off[e1];
+            }
+        };
+        if (full) cells(std::true_type{}); else cells(std::false_type{});
         u32 wpos = 0;                                                    // pairs of this round so far (scalar)
         uint2 *half = (uint2 *)L.s_q[wv] + (round & 1u) * HALF;
 #pragma unroll
         for (int q = 0; q < B; q++) {
             const i32 qs = (i32)((u32)rbase + rel[q]), qe = (i32)((u32)qs + len[q]);
-            const u64 *pj = L.s_ent + ca[q];
+            u32 j = ca[q];
 #if defined(IVX_FP_ABL) && IVX_FP_ABL >= 2
-            const u64 *pe = pj + ((cb[q] ^ roww[q]) == 0x12345u ? 1u : 0u);     // (profiling: no candidate loop; the cell lookups stay live)
+            const u32 jend = j + ((cb[q] ^ roww[q]) == 0x12345u ? 1u : 0u);     // (profiling: no candidate loop; the cell lookups stay live)
 #else
-            const u64 *pe = L.s_ent + cb[q];
+            const u32 jend = cb[q];
 #endif
             // (walking two or four rows' lists side by side -- their slice reads in flight together, one wait for all -- was
             //  measured: no change.  The walk is bound by the instructions it issues, not by those waits.)
-            while (__builtin_amdgcn_ballot_w64(pj < pe) != 0) {
-                const bool act = pj < pe;
+            // One backward branch per step; the match block sits on the fall-through path (a taken branch empties the
+            // wavefront's instruction buffer, and the kernel retired 31 branches per 64 rows).
+            if (__builtin_amdgcn_ballot_w64(j < jend) != 0) {
+                do {
+                    const bool act = j < jend;
 #if defined(IVX_FP_BCAST)
-                const u64 x = L.s_ent[__builtin_amdgcn_readfirstlane((u32)(pj - L.s_ent)) & 4095u];   // (profiling: one address per wavefront, no bank conflicts)
+                    const u64 x = L.s_ent[__builtin_amdgcn_readfirstlane(j) & 4095u];                  // (profiling: one address per wavefront, no bank conflicts)
 #else
-                const u64 x = *pj;                                       // (a lane past its list reads on inside LDS; its result is not used)
+                    const u64 x = L.s_ent[j];                            // (a lane past its list reads on inside LDS; its result is not used)
 #endif
 #if defined(IVX_FP_DUP)
-                { u64 y = *(const volatile u64 *)(pj + 1); asm volatile("" :: "v"(y)); }              // (profiling: every slice read twice)
+                    { u64 y = *(const volatile u64 *)(L.s_ent + j + 1); asm volatile("" :: "v"(y)); }  // (profiling: every slice read twice)
 #endif
-                const bool hit = act && (i32)(u32)x <= qe && (i32)(u32)(x >> 32) >= qs;
-                const u64 mm = __builtin_amdgcn_ballot_w64(hit);
-#if defined(IVX_FP_ABL) && IVX_FP_ABL == 1
-                wpos += (u32)__popcll(mm);
-#else
-                if (mm != 0) {
-                    if (hit) half[(wpos + mask_rank(mm)) & (HALF - 1)] = make_uint2((u32)(pj - L.s_ent), roww[q]);
+                    const bool hit = act && (i32)(u32)x <= qe && (i32)(u32)(x >> 32) >= qs;
+                    const u64 mm = __builtin_amdgcn_ballot_w64(hit);
+#if !(defined(IVX_FP_ABL) && IVX_FP_ABL == 1)
+                    if (__builtin_expect(hit, 1)) half[(wpos + mask_rank(mm)) & (HALF - 1)] = make_uint2(j, roww[q]);
+#endif
                     wpos += (u32)__popcll(mm);
-                }
-#endif
-                pj++;
+                    j++;
+                } while (__builtin_amdgcn_ballot_w64(j < jend) != 0);
             }
         }
         u32 got = wpos;

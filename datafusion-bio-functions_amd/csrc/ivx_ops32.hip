@@ -278,6 +278,23 @@ struct NearestCtx {
 // (issuing the two rank lookups side by side and loading the two records the decision needs together -- three dependent
 //  round trips instead of five or six -- was measured and dropped: routed probe 3.66 -> 4.5 ms, sorted 1.5 -> 1.6 ms per 50M
 //  rows; the probe is bound by the sectors it misses, not by the length of its dependency chain)
+// pmax_first: the same answer from ONE rank lookup when the row does overlap something.  idx = the key's first position whose
+// running max of ends reaches qs; the row there has end >= qs itself (it is where the maximum first got there), every
+// overlapping row sits at or behind it, and rows are in start order: so it is the first overlap iff its start <= qe, i.e. iff
+// idx < pend -- the reference's test prefix_max_end[pend - 1] >= qs says exactly that -- and if its start is beyond qe nothing
+// overlaps.  The by_start rank (pend) is then only looked up for rows WITHOUT an overlap, which still need it: two or three
+// index sectors per overlapping row instead of five or six (the routed probe is bound by the sectors it misses).
+__device__ __forceinline__ bool first_overlap_pmax(const NearestCtx &x, u32 k, u32 off, u32 cnt, i32 qs, i32 qe, Cand *out)
+{
+    if (qe < qs) return false;
+    const u32 idx = grid_rank_lt<4>(x.nv.pmax, x.sh_p, k, qs);       // prefix_max_end.partition_point(< start), over the whole key
+    if (idx >= off + cnt) return false;
+    const Cand c = x.by_start(idx);
+    if (c.s > qe) return false;
+    *out = c;
+    return true;
+}
+
 __device__ __forceinline__ bool first_overlap(const NearestCtx &x, u32 k, u32 off, i32 qs, i32 qe, u32 *plen_abs, Cand *out)
 {
     const u32 pend = grid_rank_le<4>(x.nv.by_start, x.sh_s, k, qe);  // by_start.partition_point(first <= end)
@@ -291,14 +308,18 @@ __device__ __forceinline__ bool first_overlap(const NearestCtx &x, u32 k, u32 of
 }
 
 // the one nearest build row of key k for the (already strict-adjusted) query [qs,qe]
-__device__ __forceinline__ bool nearest_one(const NearestCtx &x, u32 k, i32 qs, i32 qe, int include_overlaps, Cand *best)
+__device__ __forceinline__ bool nearest_one(const NearestCtx &x, u32 k, i32 qs, i32 qe, int include_overlaps, Cand *best, bool pmax_first = false)
 {
     const NearestView &nv = x.nv;
     bool found = false;
     if (k < nv.by_start.nkeys && nv.by_start.kcnt[k] != 0) {
         const u32 off = nv.by_start.koff[k], cnt = nv.by_start.kcnt[k];
-        u32 pend;
-        if (include_overlaps) found = first_overlap(x, k, off, qs, qe, &pend, best);
+        u32 pend = 0;
+        if (include_overlaps && pmax_first) {
+            found = first_overlap_pmax(x, k, off, cnt, qs, qe, best);
+            if (!found) pend = grid_rank_le<4>(nv.by_start, x.sh_s, k, qe);
+        }
+        else if (include_overlaps) found = first_overlap(x, k, off, qs, qe, &pend, best);
         else pend = grid_rank_le<4>(nv.by_start, x.sh_s, k, qe);
         if (!found) {                                                    // nearest_non_overlap_one :192-220
             const u32 li = grid_rank_lt<4>(nv.by_end, x.sh_e, k, qs);    // by_end.partition_point(last < start)
@@ -316,7 +337,7 @@ __device__ __forceinline__ bool nearest_one(const NearestCtx &x, u32 k, i32 qs, 
 // gate (nullable): run only if *gate == 0 (the routed path found the probe rows in region order and moved nothing)
 __global__ __launch_bounds__(OT) void k_probe_nearest1(NearestView nv, const u32 *__restrict__ pkey, const i32 *__restrict__ ps,
                                                        const i32 *__restrict__ pe, u64 n, int strict, int include_overlaps,
-                                                       u32 *__restrict__ ob, u32 *__restrict__ op, i64 *__restrict__ od, const u32 *gate)
+                                                       u32 *__restrict__ ob, u32 *__restrict__ op, i64 *__restrict__ od, const u32 *gate, int pmax_first = 1)
 {
     if (gate && *gate != 0) return;
     NearestCtx x; x.nv = nv; x.sh_s = nv.by_start.hdr[0]; x.sh_e = nv.by_end.hdr[0]; x.sh_p = nv.pmax.hdr[0];
@@ -328,8 +349,8 @@ __global__ __launch_bounds__(OT) void k_probe_nearest1(NearestView nv, const u32
         Cand best{};
         bool found;
         const u32 k0 = (u32)__builtin_amdgcn_readfirstlane((int)k);       // sorted probe rows: one key per wavefront, its per-key tables (fifteen lookups per row) go through the scalar unit: 2.0 -> 1.5 ms per 50M rows
-        if (__ballot(k != k0) == 0) found = nearest_one(x, k0, qs, qe, include_overlaps, &best);
-        else found = nearest_one(x, k, qs, qe, include_overlaps, &best);
+        if (__ballot(k != k0) == 0) found = nearest_one(x, k0, qs, qe, include_overlaps, &best, pmax_first != 0);
+        else found = nearest_one(x, k, qs, qe, include_overlaps, &best, pmax_first != 0);
         ob[i] = found ? best.row : IVX_NULL_IDX;
         op[i] = (u32)i;
         if (od) od[i] = found ? cand_dist(rs, re, best.s, best.e) : -1;  // raw coordinates, nearest.rs:367-374
@@ -342,7 +363,7 @@ __global__ __launch_bounds__(OT) void k_probe_nearest1(NearestView nv, const u32
 constexpr int NR_T = 256;
 __global__ __launch_bounds__(NR_T) void k_nearest_routed(NearestView nv, const u32 *__restrict__ rkey, u32 nreg, const u64 *__restrict__ pse,
                                                          const u32 *__restrict__ offs, u32 nblk, u32 adj, int include_overlaps,
-                                                         u32 *__restrict__ vb, i64 *__restrict__ vd, const u32 *unsorted)
+                                                         u32 *__restrict__ vb, i64 *__restrict__ vd, const u32 *unsorted, int pmax_first)
 {
     __shared__ u32 s_rfirst[IVX_MAXREG_WIDE + 2];
     if (*unsorted == 0) return;
@@ -364,7 +385,7 @@ __global__ __launch_bounds__(NR_T) void k_nearest_routed(NearestView nv, const u
         // (reading the per-key tables through the scalar unit when the wavefront shares its region, as k_probe_nearest1
         // does, is slower here -- 2.6 -> 2.85 ms per 50M rows: the lanes' reads of one address are a single request already,
         // and this kernel waits on the scattered index sectors of its unsorted rows, not on issuing loads)
-        const bool found = nearest_one(x, k, qs, qe, include_overlaps, &best);
+        const bool found = nearest_one(x, k, qs, qe, include_overlaps, &best, pmax_first != 0);
         vb[i] = found ? best.row : IVX_NULL_IDX;
         if (vd) vd[i] = found ? cand_dist(wsub(qs, (i32)adj), wadd(qe, (i32)adj), best.s, best.e) : -1;
     }
@@ -908,10 +929,11 @@ ivx_status ivx_nearest_probe(ivx_ctx *ctx, const ivx_index *ix, const u32 *key, 
             u32 *vb; i64 *vd = nullptr;
             IVX_TRY(ctx->get_scratch(WS_T2, n * sizeof(u32), (void **)&vb));
             if (od) IVX_TRY(ctx->get_scratch(WS_T3, n * sizeof(i64), (void **)&vd));
+            const int pmax_first = getenv("IVX_NEAREST_PMAX_FIRST") ? atoi(getenv("IVX_NEAREST_PMAX_FIRST")) : 1;
             // five 256-thread workgroups per CU, not eight: the rows in flight on an XCD then span less of the index than its L2
             // holds (grid 2048 -> 1280: 3.75 -> 3.17 ms per 50M rows; 1024..1536 are within 3 %, 1792 and 2048 fall off)
             hipLaunchKernelGGL(k_nearest_routed, dim3((ivx_stream_grid(n, NR_T * 4, 1280u) + 7u) & ~7u), dim3(NR_T), 0, st, ix->nv, ix->nroute.rkey, ix->nroute_nreg, R.pse,
-                               R.hist, R.nblk, strict ? 1u : 0u, include_overlaps, vb, vd, R.unsorted);
+                               R.hist, R.nblk, strict ? 1u : 0u, include_overlaps, vb, vd, R.unsorted, pmax_first);
             IVX_TRY(ivx_unroute_pair(ctx, R, n, vb, vd, ob, op, od, -1));
             // rows that came in region order were not moved: the plain kernel answers them in place
             hipLaunchKernelGGL(k_probe_nearest1, dim3(ivx_stream_grid(n, OT * 4)), dim3(OT), 0, st, ix->nv, key, s, e, n, strict, include_overlaps, ob, op, od, R.unsorted);
