@@ -481,7 +481,7 @@ static ivx_status overlap_common(ivx_ctx *ctx, const ivx_index *ix, int mem, int
             if (mode == JP_COUNT && pl.valid) { memcpy(pl.in, in, sizeof(in)); pl.mem = mem; pl.n = n; pl.ix = ix; pl.ix_serial = ix->serial; pl.stream = ctx->stream; }
         }
         else if (rowval) IVX_TRY(ivx_rowval_probe_regions(ctx, ix->jv, ix->jv_nreg, mode == JP_PER_ROW ? IVX_RV_PER_ROW : IVX_RV_EXISTS, dk, ds, de, n, 0,
-                                                          mode == JP_PER_ROW ? (void *)d_row : (void *)d_ex, ctx->d_scalars, ix->jv_filter, ix->jv_pk24));
+                                                          mode == JP_PER_ROW ? (void *)d_row : (void *)d_ex, ctx->d_scalars, ix->jv_filter, ix->jv_pk24, ix->jv_fast && !ix->jv_fast_unknown));
         else if (n && (mode == JP_PER_ROW || mode == JP_EXISTS) && ix->nroute_nreg > 0 && rowval_routed_ok(n))
             IVX_TRY(ivx_join_rowval_routed(ctx, ix, mode, dk, ds, de, n, d_row, d_ex, ctx->d_scalars));   // too many regions for the LDS slices: route, gather, put back
         else IVX_TRY(ivx_join_probe(ctx, ix->jv, mode, dk, ds, de, n, d_row, d_ex, d_b, d_p, cap, ctx->d_scalars));

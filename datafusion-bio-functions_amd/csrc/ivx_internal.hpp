@@ -268,6 +268,6 @@ ivx_status ivx_route_rows(ivx_ctx *ctx, const JoinIndexView &rv, const u32 *key,
 ivx_status ivx_unroute_pair(ivx_ctx *ctx, const ivx_routed &r, u64 n, const u32 *vb, const i64 *vd, u32 *ob, u32 *op, i64 *od, i64 dflt);
 ivx_status ivx_rowval_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nreg, int kind,
                                     const u32 *key, const i32 *s, const i32 *e, u64 n, int strict, void *out, u64 *d_total,
-                                    bool has_filter = false, bool pk24 = false);
+                                    bool has_filter = false, bool pk24 = false, bool fast = false);
 
 ivx_status ivx_index_alloc(ivx_ctx *ctx, ivx_index *ix, size_t bytes, void **out);

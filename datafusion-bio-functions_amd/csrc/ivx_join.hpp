@@ -18,9 +18,9 @@ __device__ __forceinline__ u32 cell_of(const i32 *origin, const u32 *lbase, u32 
     return lbase[(u64)l * nkeys + k] + (sh >= 32 ? 0u : off >> sh);
 }
 
-// visit every build row of key k overlapping [qs,qe] that sits in levels lev0..nlev-1
+// visit every build row of key k overlapping [qs,qe] that sits in levels lev0..nlev-1: f(entry)
 template <class F>
-__device__ __forceinline__ void walk(const JoinIndexView &ix, u32 sh0, u32 lev0, u32 nlev, u32 k, i32 qs, i32 qe, F &&f)
+__device__ __forceinline__ void walk_ent(const JoinIndexView &ix, u32 sh0, u32 lev0, u32 nlev, u32 k, i32 qs, i32 qe, F &&f)
 {
     if (k >= ix.nkeys) return;
     if (ix.kcnt[k] == 0) return;
@@ -46,8 +46,14 @@ __device__ __forceinline__ void walk(const JoinIndexView &ix, u32 sh0, u32 lev0,
         const u32 a = ix.binstart[base + blo], b = ix.binstart[base + bhi + 1];
         for (u32 j = a; j < b; j++) {
             const ivx_ent x = ix.ent[j];
-            if (x.s <= qe && x.e >= qs) f(x.row);
+            if (x.s <= qe && x.e >= qs) f(x);
         }
     }
+}
+// ... f(build row)
+template <class F>
+__device__ __forceinline__ void walk(const JoinIndexView &ix, u32 sh0, u32 lev0, u32 nlev, u32 k, i32 qs, i32 qe, F &&f)
+{
+    walk_ent(ix, sh0, lev0, nlev, k, qs, qe, [&](const ivx_ent &x) { f(x.row); });
 }
 

@@ -1481,6 +1481,156 @@ __global__ __launch_bounds__(256) void k_fill_rest(JoinIndexView ix, const u64 *
     }
 }
 
+// ------------------------------------------------------------------ lean per-row-value probe (round 3)
+// count_overlaps / the join's rle_right and exists (RV_COUNT, RV_MATCHES) and coverage (RV_COVERAGE) over packed rows in region
+// pages when every region is one LDS-resident level: k_fill_fast's row streaming and walk without a ring, rounds or any
+// synchronisation between wavefronts -- a row's value replaces the low half of its packed word in place, as in
+// k_probe_regions<RV_*>.  Rows the packed form cannot carry are listed (region, virtual row) and valued by k_rv_rest with the
+// generic walk over the index in global memory.
+#ifndef IVX_RV_WPS
+#define IVX_RV_WPS 4
+#endif
+#ifndef IVX_RV_B
+#define IVX_RV_B 8
+#endif
+template <int KIND, int B>
+__global__ __launch_bounds__(RP_T, IVX_RV_WPS) void k_rv_fast(JoinIndexView ix, u64 *__restrict__ pool, const u32 *__restrict__ rcur, const u32 *__restrict__ cfirst,
+                                                  PageTab pt, u32 rowbits, u64 *__restrict__ rest_rows, u32 *rest_n)
+{
+    constexpr u32 WB = IVX_WAVE * B, SUB = 8u / B;
+    __shared__ unsigned short s_off[RP_CCAP];
+    __shared__ u64 s_ent[RP_ECAP];
+    __shared__ u32 s_cfirst[IVX_MAXREG_WIDE + 2];
+    ProbeLds L{s_off, s_ent, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    const u32 wv = __builtin_amdgcn_readfirstlane(threadIdx.x / IVX_WAVE), ln = lane_id();
+    const u32 nreg = ix.hdr[HDR_NREG];
+    for (u32 t = threadIdx.x; t <= nreg; t += RP_T) s_cfirst[t] = cfirst[t];
+    __syncthreads();
+    const u32 nchunk = s_cfirst[nreg];
+    const u32 c_lo = (u32)((u64)nchunk * blockIdx.x / gridDim.x), c_hi = (u32)((u64)nchunk * (blockIdx.x + 1) / gridDim.x);
+    if (c_lo >= c_hi) return;
+    const u32 maxlen = pk_maxlen(rowbits);
+    const u32 pmask = (1u << pt.lgpg) - 1u;
+    Slice S;
+    slice_init(ix, S, L);
+    u32 r_next;
+    { u32 a = 0, b = nreg; while (a < b) { const u32 m = (a + b + 1) >> 1; if (s_cfirst[m] <= c_lo) a = m; else b = m - 1; } r_next = a; }
+    const u32 nbatch = (c_hi - c_lo) * SUB;
+    u64 nx[B];
+    u32 ncnt = 0, nfirst = 0; u64 *nsrc = pool;
+    auto prefetch = [&](u32 i) {
+        const u32 c = c_lo + i / SUB, sb = i % SUB;
+        while (c >= s_cfirst[r_next + 1]) r_next++;
+        nfirst = (c - s_cfirst[r_next]) * FP_CHUNK + wv * (8u * IVX_WAVE) + sb * WB;
+        const u32 rows = rcur[r_next];
+        ncnt = rows > nfirst ? (rows - nfirst < WB ? rows - nfirst : WB) : 0u;
+        if (ncnt) {
+            u32 pg = pt.ptab[(u64)r_next * pt.pstride + (nfirst >> pt.lgpg)];
+            if (pg == 0u) pg = 1u;                                       // (never published: see pages_load; stay in bounds)
+            nsrc = pool + (((u64)(pg - 1u) << pt.lgpg) + (nfirst & pmask));
+#pragma unroll
+            for (int q = 0; q < B; q++) nx[q] = nsrc[q * IVX_WAVE + ln];
+        }
+    };
+    prefetch(0);
+    u32 loaded_r = 0xFFFFFFFFu;
+    for (u32 i = 0; i < nbatch; i++) {
+        const u32 r = r_next, cnt = ncnt, first = nfirst;
+        u64 *dst = nsrc;
+        if (r != loaded_r) { slice_load(ix, S, L, r, true); loaded_r = r; }
+        const bool full = cnt == WB;
+        u32 rel[B], len[B], roww[B];
+#pragma unroll
+        for (int q = 0; q < B; q++) {
+            const u32 lo32 = (u32)nx[q], hi32 = (u32)(nx[q] >> 32);
+            rel[q] = lo32 & 0xFFFFFFu;
+            len[q] = (lo32 >> 24) | ((rowbits < 32 ? (hi32 >> rowbits) & 0xFFu : 0u) << 8);
+            roww[q] = hi32;                                              // (the un-permute masks the row id out of it)
+        }
+        if (i + 1 < nbatch) prefetch(i + 1);
+        const u32 sh0 = S.sh0, off = S.off, cmax = S.cmax, ncm1 = S.ncm1;
+        const i32 rbase = S.rbase;
+        u32 ca[B], cb[B], slow = 0, okm = 0;
+        auto cells = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+            for (int q = 0; q < B; q++) {
+                const u32 t = ((rel[q] + 1u) >> sh0) + off;
+                const u32 bl0 = (t > 1u ? t : 1u) - 1u;
+                const u32 bh0 = ((rel[q] + len[q]) >> sh0) + off;
+                const u32 bh = bh0 < cmax ? bh0 : cmax;
+                bool bad = len[q] == maxlen || bh >= ncm1;
+                const bool ok = FULL || (u32)q * IVX_WAVE + ln < cnt;
+                if (ok && bad) slow |= 1u << q;
+                if (ok && !bad) okm |= 1u << q;
+                bad |= !ok;
+                const u32 e1 = bad ? 0u : bh + 1u;
+                const u32 bl = bl0 < e1 ? bl0 : e1;
+                ca[q] = s_off[bl];
+                cb[q] = s_off[e1];
+            }
+        };
+        if (full) cells(std::true_type{}); else cells(std::false_type{});
+#pragma unroll
+        for (int q = 0; q < B; q++) {
+            const i32 qs = (i32)((u32)rbase + rel[q]), qe = (i32)((u32)qs + len[q]);
+            const i32 ca1 = rv_wadd(qe, 1), cb1 = rv_wsub(qs, 1);        // coverage: the closed query grown by one on either side
+            u32 v = 0;
+            for (u32 j = ca[q]; j < cb[q]; j++) {
+                const u64 x = s_ent[j];
+                const i32 xs = (i32)(u32)x, xe = (i32)(u32)(x >> 32);
+                if (xs <= qe && xe >= qs) {
+                    if (KIND == RV_COVERAGE) { const i32 d = rv_wsub(ca1 < xe ? ca1 : xe, cb1 > xs ? cb1 : xs); v = (u32)rv_wadd((i32)v, d > 1 ? d : 1); }
+                    else v++;
+                }
+            }
+            if ((okm >> q) & 1u) dst[q * IVX_WAVE + ln] = (u64)v | ((u64)roww[q] << 32);
+        }
+        if (__builtin_expect(slow != 0, 0)) {
+#pragma unroll
+            for (int q = 0; q < B; q++)
+                if ((slow >> q) & 1u) rest_rows[atomicAdd(rest_n + 1, 1u)] = (u64)(first + (u32)q * IVX_WAVE + ln) | ((u64)r << 32);
+        }
+    }
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void k_rv_rest(JoinIndexView ix, u64 *__restrict__ pool, PageTab pt, const u64 *__restrict__ rest_rows,
+                                                 const u32 *__restrict__ rest_n, const i32 *__restrict__ ps_in, const i32 *__restrict__ pe_in,
+                                                 u32 rowbits, u32 adj)
+{
+    const u32 nrow = rest_n[1];
+    const u32 rowmask = rowbits >= 32 ? 0xFFFFFFFFu : (1u << rowbits) - 1u;
+    const u32 maxlen = pk_maxlen(rowbits);
+    const u32 pmask = (1u << pt.lgpg) - 1u;
+    const u32 sh0 = ix.hdr[HDR_SH0], nlev = ix.hdr[HDR_NLEV];
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < nrow; i += gridDim.x * blockDim.x) {
+        const u64 ent = rest_rows[i];
+        const u32 r = (u32)(ent >> 32), vr = (u32)ent;
+        u32 pg = pt.ptab[(u64)r * pt.pstride + (vr >> pt.lgpg)];
+        if (pg == 0u) pg = 1u;
+        u64 *slot = pool + (((u64)(pg - 1u) << pt.lgpg) + (vr & pmask));
+        const u64 x = *slot;
+        const u32 lo32 = (u32)x, hi32 = (u32)(x >> 32);
+        const u32 len = (lo32 >> 24) | ((rowbits < 32 ? (hi32 >> rowbits) & 0xFFu : 0u) << 8);
+        const u32 row = hi32 & rowmask;
+        i32 qs, qe;
+        if (len == maxlen) { qs = (i32)((u32)ps_in[row] + adj); qe = (i32)((u32)pe_in[row] - adj); }
+        else { qs = (i32)((u32)ix.rdesc[r].rbase + (lo32 & 0xFFFFFFu)); qe = (i32)((u32)qs + len); }
+        u32 v = 0;
+        if (KIND == RV_COVERAGE) {
+            const i32 a = rv_wadd(qe, 1), b = rv_wsub(qs, 1);
+            walk_ent(ix, sh0, 0, nlev, ix.rkey[r], qs, qe, [&](const ivx_ent &n) {
+                const i32 d = rv_wsub(a < n.e ? a : n.e, b > n.s ? b : n.s);
+                v = (u32)rv_wadd((i32)v, d > 1 ? d : 1);
+            });
+        } else if (KIND != RV_COUNT || !(qe < qs)) {
+            walk_ent(ix, sh0, 0, nlev, ix.rkey[r], qs, qe, [&](const ivx_ent &) { v++; });
+        }
+        *slot = (u64)v | ((u64)hi32 << 32);
+    }
+}
+
 // ------------------------------------------------------------------ match-dense fill: count, scan, write
 // With several pairs per probe row the staging ring holds only one 64-row batch per wavefront and the 16
 // wavefronts of a workgroup end up in lock step, round after round.  For such joins the pairs are written in two
@@ -1803,7 +1953,7 @@ __global__ __launch_bounds__(512) void k_unpermute_paged(const u64 *__restrict__
 // join's rle_right: u32 out, *d_total += all matches), IVX_RV_EXISTS (semi / anti join: u8 out).
 ivx_status ivx_rowval_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nreg, int kind,
                                     const u32 *key, const i32 *s, const i32 *e, u64 n, int strict, void *out, u64 *d_total,
-                                    bool has_filter, bool pk24)
+                                    bool has_filter, bool pk24, bool fast)
 {
     if (n == 0) return IVX_OK;
     if (nreg == 0 || nreg > IVX_MAXREG_WIDE) return ctx->fail(IVX_ERR_INVALID, "per-row region probe: one partition pass only");
@@ -1825,7 +1975,7 @@ ivx_status ivx_rowval_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 n
         const u64 npages = (n >> lgpg) + nreg + 1;
         const u64 ntiles = (n + TILE - 1) / TILE;
         u32 *ctl, *ptab; u64 *pool; uint2 *vtab;
-        IVX_TRY(ctx->get_scratch(WS_SORTHIST, (1024 + 8 + 1032) * sizeof(u32), (void **)&ctl));
+        IVX_TRY(ctx->get_scratch(WS_SORTHIST, (1024 + 8 + 1032 + 1032) * sizeof(u32), (void **)&ctl));
         IVX_TRY(ctx->get_scratch(WS_T2, (size_t)nreg * pstride * sizeof(u32), (void **)&ptab));
         IVX_TRY(ctx->get_scratch(WS_T0, (size_t)(npages << lgpg) * sizeof(u64), (void **)&pool));
         IVX_TRY(ctx->get_scratch(WS_T1, (size_t)ntiles * 256 * sizeof(uint2), (void **)&vtab));
@@ -1845,10 +1995,25 @@ ivx_status ivx_rowval_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 n
 #undef IVX_RVPART3
 #undef IVX_RVPART2
 #undef IVX_RVPART
+        // every region one LDS-resident level: the lean kernel values the rows, k_rv_rest the few the packed form cannot carry
+        // (IVX_FILL=old: the general kernel)
+        const bool lean = fast && lgpg >= 13 && !(getenv("IVX_FILL") && !strcmp(getenv("IVX_FILL"), "old"));
+        if (lean) {
+            u64 *rest_rows;
+            IVX_TRY(ctx->get_scratch(WS_T3, (size_t)(n + 64) * sizeof(u64), (void **)&rest_rows));
+            u32 *rest_n = ctl + 1024 + 4;
+            hipLaunchKernelGGL(k_chunk_bounds, dim3(1), dim3(1024), 0, st, (const u32 *)rcur, nreg, rf, rf + 1032);
+#define IVX_RVF(K_) do { \
+            hipLaunchKernelGGL((k_rv_fast<K_, IVX_RV_B>), dim3(RP_GRID * (IVX_RV_WPS / 4)), dim3(RP_T), 0, st, jv, pool, (const u32 *)rcur, (const u32 *)(rf + 1032), pt, rowbits, rest_rows, rest_n); \
+            hipLaunchKernelGGL((k_rv_rest<K_>), dim3(256), dim3(256), 0, st, jv, pool, pt, (const u64 *)rest_rows, (const u32 *)rest_n, s, e, rowbits, adj); } while (0)
+            if (kind == IVX_RV_COVERAGE) IVX_RVF(RV_COVERAGE); else if (kind == IVX_RV_COUNT) IVX_RVF(RV_COUNT); else IVX_RVF(RV_MATCHES);
+#undef IVX_RVF
+        } else {
         hipLaunchKernelGGL(k_page_bounds, dim3(1), dim3(1024), 0, st, (const u32 *)rcur, nreg, rf);
 #define IVX_RVP(M_) hipLaunchKernelGGL((k_probe_regions<M_, RP_B, false, true, true>), dim3(RP_VGRID), dim3(RP_T), 0, st, jv, (const void *)pool, (const void *)nullptr, (const u32 *)rf, 1u, 1u, (u32 *)pool, (u32 *)nullptr, (u64)0, (unsigned long long *)nullptr, 1u, adj, (const u32 *)nullptr, 0, pt, (const u32 *)nullptr, s, e, rowbits)
         if (kind == IVX_RV_COVERAGE) IVX_RVP(RV_COVERAGE); else if (kind == IVX_RV_COUNT) IVX_RVP(RV_COUNT); else IVX_RVP(RV_MATCHES);
 #undef IVX_RVP
+        }
 #define IVX_UPP(O_) hipLaunchKernelGGL((k_unpermute_paged<O_, (int)TILE>), dim3((u32)ntiles), dim3(512), 0, st, (const u64 *)pool, (const uint2 *)vtab, pt, nreg, rowbits, n, out, (unsigned long long *)d_total)
         switch (kind) {
         case IVX_RV_COVERAGE: IVX_UPP(UP_I64S); break;

@@ -894,7 +894,7 @@ static ivx_status rowval_routed(ivx_ctx *ctx, const ivx_index *ix, bool coverage
 ivx_status ivx_count_probe(ivx_ctx *ctx, const ivx_index *ix, const u32 *key, const i32 *s, const i32 *e, u64 n, int strict, i64 *out)
 {
     if (n == 0) return IVX_OK;
-    if (rowval_regions_wanted(ix, n)) return ivx_rowval_probe_regions(ctx, ix->jv, ix->jv_nreg, IVX_RV_COUNT, key, s, e, n, strict, out, nullptr, ix->jv_filter, ix->jv_pk24);
+    if (rowval_regions_wanted(ix, n)) return ivx_rowval_probe_regions(ctx, ix->jv, ix->jv_nreg, IVX_RV_COUNT, key, s, e, n, strict, out, nullptr, ix->jv_filter, ix->jv_pk24, ix->jv_fast);
     if (rowval_routed_wanted(ix, n)) return rowval_routed(ctx, ix, false, key, s, e, n, strict, out);
     hipLaunchKernelGGL(k_probe_count, dim3(ivx_stream_grid(n, OT * 4)), dim3(OT), 0, ctx->stream, ix->gs, ix->ge, key, s, e, n, strict, out, (const u32 *)nullptr);
     IVX_HIP(ctx, hipGetLastError());
@@ -904,7 +904,7 @@ ivx_status ivx_count_probe(ivx_ctx *ctx, const ivx_index *ix, const u32 *key, co
 ivx_status ivx_coverage_probe(ivx_ctx *ctx, const ivx_index *ix, const u32 *key, const i32 *s, const i32 *e, u64 n, int strict, i64 *out)
 {
     if (n == 0) return IVX_OK;
-    if (rowval_regions_wanted(ix, n)) return ivx_rowval_probe_regions(ctx, ix->jv, ix->jv_nreg, IVX_RV_COVERAGE, key, s, e, n, strict, out, nullptr, ix->jv_filter, ix->jv_pk24);
+    if (rowval_regions_wanted(ix, n)) return ivx_rowval_probe_regions(ctx, ix->jv, ix->jv_nreg, IVX_RV_COVERAGE, key, s, e, n, strict, out, nullptr, ix->jv_filter, ix->jv_pk24, ix->jv_fast);
     if (rowval_routed_wanted(ix, n)) return rowval_routed(ctx, ix, true, key, s, e, n, strict, out);
     hipLaunchKernelGGL(k_probe_coverage, dim3(ivx_stream_grid(n, OT * 4)), dim3(OT), 0, ctx->stream, ix->cv, key, s, e, n, strict, out, (const u32 *)nullptr);
     IVX_HIP(ctx, hipGetLastError());
