@@ -46,7 +46,33 @@ int main(void)
     printf("merge rows=%llu first=(%lld,%lld,%lld) second=(%lld,%lld,%lld)\n", (unsigned long long)m,
            (long long)os[0], (long long)oe[0], (long long)on[0], (long long)os[1], (long long)oe[1], (long long)on[1]);
 
+    /* round-3 entry points: a sharded per-row column back in input order (ivx_scatter_fixed), what the context has reserved,
+     * the memory limit, scratch back to the device (ivx_ctx_trim), the overlapped build switch */
+    const int64_t vals[3] = {30, 10, 20};
+    const uint32_t rows[3] = {3, 1, 2};
+    int64_t col[5] = {-1, -1, -1, -1, -1};
+    CHECK(ivx_scatter_fixed(ctx, IVX_MEM_HOST, vals, 8, rows, 3, col, 5));
+    const int scat_ok = col[0] == -1 && col[1] == 10 && col[2] == 20 && col[3] == 30 && col[4] == -1;
+    const uint32_t bad_rows[1] = {5};
+    const int scat_bad = ivx_scatter_fixed(ctx, IVX_MEM_HOST, vals, 8, bad_rows, 1, col, 5) == IVX_ERR_INVALID;
+    const uint64_t held = ivx_ctx_reserved_bytes(ctx);
+    CHECK(ivx_ctx_set_memory_limit(ctx, 1));                      /* one byte: the next build cannot reserve its index */
+    ivx_index *ix2 = NULL;
+    const int oom = ivx_index_build(ctx, IVX_KIND_OVERLAP, IVX_MEM_HOST, bk, bs, be, 10, 2, &ix2) == IVX_ERR_OOM && ix2 == NULL;
+    CHECK(ivx_ctx_set_memory_limit(ctx, 0));
+    CHECK(ivx_ctx_trim(ctx, 0));
+    const uint64_t after = ivx_ctx_reserved_bytes(ctx);
+    CHECK(ivx_ctx_set_build_overlap(ctx, 1));
+    CHECK(ivx_index_build(ctx, IVX_KIND_OVERLAP, IVX_MEM_HOST, bk, bs, be, 10, 2, &ix2));
+    uint64_t total2 = 0;
+    CHECK(ivx_probe_overlap_count(ctx, ix2, IVX_MEM_HOST, pk, ps, pe, 12, NULL, &total2));
+    CHECK(ivx_ctx_synchronize(ctx));
+    ivx_index_free(ix2);
+    printf("scatter ok=%d bad_index_refused=%d reserved=%llu after_trim=%llu oom=%d total2=%llu\n", scat_ok, scat_bad,
+           (unsigned long long)held, (unsigned long long)after, oom, (unsigned long long)total2);
+
     free(bi); free(pi);
     ivx_ctx_free(ctx);
+    if (!(scat_ok && scat_bad && held > 0 && after == 0 && oom && total2 == 16)) return 1;
     return (total == 16 && written == 16 && rle == 16 && ok && m == 2 && os[0] == 100 && oe[0] == 250 && on[0] == 2 && os[1] == 300) ? 0 : 1;
 }

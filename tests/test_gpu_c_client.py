@@ -20,3 +20,4 @@ def test_c_client_builds_and_runs(tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     assert "join pairs=16 written=16 rle_sum=16 valid=1" in r.stdout
     assert "merge rows=2 first=(100,250,2) second=(300,400,1)" in r.stdout
+    assert "scatter ok=1 bad_index_refused=1" in r.stdout and "after_trim=0 oom=1 total2=16" in r.stdout
