@@ -2483,7 +2483,7 @@ ivx_status ivx_join_probe_regions(ivx_ctx *ctx, const JoinIndexView &jv, u32 nre
                 FpRest *rest = (FpRest *)rest_buf;
                 u64 *rest_rows = (u64 *)(rest + fp_max_batches(n, nreg));
                 {
-                    IVX_HIP(ctx, hipMemsetAsync(rest_n, 0, 2 * sizeof(u32), st));
+                    if (planned) IVX_HIP(ctx, hipMemsetAsync(rest_n, 0, 2 * sizeof(u32), st));   // (else: zeroed with the routing pass's counters just now)
 #define IVX_FILLF(B_) hipLaunchKernelGGL((k_fill_fast<B_>), dim3(RP_GRID), dim3(RP_T), 0, st, jv, pool_se, (const u32 *)ctl, (const u32 *)(rfirst + 1032), pt, ob, op, cap, cur, (const u32 *)bsel, rowbits, rest, rest_rows, rest_n)
                     if (bsel) { IVX_FILLF(8); IVX_FILLF(4); IVX_FILLF(2); IVX_FILLF(1); }
                     else switch (fill_rows_per_lane(hint, n)) { case 1: IVX_FILLF(1); break; case 2: IVX_FILLF(2); break; case 4: IVX_FILLF(4); break; default: IVX_FILLF(8); }
