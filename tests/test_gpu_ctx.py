@@ -145,4 +145,13 @@ def test_build_overlap_gives_the_same_pairs():
         ix.free()
     ix = a.build(pyivx.KIND_OVERLAP, bk, bs, be, n_keys=24)
     ix.free()                                                    # freed with its tail possibly still running
+    # a build side the lean fill kernel does not take (long rows: several index levels): with the tail overlapped the host does
+    # not know that when it launches the fill -- the kernels decide on the device
+    lk, ls, le = synth.gen_torch(200_000, 30_000, 24, 23, dev)
+    want2 = orc.pair_keys(*orc.join_single(lk.cpu().numpy().view(np.uint32), ls.cpu().numpy(), le.cpu().numpy(), *hp, threads=8))
+    ix = a.build(pyivx.KIND_OVERLAP, lk, ls, le, n_keys=24)
+    b, p = a.overlap_fill(ix, pk, ps, pe, cap=len(want2))
+    assert np.array_equal(keys(b, p), want2)
+    a.synchronize()
+    ix.free()
     a.close(); other.close()
