@@ -30,12 +30,13 @@ struct Pack64 { i64 min_s, min_e; u32 bits_s, bits_e; const u64 *base; const lon
 struct SortedRows {
     const u32 *ks; const i64 *ss, *es;
     const u32 *s32, *e32; i64 min_s, min_e;
+    const u8 *k8;               // narrow rows of at most 256 keys: the key column as bytes (ks' storage)
 #ifdef __HIPCC__
     // row i: its key, start, end and whether it is the first row of its key
     __device__ __forceinline__ void get(u64 i, u32 &k, i64 &s, i64 &e, bool &first) const
     {
-        k = ks[i];
-        first = i == 0 || ks[i - 1] != k;
+        if (k8 != nullptr) { k = k8[i]; first = i == 0 || k8[i - 1] != k; }
+        else { k = ks[i]; first = i == 0 || ks[i - 1] != k; }
         if (s32 != nullptr) { s = (i64)((u64)min_s + s32[i]); e = (i64)((u64)min_e + e32[i]); }
         else { s = ss[i]; e = es[i]; }
     }

@@ -193,7 +193,8 @@ constexpr u32 FIX_MAXRUN = 64;
 constexpr u32 UNPACK_TILES = 8;
 // NARROW: start and end leave as 32-bit offsets from p.min_s / p.min_e (the columns' storage is used as u32 arrays): 12
 // instead of 20 bytes per row here and in every pass of the merge sweep behind it (SortedRows, ivx_runs.hpp)
-template <bool FIX, bool NARROW = false>
+// ... and the key as one byte when there are at most 256 keys (K8)
+template <bool FIX, bool NARROW = false, bool K8 = false>
 __global__ __launch_bounds__(ST) void k_unpack1(const u64 *__restrict__ w0, const u32 *__restrict__ w1, u64 n, Pack64 p,
                                                 u32 *ks, i64 *ss, i64 *es, u32 *rows, u32 lo_bits, u32 *toolong)
 {
@@ -252,10 +253,11 @@ __global__ __launch_bounds__(ST) void k_unpack1(const u64 *__restrict__ w0, cons
         if (p.lin) {
             const u64 lin = shr64(w, p.bits_e);
             const u32 k = lin_key64(s_base, p.nkeys, lin);
-            ks[pos] = k;
+            if (K8) ((u8 *)ks)[pos] = (u8)k; else ks[pos] = k;
             so = (u64)p.kmin[k] + (lin - s_base[k]) - (u64)p.min_s;
         } else {
-            ks[pos] = (u32)shr64(w, p.bits_s + p.bits_e);
+            const u32 k = (u32)shr64(w, p.bits_s + p.bits_e);
+            if (K8) ((u8 *)ks)[pos] = (u8)k; else ks[pos] = k;
             so = low64(shr64(w, p.bits_e), p.bits_s);
         }
         if (NARROW) { ((u32 *)ss)[pos] = (u32)so; ((u32 *)es)[pos] = (u32)low64(w, p.bits_e); }
@@ -331,7 +333,8 @@ ivx_status sort64(ivx_ctx *ctx, int slot_a, int slot_b, const u32 *key, const i6
     // complement / the right side of subtract do not: equal words are equal rows, and the record is 8 bytes instead of 12)
     const int nw = total <= 64 ? 1 : 3;
     narrow = narrow && nw == 1 && (u64)r.max_s - (u64)r.min_s <= 0xFFFFFFFFull && (u64)r.max_e - (u64)r.min_e <= 0xFFFFFFFFull;
-    if (narrow) { sw->s32 = (const u32 *)ss; sw->e32 = (const u32 *)es; sw->min_s = r.min_s; sw->min_e = r.min_e; }
+    const bool k8 = narrow && nkeys <= 256 && !getenv("IVX_NO_K8");
+    if (narrow) { sw->s32 = (const u32 *)ss; sw->e32 = (const u32 *)es; sw->min_s = r.min_s; sw->min_e = r.min_e; if (k8) sw->k8 = (const u8 *)ks; }
     for (int q = 0; q < nw; q++) {
         IVX_TRY(ctx->get_scratch(slot_a + q, n * sizeof(u64), (void **)&a[q]));
         IVX_TRY(ctx->get_scratch(slot_b + q, n * sizeof(u64), (void **)&b[q]));
@@ -357,7 +360,10 @@ ivx_status sort64(ivx_ctx *ctx, int slot_a, int slot_b, const u32 *key, const i6
             IVX_TRY(ivx_radix_sort(ctx, 1, a, b, n, f, 1, &in_b, true, with_rows ? pay : nullptr));
             o = in_b ? b : a;
             u32 *toolong = flags + 1;                                   // (upper half of the key-flag word; zeroed by the caller)
-            if (narrow)
+            if (narrow && k8)
+            hipLaunchKernelGGL((k_unpack1<true, true, true>), dim3((grid1(n) + UNPACK_TILES - 1) / UNPACK_TILES), dim3(ST), 0, st, (const u64 *)o[0], (const u32 *)pay[in_b], n, p, ks, ss, es, rows,
+                               p.bits_e, toolong);
+            else if (narrow)
             hipLaunchKernelGGL((k_unpack1<true, true>), dim3((grid1(n) + UNPACK_TILES - 1) / UNPACK_TILES), dim3(ST), 0, st, (const u64 *)o[0], (const u32 *)pay[in_b], n, p, ks, ss, es, rows,
                                p.bits_e, toolong);
             else
@@ -375,7 +381,10 @@ ivx_status sort64(ivx_ctx *ctx, int slot_a, int slot_b, const u32 *key, const i6
             const ivx_sort_field f[1] = {{0, 0, (int)((total + 7) / 8 * 8)}};
             IVX_TRY(ivx_radix_sort(ctx, 1, a, b, n, f, 1, &in_b, true, with_rows ? pay : nullptr));
             o = in_b ? b : a;
-            if (narrow)
+            if (narrow && k8)
+            hipLaunchKernelGGL((k_unpack1<false, true, true>), dim3((grid1(n) + UNPACK_TILES - 1) / UNPACK_TILES), dim3(ST), 0, st, (const u64 *)o[0], (const u32 *)pay[in_b], n, p, ks, ss, es, rows,
+                               0u, (u32 *)nullptr);
+            else if (narrow)
             hipLaunchKernelGGL((k_unpack1<false, true>), dim3((grid1(n) + UNPACK_TILES - 1) / UNPACK_TILES), dim3(ST), 0, st, (const u64 *)o[0], (const u32 *)pay[in_b], n, p, ks, ss, es, rows,
                                0u, (u32 *)nullptr);
             else
