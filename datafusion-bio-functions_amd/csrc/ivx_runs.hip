@@ -243,6 +243,256 @@ static ivx_status sweep(ivx_ctx *ctx, const SortedRows &rows, u64 n,
     return IVX_OK;
 }
 
+namespace {
+
+// ---------------------------------------------------------------------------------------------- one-pass merge sweep
+// The whole sweep in ONE kernel over the sort's packed 8-byte words (Pack64), for the inputs every caller meets: rows with
+// start <= end, min_dist >= 0 (and, strict with min_dist = 0, no empty row).  For those
+//   * cur_end before a row is simply the largest end among the earlier rows of its key -- a run head starts beyond every
+//     earlier end, so the maximum over the key is the maximum over the current run;
+//   * the order of rows with the same (key, start) does not matter: the first of them decides head-or-not by the same test,
+//     the others merge into it, cur_end after the group is the maximum either way -- so the words need only be sorted on
+//     their (key, start) bits, not repaired by end.
+// With V = (key + 1) << bits_e | (end - min_e) the segmented running maximum is a plain one (a later key's V beats every
+// earlier one), and both device-wide scans -- the maximum, then the run heads counted against it -- are chained through
+// per-tile status words (decoupled look-back: flag in the low two bits, 1 = the tile's own aggregate, 2 = inclusive prefix)
+// by tiles that take their number from a counter, so every predecessor of a tile is resident or done.  Unpack + three
+// passes over 12-byte rows become one kernel that reads the 8-byte word once and writes the runs.
+// A run is emitted by the head that FOLLOWS it (which holds cur_end before itself = the run's end, and the previous head's
+// row number), the last one by row n - 1.
+constexpr int FT = 512, FI = 8, FTILE = FT * FI, FWV = FT / IVX_WAVE;
+
+__device__ __forceinline__ u64 ld_status(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_status(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+struct MaxPay {
+    __device__ static u64 ident() { return 0; }
+    __device__ static u64 comb(u64 a, u64 b) { return a > b ? a : b; }
+};
+struct HeadPay {                                   // heads so far << 31 | (row number of the latest head) + 1
+    __device__ static u64 ident() { return 0; }
+    __device__ static u64 comb(u64 a, u64 b)
+    {
+        const u64 la = a & 0x7FFFFFFFull, lb = b & 0x7FFFFFFFull;
+        return (((a >> 31) + (b >> 31)) << 31) | (la > lb ? la : lb);
+    }
+};
+
+// one whole wavefront: the exclusive prefix of tile `tile` (payloads of 62 bits), leaving the tile's inclusive one behind
+template <class P>
+__device__ __forceinline__ u64 lookback(u64 *st, u32 tile, u64 agg)
+{
+    const u32 ln = lane_id();
+    u64 excl = P::ident();
+    if (tile > 0) {
+        long long hi = (long long)tile - 1;
+        for (;;) {
+            const long long t = hi - (long long)ln;
+            u64 v = 2;                                                  // before tile 0: an inclusive identity
+            if (t >= 0) v = ld_status(st + t);
+            while (__ballot((v & 3) == 0)) {
+                __builtin_amdgcn_s_sleep(1);
+                if (t >= 0 && (v & 3) == 0) v = ld_status(st + t);
+            }
+            const u64 incl = __ballot((v & 3) == 2);
+            const u32 first = incl ? (u32)__builtin_ctzll(incl) : 64u;
+            u64 pay = ln <= first ? (v >> 2) : P::ident();
+#pragma unroll
+            for (int dd = IVX_WAVE / 2; dd > 0; dd >>= 1) pay = P::comb(pay, __shfl_xor(pay, dd, IVX_WAVE));
+            excl = P::comb(excl, pay);
+            if (incl) break;
+            hi -= IVX_WAVE;
+        }
+    }
+    if (ln == 0) st_status(st + tile, 2 | (P::comb(excl, agg) << 2));
+    return excl;
+}
+
+__device__ __forceinline__ u64 f_shr(u64 x, u32 sh) { return sh >= 64 ? 0 : x >> sh; }
+__device__ __forceinline__ u64 f_low(u64 x, u32 bits) { return bits >= 64 ? x : x & ((1ull << bits) - 1); }
+
+template <bool LIN>
+__global__ __launch_bounds__(FT, 4) void k_merge_fused(const u64 *__restrict__ w, u64 n, Pack64 p, i64 d, int strict, ivx_runs_out out,
+                                                   u64 *st1, u64 *st2, u32 *ctr, u64 *d_m)
+{
+    extern __shared__ u64 s_tab[];                                      // LIN: base[nkeys + 1], kmin[nkeys]
+    __shared__ u64 s_x[FWV][IVX_WAVE * FI + IVX_WAVE];                  // a wavefront's 512 words, one spare slot per lane
+    __shared__ u64 s_wmax[FWV];
+    __shared__ u32 s_wh[FWV], s_wl[FWV];
+    __shared__ u64 s_p1, s_p2;
+    __shared__ u32 s_tile;
+    const u32 tid = threadIdx.x, wv = tid / IVX_WAVE, ln = lane_id();
+    if (tid == 0) s_tile = atomicAdd(ctr, 1u);
+    const u64 *s_base = s_tab;
+    const u64 *s_kmin = s_tab + p.nkeys + 1;
+    if (LIN) {
+        for (u32 k = tid; k <= p.nkeys; k += FT) s_tab[k] = p.base[k];
+        for (u32 k = tid; k < p.nkeys; k += FT) s_tab[p.nkeys + 1 + k] = (u64)p.kmin[k];
+    }
+    __syncthreads();
+    const u32 tile = s_tile;
+    const u64 w0 = (u64)tile * FTILE + (u64)wv * (IVX_WAVE * FI);
+    // ---- the wavefront's 512 consecutive words: coalesced loads, then every lane takes its 8 consecutive ones
+#pragma unroll
+    for (int q = 0; q < FI; q++) {
+        const u64 idx = w0 + (u64)q * IVX_WAVE + ln;
+        const u32 e = (u32)q * IVX_WAVE + ln;
+        s_x[wv][e + (e >> 3)] = idx < n ? w[idx] : 0ull;
+    }
+    __syncthreads();
+    u64 r[FI];
+#pragma unroll
+    for (int i = 0; i < FI; i++) r[i] = s_x[wv][ln * (FI + 1) + i];
+    const u64 row0 = w0 + (u64)ln * FI;
+    const u32 nv = row0 >= n ? 0u : (n - row0 < (u64)FI ? (u32)(n - row0) : (u32)FI);
+    const u32 be = p.bits_e, bs = p.bits_s;
+    // ---- key, start, V of every row
+    u32 k[FI]; i64 s[FI]; u64 V[FI];
+    u32 kk = 0;
+    if (LIN && nv) {
+        const u64 lin = f_shr(r[0], be);
+        u32 a = 0, b = p.nkeys;                                         // first k with base[k + 1] > lin
+        while (a < b) { const u32 mid = (a + b) >> 1; if (s_base[mid + 1] > lin) b = mid; else a = mid + 1; }
+        kk = a;
+    }
+#pragma unroll
+    for (int i = 0; i < FI; i++) {
+        k[i] = 0; s[i] = 0; V[i] = 0;
+        if ((u32)i < nv) {
+            if (LIN) {
+                const u64 lin = f_shr(r[i], be);
+                while (kk + 1 < p.nkeys && lin >= s_base[kk + 1]) kk++;   // (bounded: a key id >= n_keys -- reported by the caller -- packs garbage)
+                s[i] = (i64)(s_kmin[kk] + (lin - s_base[kk]));
+            } else {
+                kk = (u32)f_shr(r[i], bs + be);
+                s[i] = (i64)((u64)p.min_s + f_low(f_shr(r[i], be), bs));
+            }
+            k[i] = kk;
+            V[i] = ((u64)(kk + 1) << be) | f_low(r[i], be);
+        }
+    }
+    // ---- running maximum of V: thread, wavefront, workgroup, device
+    u64 tm = 0;
+#pragma unroll
+    for (int i = 0; i < FI; i++) tm = V[i] > tm ? V[i] : tm;
+    u64 inc = tm;
+#pragma unroll
+    for (int dd = 1; dd < IVX_WAVE; dd <<= 1) { const u64 o = __shfl_up(inc, dd, IVX_WAVE); if (ln >= (u32)dd && o > inc) inc = o; }
+    if (ln == IVX_WAVE - 1) s_wmax[wv] = inc;
+    __syncthreads();
+    u64 wpre = 0, agg = 0;
+#pragma unroll
+    for (int j = 0; j < FWV; j++) { const u64 v = s_wmax[j]; if ((u32)j < wv && v > wpre) wpre = v; if (v > agg) agg = v; }
+    if (wv == 0) {
+        if (ln == 0 && tile > 0) st_status(st1 + tile, 1 | (agg << 2));
+        const u64 ex = lookback<MaxPay>(st1, tile, agg);
+        if (ln == 0) s_p1 = ex;
+    }
+    __syncthreads();
+    u64 X = s_p1 > wpre ? s_p1 : wpre;                                   // V-maximum over every row before this thread's first
+    { const u64 up = __shfl_up(inc, 1, IVX_WAVE); if (ln > 0 && up > X) X = up; }
+    // ---- run heads (merge.rs:291-296 against cur_end before the row)
+    u32 hm = 0;
+    {
+        u64 x = X;
+#pragma unroll
+        for (int i = 0; i < FI; i++) {
+            if ((u32)i < nv) {
+                const bool same = f_shr(x, be) == (u64)k[i] + 1;
+                const bool head = !same || !merges(s[i], (i64)((u64)p.min_e + f_low(x, be)), d, strict);
+                hm |= head ? 1u << i : 0u;
+                x = V[i] > x ? V[i] : x;
+            }
+        }
+    }
+    const u32 h = (u32)__builtin_popcount(hm);
+    const u32 lastp1 = hm ? (u32)(row0 + (31u - (u32)__builtin_clz(hm))) + 1u : 0u;
+    u32 hinc = h, linc = lastp1;
+#pragma unroll
+    for (int dd = 1; dd < IVX_WAVE; dd <<= 1) {
+        const u32 oh = __shfl_up(hinc, dd, IVX_WAVE), ol = __shfl_up(linc, dd, IVX_WAVE);
+        if (ln >= (u32)dd) { hinc += oh; linc = ol > linc ? ol : linc; }
+    }
+    if (ln == IVX_WAVE - 1) { s_wh[wv] = hinc; s_wl[wv] = linc; }
+    __syncthreads();
+    u32 hpre = 0, lpre = 0, hagg = 0, lagg = 0;
+#pragma unroll
+    for (int j = 0; j < FWV; j++) {
+        const u32 a = s_wh[j], b = s_wl[j];
+        if ((u32)j < wv) { hpre += a; lpre = b > lpre ? b : lpre; }
+        hagg += a; lagg = b > lagg ? b : lagg;
+    }
+    if (wv == 0) {
+        const u64 agg2 = ((u64)hagg << 31) | lagg;
+        if (ln == 0 && tile > 0) st_status(st2 + tile, 1 | (agg2 << 2));
+        const u64 ex = lookback<HeadPay>(st2, tile, agg2);
+        if (ln == 0) s_p2 = ex;
+    }
+    __syncthreads();
+    u32 rid = (u32)(s_p2 >> 31) + hpre + (hinc - h);                      // runs that start before this thread's rows
+    u32 prev = (u32)(s_p2 & 0x7FFFFFFFull);                               // (row number of the latest head before them) + 1
+    prev = lpre > prev ? lpre : prev;
+    { const u32 up = __shfl_up(linc, 1, IVX_WAVE); if (ln > 0 && up > prev) prev = up; }
+    // ---- emit: a head closes the run before it and opens its own
+    u64 x = X;
+#pragma unroll
+    for (int i = 0; i < FI; i++) {
+        if ((u32)i < nv) {
+            if ((hm >> i) & 1u) {
+                const u64 idx = row0 + i;
+                if (prev) {
+                    if (out.end) out.end[rid - 1] = (i64)((u64)p.min_e + f_low(x, be));
+                    if (out.count) out.count[rid - 1] = (i64)(idx - (prev - 1));
+                }
+                if (out.key) out.key[rid] = k[i];
+                if (out.start) out.start[rid] = s[i];
+                prev = (u32)idx + 1;
+                rid++;
+            }
+            x = V[i] > x ? V[i] : x;
+        }
+    }
+    if (nv && row0 + nv == n) {                                          // the thread that holds the last row
+        if (out.end) out.end[rid - 1] = (i64)((u64)p.min_e + f_low(x, be));
+        if (out.count) out.count[rid - 1] = (i64)(n - (prev - 1));
+        *d_m = rid;
+    }
+}
+
+}  // namespace
+
+bool ivx_merge_packed_ok(const Pack64 &p, u64 n, u32 nkeys, i64 min_dist, int strict, bool malformed, bool has_empty)
+{
+    u32 bk = 0;
+    for (u64 x = nkeys; x; x >>= 1) bk++;                                // bits of key + 1
+    if (malformed || min_dist < 0 || (strict && min_dist == 0 && has_empty)) return false;
+    if (n >= 0x7FFFFFFFull || bk + p.bits_e > 62) return false;
+    if (p.lin && ((size_t)nkeys * 2 + 1) * sizeof(u64) > 40 * 1024) return false;
+    return true;
+}
+
+ivx_status ivx_merge_runs_packed(ivx_ctx *ctx, const u64 *w, u64 n, const Pack64 &p, i64 min_dist, int strict, const ivx_runs_out &out, u64 *m)
+{
+    *m = 0;
+    if (n == 0) return IVX_OK;
+    hipStream_t stq = ctx->stream;
+    const u64 ntile = (n + FTILE - 1) / FTILE;
+    u64 *st;
+    IVX_TRY(ctx->get_scratch(WS_SCAN0, (2 * ntile + 1) * sizeof(u64), (void **)&st));
+    IVX_HIP(ctx, hipMemsetAsync(st, 0, (2 * ntile + 1) * sizeof(u64), stq));
+    u64 *d_m = ctx->d_scalars + 2;
+    const size_t tab = p.lin ? ((size_t)p.nkeys * 2 + 1) * sizeof(u64) : 0;
+    if (p.lin)
+        hipLaunchKernelGGL((k_merge_fused<true>), dim3((u32)ntile), dim3(FT), tab, stq, w, n, p, min_dist, strict, out, st + 1, st + 1 + ntile, (u32 *)st, d_m);
+    else
+        hipLaunchKernelGGL((k_merge_fused<false>), dim3((u32)ntile), dim3(FT), tab, stq, w, n, p, min_dist, strict, out, st + 1, st + 1 + ntile, (u32 *)st, d_m);
+    IVX_HIP(ctx, hipGetLastError());
+    IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 2, d_m, sizeof(u64), hipMemcpyDeviceToHost, stq));
+    IVX_HIP(ctx, hipStreamSynchronize(stq));
+    *m = ctx->h_scalars[2];
+    return IVX_OK;
+}
+
 ivx_status ivx_merge_runs(ivx_ctx *ctx, const u32 *ks, const i64 *ss, const i64 *es, u64 n,
                           i64 min_dist, int strict, const ivx_runs_out &out, u64 *m)
 {

@@ -55,6 +55,12 @@ ivx_status ivx_merge_runs(ivx_ctx *ctx, const u32 *ks, const i64 *ss, const i64 
 // the same over either form of sorted rows
 ivx_status ivx_merge_runs_rows(ivx_ctx *ctx, const SortedRows &rows, u64 n, i64 min_dist, int strict, const ivx_runs_out &out, u64 *m);
 
+// The same runs in ONE pass over the sort's packed words (sorted on their (key, start) bits; ivx_runs.hip "one-pass merge
+// sweep"), for inputs that allow it: ivx_merge_packed_ok -- malformed = some row has end < start, has_empty = some row has
+// end == start.  Uses scratch WS_SCAN0.
+bool ivx_merge_packed_ok(const Pack64 &p, u64 n, u32 nkeys, i64 min_dist, int strict, bool malformed, bool has_empty);
+ivx_status ivx_merge_runs_packed(ivx_ctx *ctx, const u64 *w, u64 n, const Pack64 &p, i64 min_dist, int strict, const ivx_runs_out &out, u64 *m);
+
 // cluster(): the same sweep, but every sorted row gets the id and the extent of its run
 // (cluster.rs:598-661).  Ids count runs in order from 0, or from key_base[key] for the first run
 // of each key when key_base is given ([nkeys], device; ClusterIdCoordinator offsets,

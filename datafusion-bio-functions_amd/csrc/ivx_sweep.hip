@@ -60,7 +60,8 @@ __global__ __launch_bounds__(ST) void k_unpack64(const u64 *__restrict__ w0, con
 // ---- packed variant: when (key, start - min start, end - min end) fit 64 bits together -- genomic
 // coordinates always do -- the sort key is ONE word and the record 16 bytes instead of 24, with fewer
 // radix digits in total
-struct Range64 { long long min_s, max_s, min_e, max_e; unsigned long long unsorted; };   // unsorted: some row sorts before its predecessor
+struct Range64 { long long min_s, max_s, min_e, max_e; unsigned long long unsorted, odd; };   // unsorted: some row sorts before its predecessor;
+                                                                                                // odd: bit 0 some end < start, bit 1 some end == start
 
 // kmin / kmax (nullable; nkeys <= LIN_KEYS): also every key's own range of starts, for the linearised sort word below --
 // privatised in LDS, and a bound is touched by an atomic only when a row moves it (a plain read comes first)
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(ST) void k_range64(const u32 *__restrict__ key, con
         __syncthreads();
     }
     i64 lo_s = INT64_MAX, hi_s = INT64_MIN, lo_e = INT64_MAX, hi_e = INT64_MIN;
-    bool bad = false, inv = false;
+    bool bad = false, inv = false, mal = false, emp = false;
     constexpr int U = 4;                                                // rows per thread in flight (their loads depend on nothing)
     for (u64 i0 = (u64)blockIdx.x * (ST * U) + threadIdx.x; i0 < n; i0 += (u64)gridDim.x * (ST * U)) {
         i64 a[U], b[U], pa[U], pb[U]; u32 k[U], pk[U];
@@ -98,6 +99,7 @@ __global__ __launch_bounds__(ST) void k_range64(const u32 *__restrict__ key, con
             lo_s = a[u] < lo_s ? a[u] : lo_s; hi_s = a[u] > hi_s ? a[u] : hi_s;
             lo_e = b[u] < lo_e ? b[u] : lo_e; hi_e = b[u] > hi_e ? b[u] : hi_e;
             bad |= k[u] >= nkeys;
+            mal |= b[u] < a[u]; emp |= b[u] == a[u];
             if (kmin && k[u] < nkeys) {
                 if (a[u] < *(volatile long long *)&smin[k[u]]) atomicMin(&smin[k[u]], (long long)a[u]);
                 if (a[u] > *(volatile long long *)&smax[k[u]]) atomicMax(&smax[k[u]], (long long)a[u]);
@@ -118,6 +120,10 @@ __global__ __launch_bounds__(ST) void k_range64(const u32 *__restrict__ key, con
     if (lane_id() == 0) { red[0][wv] = lo_s; red[1][wv] = hi_s; red[2][wv] = lo_e; red[3][wv] = hi_e; }
     if (bad) flags[0] = 1;
     if (inv) out->unsorted = 1;
+    {
+        const unsigned long long o = (__ballot(mal) ? 1ull : 0ull) | (__ballot(emp) ? 2ull : 0ull);
+        if (o && lane_id() == 0) atomicOr(&out->odd, o);
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < ST / IVX_WAVE; w++) {
@@ -281,17 +287,21 @@ u32 bits_of(u64 x) { u32 b = 0; while (x) { b++; x >>= 1; } return b; }
 // sort (key,start,end,row) ascending; rows of equal (key,start,end) keep input order = ascending row
 // sw (nullable; needs rows == nullptr): the caller reads the sorted rows through a SortedRows -- narrow columns (32-bit
 // offsets, stored in ss / es as u32 arrays) whenever the one-word form applies and both ranges fit 32 bits, else the wide ones.
+// pk (nullable; with sw): the caller is the merge sweep with pk->d / pk->strict and takes the PACKED words, sorted on their
+// (key, start) bits only, whenever ivx_merge_packed_ok says the one-pass sweep applies: pk->ok, and nothing is unpacked.
+struct PackedWant { i64 d; int strict; bool ok; const u64 *w; Pack64 p; };
 ivx_status sort64(ivx_ctx *ctx, int slot_a, int slot_b, const u32 *key, const i64 *s, const i64 *e, u64 n, u32 nkeys,
-                  u32 *ks, i64 *ss, i64 *es, u32 *rows, SortedRows *sw = nullptr)
+                  u32 *ks, i64 *ss, i64 *es, u32 *rows, SortedRows *sw = nullptr, PackedWant *pk = nullptr)
 {
     if (sw) { *sw = SortedRows{}; sw->ks = ks; sw->ss = ss; sw->es = es; }
+    if (pk) pk->ok = false;
     if (n == 0) return IVX_OK;
     bool narrow = sw != nullptr && rows == nullptr && !getenv("IVX_NO_NARROW_SWEEP");
     hipStream_t st = ctx->stream;
     u32 *flags = (u32 *)(ctx->d_scalars + 8);
     Range64 *d_rng = (Range64 *)(ctx->d_scalars + 24);
     Range64 *h_init = (Range64 *)(ctx->h_scalars + 48);                   // pinned, so the async copy may read it later
-    *h_init = Range64{INT64_MAX, INT64_MIN, INT64_MAX, INT64_MIN, 0ull};
+    *h_init = Range64{INT64_MAX, INT64_MIN, INT64_MAX, INT64_MIN, 0ull, 0ull};
     IVX_HIP(ctx, hipMemcpyAsync(d_rng, h_init, sizeof(Range64), hipMemcpyHostToDevice, st));
     // every key's own range of starts as well, when the key table fits LDS (the linearised sort word, Pack64)
     long long *kmin = nullptr, *kmax = nullptr; u64 *base = nullptr;
@@ -308,7 +318,7 @@ ivx_status sort64(ivx_ctx *ctx, int slot_a, int slot_b, const u32 *key, const i6
     hipLaunchKernelGGL(k_range64, dim3(ivx_stream_grid(n, ST * 16, 4096)), dim3(ST), try_lin ? (size_t)nkeys * 16 : 0, st, key, s, e, n, nkeys, d_rng, flags,
                        kmin, kmax);
     if (try_lin) hipLaunchKernelGGL(k_lin_layout64, dim3(1), dim3(1024), 0, st, (const long long *)kmin, (const long long *)kmax, nkeys, base, d_lin);
-    IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 24, d_rng, 8 * sizeof(u64), hipMemcpyDeviceToHost, st));   // Range64 (5 words) .. d_lin (2 words)
+    IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 24, d_rng, 8 * sizeof(u64), hipMemcpyDeviceToHost, st));   // Range64 (6 words), d_lin (2 words)
     IVX_HIP(ctx, hipStreamSynchronize(st));
     const Range64 r = *(const Range64 *)(ctx->h_scalars + 24);
     if (!r.unsorted && !getenv("IVX_FORCE_SORT")) {
@@ -346,6 +356,15 @@ ivx_status sort64(ivx_ctx *ctx, int slot_a, int slot_b, const u32 *key, const i6
         IVX_TRY(ctx->get_scratch(slot_b + 1, n * sizeof(u32), (void **)&pay[1]));
     }
     int in_b = 0;
+    if (nw == 1 && pk && !rows && !getenv("IVX_NO_FUSED_SWEEP") && ivx_merge_packed_ok(p, n, nkeys, pk->d, pk->strict, (r.odd & 1) != 0, (r.odd & 2) != 0)) {
+        hipLaunchKernelGGL(k_pack1, dim3(grid1(n)), dim3(ST), 0, st, key, s, e, n, p, a[0], (u32 *)nullptr);
+        const int lo = (int)p.bits_e;
+        const ivx_sort_field f[1] = {{0, lo, lo + (int)((total - p.bits_e + 7) / 8 * 8)}};
+        IVX_TRY(ivx_radix_sort(ctx, 1, a, b, n, f, 1, &in_b, true, nullptr));
+        pk->ok = true; pk->w = in_b ? b[0] : a[0]; pk->p = p;
+        IVX_HIP(ctx, hipGetLastError());
+        return IVX_OK;
+    }
     if (nw == 1) {
         hipLaunchKernelGGL(k_pack1, dim3(grid1(n)), dim3(ST), 0, st, key, s, e, n, p, a[0], pay[0]);
         // Few rows share a (key,start) when the rows are sparse in the coordinate space: then sort on those bits
@@ -855,9 +874,11 @@ ivx_status ivx_merge_device(ivx_ctx *ctx, const u32 *key, const i64 *s, const i6
     IVX_TRY(ctx->get_scratch(WS_T1, n * sizeof(i64), (void **)&ss));
     IVX_TRY(ctx->get_scratch(WS_T2, n * sizeof(i64), (void **)&es));
     SortedRows rows;
-    IVX_TRY(sort64(ctx, WS_SA0, WS_SB0, key, s, e, n, nkeys, ks, ss, es, nullptr, &rows));
+    PackedWant pk{min_dist, strict, false, nullptr, Pack64{}};
+    IVX_TRY(sort64(ctx, WS_SA0, WS_SB0, key, s, e, n, nkeys, ks, ss, es, nullptr, &rows, &pk));
     ivx_runs_out ro{ok, os, oe, on};
-    IVX_TRY(ivx_merge_runs_rows(ctx, rows, n, min_dist, strict, ro, m));
+    if (pk.ok) IVX_TRY(ivx_merge_runs_packed(ctx, pk.w, n, pk.p, min_dist, strict, ro, m));
+    else IVX_TRY(ivx_merge_runs_rows(ctx, rows, n, min_dist, strict, ro, m));
     return keyflag(ctx, "merge: key id >= n_keys");
 }
 
@@ -1005,9 +1026,11 @@ ivx_status ivx_complement_device(ivx_ctx *ctx, const u32 *key, const i64 *s, con
         IVX_TRY(ctx->get_scratch(WS_T1, n * sizeof(i64), (void **)&ss));
         IVX_TRY(ctx->get_scratch(WS_T2, n * sizeof(i64), (void **)&es));
         SortedRows rows;
-        IVX_TRY(sort64(ctx, WS_SA0, WS_SB0, key, s, e, n, nkeys, ks, ss, es, nullptr, &rows));
+        PackedWant pk{0, strict, false, nullptr, Pack64{}};
+        IVX_TRY(sort64(ctx, WS_SA0, WS_SB0, key, s, e, n, nkeys, ks, ss, es, nullptr, &rows, &pk));
         const ivx_runs_out ro{mk, ms, me, nullptr};
-        IVX_TRY(ivx_merge_runs_rows(ctx, rows, n, 0, strict, ro, &m));
+        if (pk.ok) IVX_TRY(ivx_merge_runs_packed(ctx, pk.w, n, pk.p, 0, strict, ro, &m));
+        else IVX_TRY(ivx_merge_runs_rows(ctx, rows, n, 0, strict, ro, &m));
     }
     u32 *G, *cg;
     IVX_TRY(ctx->get_scratch(WS_T5, (m + 1) * sizeof(u32), (void **)&G));       // the sweep's scratch is free again

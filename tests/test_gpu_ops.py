@@ -484,6 +484,40 @@ def test_sweeps_sort_on_key_start_then_fix_runs(ctx, dups):
             assert len(g) == len(w) and (g == w).all()
 
 
+@pytest.mark.parametrize("shape", ["sparse", "dense", "one_key", "many_keys", "empties"])
+def test_merge_one_pass_sweep(ctx, shape):
+    """Well-formed rows go through the one-pass sweep over the sort's packed words (ivx_runs.hip k_merge_fused: several
+    hundred tiles, look-back windows beyond 64 tiles, runs and keys that straddle tiles); IVX_NO_FUSED_SWEEP=1 is the
+    three-pass sweep over unpacked rows.  Both must give the oracle's runs; strict + min_dist 0 with empty rows (whose
+    order inside a start matters) must fall back by itself."""
+    rng = np.random.default_rng(4242)
+    n = 1_500_000
+    nk = {"sparse": 24, "dense": 24, "one_key": 1, "many_keys": 700, "empties": 5}[shape]
+    span = {"sparse": 200_000_000, "dense": 300_000, "one_key": 50_000_000, "many_keys": 40_000, "empties": 3_000_000}[shape]
+    k = rng.integers(0, nk, n).astype(np.uint32)
+    if shape == "many_keys":
+        k[k % 7 == 3] = 5                                              # keys without rows, one heavy key
+    s = rng.integers(0, span, n).astype(np.int64) + rng.integers(-10**6, 10**6, nk)[k]
+    e = s + rng.integers(1, 60, n)
+    if shape == "empties":
+        e[::3] = s[::3]
+    s[::17] = s[1::17][: len(s[::17])]; k[::17] = k[1::17][: len(k[::17])]; e[::17] = np.maximum(e[::17], s[::17] + (shape != "empties"))
+    for md, strict in ((0, False), (0, True), (9, True), (25, False)):
+        want = orc.merge(k, s, e, min_dist=md, strict=strict)
+        for env in ({}, {"IVX_NO_FUSED_SWEEP": "1"}, {"IVX_NO_LIN": "1"}):
+            os.environ.update(env)
+            try:
+                got = ctx.merge(k, s, e, n_keys=nk, min_dist=md, strict=strict)
+            finally:
+                for v in env:
+                    os.environ.pop(v, None)
+            for g, w in zip(got, want):
+                assert len(g) == len(w) and (g == w).all(), (shape, md, strict, env)
+    vk, vs, ve = k[:3000].copy(), s[:3000] - 50, e[:3000] + 500
+    for g, w in zip(ctx.complement(k, s, e, vk, vs, ve, n_keys=nk), orc.complement(k, s, e, vk, vs, ve)):
+        assert len(g) == len(w) and (np.asarray(g).astype(np.int64) == w.astype(np.int64)).all(), shape
+
+
 def test_merge_i64_extremes(ctx):
     big = np.iinfo(np.int64).max
     k = np.zeros(6, np.uint32)
