@@ -1,4 +1,5 @@
 // ivx_runs.hip -- interval-merge sweep as two device-wide scans (see ivx_runs.hpp).
+#include <cstdlib>
 #include "ivx_runs.hpp"
 #include "ivx_scan.hpp"
 
@@ -245,100 +246,140 @@ static ivx_status sweep(ivx_ctx *ctx, const SortedRows &rows, u64 n,
 
 namespace {
 
-// ---------------------------------------------------------------------------------------------- one-pass merge sweep
-// The whole sweep in ONE kernel over the sort's packed 8-byte words (Pack64), for the inputs every caller meets: rows with
-// start <= end, min_dist >= 0 (and, strict with min_dist = 0, no empty row).  For those
+// --------------------------------------------------------------------------------- the merge sweep over packed words
+// The sweep over the sort's packed 8-byte words (Pack64) -- no unpack pass, no per-row state in memory -- for the inputs
+// every caller meets: rows with start <= end, min_dist >= 0 (and, strict with min_dist = 0, no empty row).  For those
 //   * cur_end before a row is simply the largest end among the earlier rows of its key -- a run head starts beyond every
 //     earlier end, so the maximum over the key is the maximum over the current run;
 //   * the order of rows with the same (key, start) does not matter: the first of them decides head-or-not by the same test,
 //     the others merge into it, cur_end after the group is the maximum either way -- so the words need only be sorted on
 //     their (key, start) bits, not repaired by end.
 // With V = (key + 1) << bits_e | (end - min_e) the segmented running maximum is a plain one (a later key's V beats every
-// earlier one), and both device-wide scans -- the maximum, then the run heads counted against it -- are chained through
-// per-tile status words (decoupled look-back: flag in the low two bits, 1 = the tile's own aggregate, 2 = inclusive prefix)
-// by tiles that take their number from a counter, so every predecessor of a tile is resident or done.  Unpack + three
-// passes over 12-byte rows become one kernel that reads the 8-byte word once and writes the runs.
-// A run is emitted by the head that FOLLOWS it (which holds cur_end before itself = the run's end, and the previous head's
-// row number), the last one by row n - 1.
+// earlier one).  Three kernels over tiles of 4096 words with two scans of one word per tile between them:
+//   k_pk_max    the tile's largest V (only rows of the tile's last key can hold it: striped loads, no per-row key lookup)
+//   k_pk_runs<false>  V-maximum before the tile -> run heads -> (heads, latest head) of the tile
+//   k_pk_runs<true>   the same again, and every head closes the run before it (it holds cur_end before itself = that run's
+//               end, and the previous head's row number) and opens its own; row n - 1 closes the last run.
+// A thread takes 8 CONSECUTIVE words (coalesced loads, turned through LDS per wavefront): the key of a word's linearised
+// (key, start) is then a lookup for the first word and a compare for the others.
+// (A single kernel with both scans chained through per-tile status words -- decoupled look-back -- was built first: 1.66 ms
+// for 200 M rows against [see DESIGN.md] for these three; its tiles wait on each other twice and it has to spin.)
 constexpr int FT = 512, FI = 8, FTILE = FT * FI, FWV = FT / IVX_WAVE;
 
-__device__ __forceinline__ u64 ld_status(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_status(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-struct MaxPay {
-    __device__ static u64 ident() { return 0; }
-    __device__ static u64 comb(u64 a, u64 b) { return a > b ? a : b; }
+struct MaxPayOp {                                  // u64 maximum
+    using T = u64;
+    __host__ __device__ static T identity() { return 0; }
+    __device__ static T combine(const T &a, const T &b) { return a > b ? a : b; }
+    __device__ static T shfl_up(const T &v, int d) { return __shfl_up(v, d, IVX_WAVE); }
 };
-struct HeadPay {                                   // heads so far << 31 | (row number of the latest head) + 1
-    __device__ static u64 ident() { return 0; }
-    __device__ static u64 comb(u64 a, u64 b)
+struct HeadPayOp {                                 // heads so far << 31 | (row number of the latest head) + 1
+    using T = u64;
+    __host__ __device__ static T identity() { return 0; }
+    __device__ static T combine(const T &a, const T &b)
     {
         const u64 la = a & 0x7FFFFFFFull, lb = b & 0x7FFFFFFFull;
         return (((a >> 31) + (b >> 31)) << 31) | (la > lb ? la : lb);
     }
+    __device__ static T shfl_up(const T &v, int d) { return __shfl_up(v, d, IVX_WAVE); }
 };
-
-// one whole wavefront: the exclusive prefix of tile `tile` (payloads of 62 bits), leaving the tile's inclusive one behind
-template <class P>
-__device__ __forceinline__ u64 lookback(u64 *st, u32 tile, u64 agg)
-{
-    const u32 ln = lane_id();
-    u64 excl = P::ident();
-    if (tile > 0) {
-        long long hi = (long long)tile - 1;
-        for (;;) {
-            const long long t = hi - (long long)ln;
-            u64 v = 2;                                                  // before tile 0: an inclusive identity
-            if (t >= 0) v = ld_status(st + t);
-            while (__ballot((v & 3) == 0)) {
-                __builtin_amdgcn_s_sleep(1);
-                if (t >= 0 && (v & 3) == 0) v = ld_status(st + t);
-            }
-            const u64 incl = __ballot((v & 3) == 2);
-            const u32 first = incl ? (u32)__builtin_ctzll(incl) : 64u;
-            u64 pay = ln <= first ? (v >> 2) : P::ident();
-#pragma unroll
-            for (int dd = IVX_WAVE / 2; dd > 0; dd >>= 1) pay = P::comb(pay, __shfl_xor(pay, dd, IVX_WAVE));
-            excl = P::comb(excl, pay);
-            if (incl) break;
-            hi -= IVX_WAVE;
-        }
-    }
-    if (ln == 0) st_status(st + tile, 2 | (P::comb(excl, agg) << 2));
-    return excl;
-}
 
 __device__ __forceinline__ u64 f_shr(u64 x, u32 sh) { return sh >= 64 ? 0 : x >> sh; }
 __device__ __forceinline__ u64 f_low(u64 x, u32 bits) { return bits >= 64 ? x : x & ((1ull << bits) - 1); }
+// first k with base[k + 1] > lin (keys without rows are skipped)
+__device__ __forceinline__ u32 f_key(const u64 *base, u32 nkeys, u64 lin)
+{
+    u32 a = 0, b = nkeys;
+    while (a < b) { const u32 mid = (a + b) >> 1; if (base[mid + 1] > lin) b = mid; else a = mid + 1; }
+    return a < nkeys ? a : (nkeys ? nkeys - 1 : 0);                    // (a key id >= n_keys -- reported by the caller -- packs garbage)
+}
 
 template <bool LIN>
-__global__ __launch_bounds__(FT, 4) void k_merge_fused(const u64 *__restrict__ w, u64 n, Pack64 p, i64 d, int strict, ivx_runs_out out,
-                                                   u64 *st1, u64 *st2, u32 *ctr, u64 *d_m)
+__global__ __launch_bounds__(FT) void k_pk_max(const u64 *__restrict__ w, u64 n, Pack64 p, u64 *__restrict__ agg)
+{
+    extern __shared__ u64 s_tab[];                                      // LIN: base[nkeys + 1]
+    __shared__ u64 red[FWV];
+    if (LIN) for (u32 k = threadIdx.x; k <= p.nkeys; k += FT) s_tab[k] = p.base[k];
+    const u64 t0 = (u64)blockIdx.x * FTILE;
+    const u32 tn = (u32)(n - t0 < (u64)FTILE ? n - t0 : (u64)FTILE);
+    const u32 be = p.bits_e, bs = p.bits_s;
+    u64 x[FI];
+#pragma unroll
+    for (int q = 0; q < FI; q++) { const u32 j = (u32)q * FT + threadIdx.x; x[q] = j < tn ? w[t0 + j] : 0ull; }
+    const u64 wl = w[t0 + tn - 1];                                      // the tile's last row: the tile's last key
+    __syncthreads();
+    u32 kl; u64 lo;                                                     // rows of that key: word >= lo
+    if (LIN) { kl = f_key(s_tab, p.nkeys, f_shr(wl, be)); lo = s_tab[kl] << be; }
+    else { kl = (u32)f_shr(wl, bs + be); lo = bs + be >= 64 ? 0 : (u64)kl << (bs + be); }
+    u64 m = 0;
+#pragma unroll
+    for (int q = 0; q < FI; q++) { const u64 eo = f_low(x[q], be); if ((u32)q * FT + threadIdx.x < tn && x[q] >= lo && eo > m) m = eo; }
+#pragma unroll
+    for (int dd = IVX_WAVE / 2; dd > 0; dd >>= 1) { const u64 o = __shfl_xor(m, dd, IVX_WAVE); m = o > m ? o : m; }
+    if (lane_id() == 0) red[threadIdx.x / IVX_WAVE] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int j = 1; j < FWV; j++) m = red[j] > m ? red[j] : m;
+        agg[blockIdx.x] = ((u64)(kl + 1) << be) | m;
+    }
+}
+
+// 32-bit wavefront scans on the DPP path (row shifts, then the row broadcasts of gfx9): no LDS round trip per step as with
+// ds_bpermute.  Lanes without a source take `old` = 0, the identity of both operators used here.
+template <int CTRL, int ROWS>
+__device__ __forceinline__ u32 dpp0(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWS, 0xf, false); }
+__device__ __forceinline__ u32 wave_incl_max32(u32 v)
+{
+    u32 o;
+    o = dpp0<0x111, 0xf>(v); v = o > v ? o : v;                          // row_shr:1, 2, 4, 8
+    o = dpp0<0x112, 0xf>(v); v = o > v ? o : v;
+    o = dpp0<0x114, 0xf>(v); v = o > v ? o : v;
+    o = dpp0<0x118, 0xf>(v); v = o > v ? o : v;
+    o = dpp0<0x142, 0xa>(v); v = o > v ? o : v;                          // row_bcast:15 into rows 1 and 3
+    o = dpp0<0x143, 0xc>(v); v = o > v ? o : v;                          // row_bcast:31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ u32 wave_incl_sum32(u32 v)
+{
+    v += dpp0<0x111, 0xf>(v); v += dpp0<0x112, 0xf>(v); v += dpp0<0x114, 0xf>(v); v += dpp0<0x118, 0xf>(v);
+    v += dpp0<0x142, 0xa>(v); v += dpp0<0x143, 0xc>(v);
+    return v;
+}
+__device__ __forceinline__ u32 wave_prev32(u32 v) { return dpp0<0x138, 0xf>(v); }      // wave_shr:1 (lane 0: 0)
+
+// NARROW (decided on the host: bits_e <= 32, the word's upper part -- `lin` -- fits 32 bits, every coordinate and min_dist within
+// +-2^61 so that differences cannot overflow): a wavefront whose 512 rows share ONE key -- all but a few dozen of a launch --
+// works on 32-bit (lin, end offset) pairs with the key's tables in scalar registers; the run-head test is the sign of
+//   (start - cur_end) - min_dist [- 1]  =  (lin - base) - x + K ,   K = kmin - min_e - min_dist - (strict ? 0 : 1).
+// The generic sections (any wavefront of a launch that is not NARROW, wavefronts that straddle a key or the end of the input)
+// carry a key per row and rebuild 64-bit V and the i64 start from the word where they need them.
+template <bool LIN, bool EMIT, bool NARROW>
+__global__ __launch_bounds__(FT, 8) void k_pk_runs(const u64 *__restrict__ w, u64 n, Pack64 p, i64 d, int strict, const u64 *__restrict__ pre1,
+                                                  u64 *__restrict__ agg2, const u64 *__restrict__ pre2, ivx_runs_out out, u64 *d_m)
 {
     extern __shared__ u64 s_tab[];                                      // LIN: base[nkeys + 1], kmin[nkeys]
     __shared__ u64 s_x[FWV][IVX_WAVE * FI + IVX_WAVE];                  // a wavefront's 512 words, one spare slot per lane
     __shared__ u64 s_wmax[FWV];
     __shared__ u32 s_wh[FWV], s_wl[FWV];
-    __shared__ u64 s_p1, s_p2;
-    __shared__ u32 s_tile;
     const u32 tid = threadIdx.x, wv = tid / IVX_WAVE, ln = lane_id();
-    if (tid == 0) s_tile = atomicAdd(ctr, 1u);
     const u64 *s_base = s_tab;
     const u64 *s_kmin = s_tab + p.nkeys + 1;
     if (LIN) {
         for (u32 k = tid; k <= p.nkeys; k += FT) s_tab[k] = p.base[k];
         for (u32 k = tid; k < p.nkeys; k += FT) s_tab[p.nkeys + 1 + k] = (u64)p.kmin[k];
     }
-    __syncthreads();
-    const u32 tile = s_tile;
+    const u32 tile = blockIdx.x;
     const u64 w0 = (u64)tile * FTILE + (u64)wv * (IVX_WAVE * FI);
+    const bool wfull = w0 + (u64)IVX_WAVE * FI <= n;                     // (wave-uniform)
     // ---- the wavefront's 512 consecutive words: coalesced loads, then every lane takes its 8 consecutive ones
+    if (wfull) {
 #pragma unroll
-    for (int q = 0; q < FI; q++) {
-        const u64 idx = w0 + (u64)q * IVX_WAVE + ln;
-        const u32 e = (u32)q * IVX_WAVE + ln;
-        s_x[wv][e + (e >> 3)] = idx < n ? w[idx] : 0ull;
+        for (int q = 0; q < FI; q++) { const u32 e = (u32)q * IVX_WAVE + ln; s_x[wv][e + (e >> 3)] = w[w0 + e]; }
+    } else {
+#pragma unroll
+        for (int q = 0; q < FI; q++) { const u32 e = (u32)q * IVX_WAVE + ln; s_x[wv][e + (e >> 3)] = w0 + e < n ? w[w0 + e] : 0ull; }
     }
+    const u64 P = pre1[tile], P2 = EMIT ? pre2[tile] : 0ull;
     __syncthreads();
     u64 r[FI];
 #pragma unroll
@@ -346,73 +387,110 @@ __global__ __launch_bounds__(FT, 4) void k_merge_fused(const u64 *__restrict__ w
     const u64 row0 = w0 + (u64)ln * FI;
     const u32 nv = row0 >= n ? 0u : (n - row0 < (u64)FI ? (u32)(n - row0) : (u32)FI);
     const u32 be = p.bits_e, bs = p.bits_s;
-    // ---- key, start, V of every row
-    u32 k[FI]; i64 s[FI]; u64 V[FI];
-    u32 kk = 0;
-    if (LIN && nv) {
-        const u64 lin = f_shr(r[0], be);
-        u32 a = 0, b = p.nkeys;                                         // first k with base[k + 1] > lin
-        while (a < b) { const u32 mid = (a + b) >> 1; if (s_base[mid + 1] > lin) b = mid; else a = mid + 1; }
-        kk = a;
-    }
-#pragma unroll
-    for (int i = 0; i < FI; i++) {
-        k[i] = 0; s[i] = 0; V[i] = 0;
-        if ((u32)i < nv) {
-            if (LIN) {
-                const u64 lin = f_shr(r[i], be);
-                while (kk + 1 < p.nkeys && lin >= s_base[kk + 1]) kk++;   // (bounded: a key id >= n_keys -- reported by the caller -- packs garbage)
-                s[i] = (i64)(s_kmin[kk] + (lin - s_base[kk]));
-            } else {
-                kk = (u32)f_shr(r[i], bs + be);
-                s[i] = (i64)((u64)p.min_s + f_low(f_shr(r[i], be), bs));
-            }
-            k[i] = kk;
-            V[i] = ((u64)(kk + 1) << be) | f_low(r[i], be);
+    const u32 emask = be >= 32 ? 0xFFFFFFFFu : (1u << be) - 1u;
+
+    // ---- does the whole wavefront sit in one key?  (wave-uniform; kA and its tables end up in scalar registers)
+    bool fast = false;
+    u32 kA = 0, baseA = 0;
+    i64 koffA = 0;
+    if (NARROW && wfull) {
+        const u32 lin_a = (u32)f_shr(s_x[wv][0], be), lin_b = (u32)f_shr(s_x[wv][(IVX_WAVE - 1) * (FI + 1) + FI - 1], be);
+        if (LIN) {
+            // (the rows before this tile end in key (P >> be) - 1: the search starts there and usually stops at once)
+            kA = P ? (u32)(P >> be) - 1u : 0u;
+            while (kA + 1 < p.nkeys && (u64)lin_a >= s_base[kA + 1]) kA++;
+            fast = kA + 1 >= p.nkeys || (u64)lin_b < s_base[kA + 1];
+            baseA = (u32)s_base[kA]; koffA = (i64)s_kmin[kA];
+        } else {
+            kA = bs >= 32 ? 0u : lin_a >> bs;                            // (one key: no key bits at all)
+            fast = (bs >= 32 ? 0u : lin_b >> bs) == kA;
+            baseA = bs >= 32 ? 0u : kA << bs; koffA = p.min_s;
         }
+        kA = __builtin_amdgcn_readfirstlane(kA); baseA = __builtin_amdgcn_readfirstlane(baseA);
+        fast = __builtin_amdgcn_readfirstlane((u32)fast) != 0;
     }
-    // ---- running maximum of V: thread, wavefront, workgroup, device
-    u64 tm = 0;
+
+    // generic rows: the key per row; V and the start come from the word
+    u32 k[FI];
+    auto Vof = [&](int i) -> u64 { return ((u64)(k[i] + 1) << be) | f_low(r[i], be); };
+    auto sof = [&](int i) -> i64 {
+        if (LIN) return (i64)(s_kmin[k[i]] + (f_shr(r[i], be) - s_base[k[i]]));
+        return (i64)((u64)p.min_s + f_low(f_shr(r[i], be), bs));
+    };
+
+    // ---- section 1: the wavefront's largest V, each lane's inclusive maximum
+    u32 inc32 = 0;                                                      // fast
+    u64 inc = 0;                                                        // generic
+    u64 wagg;
+    if (fast) {
+        u32 tm = 0;
 #pragma unroll
-    for (int i = 0; i < FI; i++) tm = V[i] > tm ? V[i] : tm;
-    u64 inc = tm;
+        for (int i = 0; i < FI; i++) { k[i] = 0; const u32 eo = (u32)r[i] & emask; tm = eo > tm ? eo : tm; }
+        inc32 = wave_incl_max32(tm);
+        wagg = ((u64)(kA + 1) << be) | (u32)__builtin_amdgcn_readlane((int)inc32, IVX_WAVE - 1);
+    } else {
+        u32 kk = 0;
+        if (LIN && nv) kk = f_key(s_base, p.nkeys, f_shr(r[0], be));
+        u64 tm = 0;
 #pragma unroll
-    for (int dd = 1; dd < IVX_WAVE; dd <<= 1) { const u64 o = __shfl_up(inc, dd, IVX_WAVE); if (ln >= (u32)dd && o > inc) inc = o; }
-    if (ln == IVX_WAVE - 1) s_wmax[wv] = inc;
-    __syncthreads();
-    u64 wpre = 0, agg = 0;
+        for (int i = 0; i < FI; i++) {
+            k[i] = 0;
+            if ((u32)i < nv) {
+                if (LIN) { const u64 lin = f_shr(r[i], be); while (kk + 1 < p.nkeys && lin >= s_base[kk + 1]) kk++; }
+                else kk = (u32)f_shr(r[i], bs + be);
+                k[i] = kk;
+                const u64 v = Vof(i);
+                tm = v > tm ? v : tm;
+            }
+        }
+        inc = tm;
 #pragma unroll
-    for (int j = 0; j < FWV; j++) { const u64 v = s_wmax[j]; if ((u32)j < wv && v > wpre) wpre = v; if (v > agg) agg = v; }
-    if (wv == 0) {
-        if (ln == 0 && tile > 0) st_status(st1 + tile, 1 | (agg << 2));
-        const u64 ex = lookback<MaxPay>(st1, tile, agg);
-        if (ln == 0) s_p1 = ex;
+        for (int dd = 1; dd < IVX_WAVE; dd <<= 1) { const u64 o = __shfl_up(inc, dd, IVX_WAVE); if (ln >= (u32)dd && o > inc) inc = o; }
+        wagg = __shfl(inc, IVX_WAVE - 1, IVX_WAVE);
     }
+    if (ln == 0) s_wmax[wv] = wagg;
     __syncthreads();
-    u64 X = s_p1 > wpre ? s_p1 : wpre;                                   // V-maximum over every row before this thread's first
-    { const u64 up = __shfl_up(inc, 1, IVX_WAVE); if (ln > 0 && up > X) X = up; }
-    // ---- run heads (merge.rs:291-296 against cur_end before the row)
+    u64 Xw = P;                                                          // V-maximum over every row before this wavefront's
+#pragma unroll
+    for (int j = 0; j < FWV; j++) { const u64 v = s_wmax[j]; if ((u32)j < wv && v > Xw) Xw = v; }
+
+    // ---- section 2: run heads (merge.rs:291-296 against cur_end before the row)
     u32 hm = 0;
-    {
+    u32 x32 = 0; bool hv = false;                                        // fast: cur_end offset before the thread's first row, is there one
+    u64 X = Xw;                                                          // generic
+    if (fast) {
+        const bool hvw = (u32)(Xw >> be) == kA + 1;
+        // (lane 0 of a wavefront that opens a key keeps the PREVIOUS key's cur_end in x32: its first row closes that run)
+        x32 = (u32)Xw & emask;
+        { const u32 up = wave_prev32(inc32); if (ln > 0) { x32 = hvw ? x32 : 0u; x32 = up > x32 ? up : x32; } }
+        hv = hvw || ln > 0;
+        const i64 K = koffA - p.min_e - d - (strict ? 0 : 1);
+        u32 x = x32;
+#pragma unroll
+        for (int i = 0; i < FI; i++) {
+            const u32 lin = (u32)(r[i] >> be), eo = (u32)r[i] & emask;
+            const i64 t = (i64)(u64)(lin - baseA) - (i64)(u64)x + K;
+            const bool head = (i == 0 && !hv) || t >= 0;
+            hm |= head ? 1u << i : 0u;
+            x = ((i == 0 && !hv) || eo > x) ? eo : x;
+        }
+    } else {
+        { const u64 up = __shfl_up(inc, 1, IVX_WAVE); if (ln > 0 && up > X) X = up; }
         u64 x = X;
 #pragma unroll
         for (int i = 0; i < FI; i++) {
             if ((u32)i < nv) {
                 const bool same = f_shr(x, be) == (u64)k[i] + 1;
-                const bool head = !same || !merges(s[i], (i64)((u64)p.min_e + f_low(x, be)), d, strict);
+                const bool head = !same || !merges(sof(i), (i64)((u64)p.min_e + f_low(x, be)), d, strict);
                 hm |= head ? 1u << i : 0u;
-                x = V[i] > x ? V[i] : x;
+                const u64 v = Vof(i);
+                x = v > x ? v : x;
             }
         }
     }
     const u32 h = (u32)__builtin_popcount(hm);
     const u32 lastp1 = hm ? (u32)(row0 + (31u - (u32)__builtin_clz(hm))) + 1u : 0u;
-    u32 hinc = h, linc = lastp1;
-#pragma unroll
-    for (int dd = 1; dd < IVX_WAVE; dd <<= 1) {
-        const u32 oh = __shfl_up(hinc, dd, IVX_WAVE), ol = __shfl_up(linc, dd, IVX_WAVE);
-        if (ln >= (u32)dd) { hinc += oh; linc = ol > linc ? ol : linc; }
-    }
+    const u32 hinc = wave_incl_sum32(h), linc = wave_incl_max32(lastp1);
     if (ln == IVX_WAVE - 1) { s_wh[wv] = hinc; s_wl[wv] = linc; }
     __syncthreads();
     u32 hpre = 0, lpre = 0, hagg = 0, lagg = 0;
@@ -422,41 +500,101 @@ __global__ __launch_bounds__(FT, 4) void k_merge_fused(const u64 *__restrict__ w
         if ((u32)j < wv) { hpre += a; lpre = b > lpre ? b : lpre; }
         hagg += a; lagg = b > lagg ? b : lagg;
     }
-    if (wv == 0) {
-        const u64 agg2 = ((u64)hagg << 31) | lagg;
-        if (ln == 0 && tile > 0) st_status(st2 + tile, 1 | (agg2 << 2));
-        const u64 ex = lookback<HeadPay>(st2, tile, agg2);
-        if (ln == 0) s_p2 = ex;
+    if (!EMIT) {
+        if (tid == 0) agg2[tile] = ((u64)hagg << 31) | lagg;
+        return;
     }
-    __syncthreads();
-    u32 rid = (u32)(s_p2 >> 31) + hpre + (hinc - h);                      // runs that start before this thread's rows
-    u32 prev = (u32)(s_p2 & 0x7FFFFFFFull);                               // (row number of the latest head before them) + 1
+    u32 rid = (u32)(P2 >> 31) + hpre + (hinc - h);                        // runs that start before this thread's rows
+    u32 prev = (u32)(P2 & 0x7FFFFFFFull);                                 // (row number of the latest head before them) + 1
     prev = lpre > prev ? lpre : prev;
-    { const u32 up = __shfl_up(linc, 1, IVX_WAVE); if (ln > 0 && up > prev) prev = up; }
-    // ---- emit: a head closes the run before it and opens its own
-    u64 x = X;
+    { const u32 up = wave_prev32(linc); prev = up > prev ? up : prev; }
+    // ---- section 3, emit: a head closes the run before it and opens its own
+    if (fast) {
+        u32 x = x32;
+        if (__ballot(hm != 0)) {
 #pragma unroll
-    for (int i = 0; i < FI; i++) {
-        if ((u32)i < nv) {
-            if ((hm >> i) & 1u) {
-                const u64 idx = row0 + i;
-                if (prev) {
-                    if (out.end) out.end[rid - 1] = (i64)((u64)p.min_e + f_low(x, be));
-                    if (out.count) out.count[rid - 1] = (i64)(idx - (prev - 1));
+            for (int i = 0; i < FI; i++) {
+                const u32 lin = (u32)(r[i] >> be), eo = (u32)r[i] & emask;
+                if ((hm >> i) & 1u) {
+                    const u64 idx = row0 + i;
+                    if (prev) {
+                        if (out.end) out.end[rid - 1] = (i64)((u64)p.min_e + x);
+                        if (out.count) out.count[rid - 1] = (i64)(idx - (prev - 1));
+                    }
+                    if (out.key) out.key[rid] = kA;
+                    if (out.start) out.start[rid] = (i64)((u64)koffA + (lin - baseA));
+                    prev = (u32)idx + 1;
+                    rid++;
                 }
-                if (out.key) out.key[rid] = k[i];
-                if (out.start) out.start[rid] = s[i];
-                prev = (u32)idx + 1;
-                rid++;
+                x = ((i == 0 && !hv) || eo > x) ? eo : x;
             }
-            x = V[i] > x ? V[i] : x;
+        } else if (row0 + FI == n) {
+#pragma unroll
+            for (int i = 0; i < FI; i++) { const u32 eo = (u32)r[i] & emask; x = eo > x ? eo : x; }      // (no head here: hv holds)
+        }
+        if (row0 + FI == n) {                                            // the thread that holds the last row
+            if (out.end) out.end[rid - 1] = (i64)((u64)p.min_e + x);
+            if (out.count) out.count[rid - 1] = (i64)(n - (prev - 1));
+            *d_m = rid;
+        }
+    } else {
+        u64 x = X;
+#pragma unroll
+        for (int i = 0; i < FI; i++) {
+            if ((u32)i < nv) {
+                if ((hm >> i) & 1u) {
+                    const u64 idx = row0 + i;
+                    if (prev) {
+                        if (out.end) out.end[rid - 1] = (i64)((u64)p.min_e + f_low(x, be));
+                        if (out.count) out.count[rid - 1] = (i64)(idx - (prev - 1));
+                    }
+                    if (out.key) out.key[rid] = k[i];
+                    if (out.start) out.start[rid] = sof(i);
+                    prev = (u32)idx + 1;
+                    rid++;
+                }
+                const u64 v = Vof(i);
+                x = v > x ? v : x;
+            }
+        }
+        if (nv && row0 + nv == n) {                                      // the thread that holds the last row
+            if (out.end) out.end[rid - 1] = (i64)((u64)p.min_e + f_low(x, be));
+            if (out.count) out.count[rid - 1] = (i64)(n - (prev - 1));
+            *d_m = rid;
         }
     }
-    if (nv && row0 + nv == n) {                                          // the thread that holds the last row
-        if (out.end) out.end[rid - 1] = (i64)((u64)p.min_e + f_low(x, be));
-        if (out.count) out.count[rid - 1] = (i64)(n - (prev - 1));
-        *d_m = rid;
-    }
+}
+
+template <bool LIN>
+ivx_status runs_packed(ivx_ctx *ctx, const u64 *w, u64 n, const Pack64 &p, i64 min_dist, int strict, const ivx_runs_out &out)
+{
+    hipStream_t stq = ctx->stream;
+    const u64 ntile = (n + FTILE - 1) / FTILE;
+    u64 *agg;                                                           // [0, ntile): V maxima, [ntile, 2 ntile): head summaries
+    IVX_TRY(ctx->get_scratch(WS_T5, 2 * ntile * sizeof(u64), (void **)&agg));
+    u64 *d_m = ctx->d_scalars + 2;
+    const size_t tab = LIN ? ((size_t)p.nkeys * 2 + 1) * sizeof(u64) : 0;
+    u32 bk = 0;
+    for (u64 x = p.nkeys ? p.nkeys - 1 : 0; x; x >>= 1) bk++;
+    const bool narrow = p.small && p.bits_e <= 32 && (LIN ? p.bits_s <= 32 : p.bits_s + bk <= 32) &&
+                        min_dist < (1ll << 61) && !getenv("IVX_NO_NARROW_RUNS");
+    hipLaunchKernelGGL((k_pk_max<LIN>), dim3((u32)ntile), dim3(FT), LIN ? ((size_t)p.nkeys + 1) * sizeof(u64) : 0, stq, w, n, p, agg);
+    IVX_TRY((ivxscan::exclusive<MaxPayOp>(ctx, agg, ntile)));
+    if (narrow)
+        hipLaunchKernelGGL((k_pk_runs<LIN, false, true>), dim3((u32)ntile), dim3(FT), tab, stq, w, n, p, min_dist, strict, (const u64 *)agg, agg + ntile,
+                           (const u64 *)nullptr, out, d_m);
+    else
+        hipLaunchKernelGGL((k_pk_runs<LIN, false, false>), dim3((u32)ntile), dim3(FT), tab, stq, w, n, p, min_dist, strict, (const u64 *)agg, agg + ntile,
+                           (const u64 *)nullptr, out, d_m);
+    IVX_TRY((ivxscan::exclusive<HeadPayOp>(ctx, agg + ntile, ntile)));
+    if (narrow)
+        hipLaunchKernelGGL((k_pk_runs<LIN, true, true>), dim3((u32)ntile), dim3(FT), tab, stq, w, n, p, min_dist, strict, (const u64 *)agg, (u64 *)nullptr,
+                           (const u64 *)(agg + ntile), out, d_m);
+    else
+        hipLaunchKernelGGL((k_pk_runs<LIN, true, false>), dim3((u32)ntile), dim3(FT), tab, stq, w, n, p, min_dist, strict, (const u64 *)agg, (u64 *)nullptr,
+                           (const u64 *)(agg + ntile), out, d_m);
+    IVX_HIP(ctx, hipGetLastError());
+    return IVX_OK;
 }
 
 }  // namespace
@@ -475,20 +613,10 @@ ivx_status ivx_merge_runs_packed(ivx_ctx *ctx, const u64 *w, u64 n, const Pack64
 {
     *m = 0;
     if (n == 0) return IVX_OK;
-    hipStream_t stq = ctx->stream;
-    const u64 ntile = (n + FTILE - 1) / FTILE;
-    u64 *st;
-    IVX_TRY(ctx->get_scratch(WS_SCAN0, (2 * ntile + 1) * sizeof(u64), (void **)&st));
-    IVX_HIP(ctx, hipMemsetAsync(st, 0, (2 * ntile + 1) * sizeof(u64), stq));
-    u64 *d_m = ctx->d_scalars + 2;
-    const size_t tab = p.lin ? ((size_t)p.nkeys * 2 + 1) * sizeof(u64) : 0;
-    if (p.lin)
-        hipLaunchKernelGGL((k_merge_fused<true>), dim3((u32)ntile), dim3(FT), tab, stq, w, n, p, min_dist, strict, out, st + 1, st + 1 + ntile, (u32 *)st, d_m);
-    else
-        hipLaunchKernelGGL((k_merge_fused<false>), dim3((u32)ntile), dim3(FT), tab, stq, w, n, p, min_dist, strict, out, st + 1, st + 1 + ntile, (u32 *)st, d_m);
-    IVX_HIP(ctx, hipGetLastError());
-    IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 2, d_m, sizeof(u64), hipMemcpyDeviceToHost, stq));
-    IVX_HIP(ctx, hipStreamSynchronize(stq));
+    if (p.lin) IVX_TRY(runs_packed<true>(ctx, w, n, p, min_dist, strict, out));
+    else IVX_TRY(runs_packed<false>(ctx, w, n, p, min_dist, strict, out));
+    IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 2, ctx->d_scalars + 2, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+    IVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *m = ctx->h_scalars[2];
     return IVX_OK;
 }

@@ -19,7 +19,8 @@
 // How the sweeps' sort packs a row into ONE 64-bit word (ivx_sweep.hip sort64): the end in the low bits_e bits (minus
 // min_e), above it either key ‖ (start - min_s) -- bits_s bits of start -- or, lin, the (key, start) pair's number in key-major
 // order: base[key] + (start - kmin[key]).
-struct Pack64 { i64 min_s, min_e; u32 bits_s, bits_e; const u64 *base; const long long *kmin; u32 lin, nkeys; };
+struct Pack64 { i64 min_s, min_e; u32 bits_s, bits_e; const u64 *base; const long long *kmin; u32 lin, nkeys;
+                u32 small, pad; };         // small: every start and end lies within +-2^61 (differences cannot overflow)
 
 // Rows sorted by (key, start, end) as the merge sweep reads them: three columns -- wide (u32 key, i64 start, i64 end: 20 bytes
 // per row in every pass of the sweep) or, s32 != nullptr, narrow (start and end as 32-bit offsets from min_s / min_e: 12

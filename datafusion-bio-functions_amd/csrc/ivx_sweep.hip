@@ -329,7 +329,11 @@ ivx_status sort64(ivx_ctx *ctx, int slot_a, int slot_b, const u32 *key, const i6
         return IVX_OK;
     }
     Pack64 p;
-    p.min_s = r.min_s; p.min_e = r.min_e; p.base = base; p.kmin = kmin; p.lin = 0; p.nkeys = nkeys;
+    p.min_s = r.min_s; p.min_e = r.min_e; p.base = base; p.kmin = kmin; p.lin = 0; p.nkeys = nkeys; p.pad = 0;
+    {
+        const long long lim = 1ll << 61;
+        p.small = r.min_s > -lim && r.max_s < lim && r.min_e > -lim && r.max_e < lim;
+    }
     p.bits_s = bits_of((u64)r.max_s - (u64)r.min_s); p.bits_e = bits_of((u64)r.max_e - (u64)r.min_e);
     u32 bits_k = bits_of(nkeys ? nkeys - 1 : 0);
     double positions = (double)(nkeys ? nkeys : 1) * (p.bits_s >= 62 ? 4.6e18 : (double)(1ull << p.bits_s));

@@ -504,7 +504,7 @@ def test_merge_one_pass_sweep(ctx, shape):
     s[::17] = s[1::17][: len(s[::17])]; k[::17] = k[1::17][: len(k[::17])]; e[::17] = np.maximum(e[::17], s[::17] + (shape != "empties"))
     for md, strict in ((0, False), (0, True), (9, True), (25, False)):
         want = orc.merge(k, s, e, min_dist=md, strict=strict)
-        for env in ({}, {"IVX_NO_FUSED_SWEEP": "1"}, {"IVX_NO_LIN": "1"}):
+        for env in ({}, {"IVX_NO_FUSED_SWEEP": "1"}, {"IVX_NO_LIN": "1"}, {"IVX_NO_NARROW_RUNS": "1"}):
             os.environ.update(env)
             try:
                 got = ctx.merge(k, s, e, n_keys=nk, min_dist=md, strict=strict)
