@@ -321,13 +321,9 @@ ivx_status sort64(ivx_ctx *ctx, int slot_a, int slot_b, const u32 *key, const i6
     IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 24, d_rng, 8 * sizeof(u64), hipMemcpyDeviceToHost, st));   // Range64 (6 words), d_lin (2 words)
     IVX_HIP(ctx, hipStreamSynchronize(st));
     const Range64 r = *(const Range64 *)(ctx->h_scalars + 24);
-    if (!r.unsorted && !getenv("IVX_FORCE_SORT")) {
-        // coordinate-sorted input (the usual state of BED / VCF / BAM-derived tables): nothing to sort, and equal
-        // rows already are in ascending row order
-        hipLaunchKernelGGL(k_copy_sorted, dim3(grid1(n)), dim3(ST), 0, st, key, s, e, n, ks, ss, es, rows);
-        IVX_HIP(ctx, hipGetLastError());
-        return IVX_OK;
-    }
+    // coordinate-sorted input (the usual state of BED / VCF / BAM-derived tables): nothing to sort, and equal
+    // rows already are in ascending row order
+    const bool sorted_in = !r.unsorted && !getenv("IVX_FORCE_SORT");
     Pack64 p;
     p.min_s = r.min_s; p.min_e = r.min_e; p.base = base; p.kmin = kmin; p.lin = 0; p.nkeys = nkeys; p.pad = 0;
     {
@@ -346,12 +342,20 @@ ivx_status sort64(ivx_ctx *ctx, int slot_a, int slot_b, const u32 *key, const i6
     // packed: one 64-bit sort word, plus the row ids -- a 32-bit payload -- only when the caller wants them back (merge /
     // complement / the right side of subtract do not: equal words are equal rows, and the record is 8 bytes instead of 12)
     const int nw = total <= 64 ? 1 : 3;
+    // (the packed sweep takes sorted input as well: one pack pass instead of a 20-byte copy and three passes over wide rows)
+    const bool packed = nw == 1 && pk && !rows && !getenv("IVX_NO_FUSED_SWEEP") &&
+                        ivx_merge_packed_ok(p, n, nkeys, pk->d, pk->strict, (r.odd & 1) != 0, (r.odd & 2) != 0);
+    if (sorted_in && !packed) {
+        hipLaunchKernelGGL(k_copy_sorted, dim3(grid1(n)), dim3(ST), 0, st, key, s, e, n, ks, ss, es, rows);
+        IVX_HIP(ctx, hipGetLastError());
+        return IVX_OK;
+    }
     narrow = narrow && nw == 1 && (u64)r.max_s - (u64)r.min_s <= 0xFFFFFFFFull && (u64)r.max_e - (u64)r.min_e <= 0xFFFFFFFFull;
     const bool k8 = narrow && nkeys <= 256 && !getenv("IVX_NO_K8");
     if (narrow) { sw->s32 = (const u32 *)ss; sw->e32 = (const u32 *)es; sw->min_s = r.min_s; sw->min_e = r.min_e; if (k8) sw->k8 = (const u8 *)ks; }
     for (int q = 0; q < nw; q++) {
         IVX_TRY(ctx->get_scratch(slot_a + q, n * sizeof(u64), (void **)&a[q]));
-        IVX_TRY(ctx->get_scratch(slot_b + q, n * sizeof(u64), (void **)&b[q]));
+        if (!(packed && sorted_in)) IVX_TRY(ctx->get_scratch(slot_b + q, n * sizeof(u64), (void **)&b[q]));
     }
     u32 *pay[2] = {nullptr, nullptr};
     const bool with_rows = nw == 1 && rows != nullptr;
@@ -360,11 +364,13 @@ ivx_status sort64(ivx_ctx *ctx, int slot_a, int slot_b, const u32 *key, const i6
         IVX_TRY(ctx->get_scratch(slot_b + 1, n * sizeof(u32), (void **)&pay[1]));
     }
     int in_b = 0;
-    if (nw == 1 && pk && !rows && !getenv("IVX_NO_FUSED_SWEEP") && ivx_merge_packed_ok(p, n, nkeys, pk->d, pk->strict, (r.odd & 1) != 0, (r.odd & 2) != 0)) {
+    if (packed) {
         hipLaunchKernelGGL(k_pack1, dim3(grid1(n)), dim3(ST), 0, st, key, s, e, n, p, a[0], (u32 *)nullptr);
-        const int lo = (int)p.bits_e;
-        const ivx_sort_field f[1] = {{0, lo, lo + (int)((total - p.bits_e + 7) / 8 * 8)}};
-        IVX_TRY(ivx_radix_sort(ctx, 1, a, b, n, f, 1, &in_b, true, nullptr));
+        if (!sorted_in) {
+            const int lo = (int)p.bits_e;
+            const ivx_sort_field f[1] = {{0, lo, lo + (int)((total - p.bits_e + 7) / 8 * 8)}};
+            IVX_TRY(ivx_radix_sort(ctx, 1, a, b, n, f, 1, &in_b, true, nullptr));
+        }
         pk->ok = true; pk->w = in_b ? b[0] : a[0]; pk->p = p;
         IVX_HIP(ctx, hipGetLastError());
         return IVX_OK;
