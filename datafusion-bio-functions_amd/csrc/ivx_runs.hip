@@ -353,10 +353,14 @@ __device__ __forceinline__ u32 wave_prev32(u32 v) { return dpp0<0x138, 0xf>(v); 
 //   (start - cur_end) - min_dist [- 1]  =  (lin - base) - x + K ,   K = kmin - min_e - min_dist - (strict ? 0 : 1).
 // The generic sections (any wavefront of a launch that is not NARROW, wavefronts that straddle a key or the end of the input)
 // carry a key per row and rebuild 64-bit V and the i64 start from the word where they need them.
-template <bool LIN, bool EMIT, bool NARROW>
-__global__ __launch_bounds__(FT, 8) void k_pk_runs(const u64 *__restrict__ w, u64 n, Pack64 p, i64 d, int strict, const u64 *__restrict__ pre1,
-                                                  u64 *__restrict__ agg2, const u64 *__restrict__ pre2, ivx_runs_out out, u64 *d_m)
+// MODE 0: the tile's head summary.  1: emit the runs (merge).  2: cluster() -- every row's run number and its run's start,
+// the runs' ends by number, per key the runs before its first and up to its last.
+struct PkCluster { u32 *rid; i64 *cstart; i64 *run_end; u32 *kfirst, *klast; };
+template <bool LIN, int MODE, bool NARROW>
+__global__ __launch_bounds__(FT, MODE == 2 ? 5 : 8) void k_pk_runs(const u64 *__restrict__ w, u64 n, Pack64 p, i64 d, int strict, const u64 *__restrict__ pre1,
+                                                  u64 *__restrict__ agg2, const u64 *__restrict__ pre2, ivx_runs_out out, PkCluster cl, u64 *d_m)
 {
+    constexpr bool EMIT = MODE != 0;
     extern __shared__ u64 s_tab[];                                      // LIN: base[nkeys + 1], kmin[nkeys]
     __shared__ u64 s_x[FWV][IVX_WAVE * FI + IVX_WAVE];                  // a wavefront's 512 words, one spare slot per lane
     __shared__ u64 s_wmax[FWV];
@@ -508,6 +512,91 @@ __global__ __launch_bounds__(FT, 8) void k_pk_runs(const u64 *__restrict__ w, u6
     u32 prev = (u32)(P2 & 0x7FFFFFFFull);                                 // (row number of the latest head before them) + 1
     prev = lpre > prev ? lpre : prev;
     { const u32 up = wave_prev32(linc); prev = up > prev ? up : prev; }
+    if (MODE == 2) {
+        // ---- section 3, cluster(): a head closes the run before it (run_end) and, when it opens a key, settles the keys' run
+        //      ranges; then per row the number of its run and the start of that run's head (rebuilt from the head mask row by
+        //      row: nothing per row is kept in registers across the passes)
+        const u32 rid0 = rid, prev0 = prev;
+        if (fast) {
+            u32 x = x32;
+            if (__ballot(hm != 0)) {
+#pragma unroll
+                for (int i = 0; i < FI; i++) {
+                    const u32 eo = (u32)r[i] & emask;
+                    if ((hm >> i) & 1u) {
+                        if (prev && cl.run_end) cl.run_end[rid - 1] = (i64)((u64)p.min_e + x);
+                        if (i == 0 && !hv) { cl.kfirst[kA] = rid; if (prev) cl.klast[(u32)(Xw >> be) - 1u] = rid; }
+                        prev = (u32)(row0 + i) + 1; rid++;
+                    }
+                    x = ((i == 0 && !hv) || eo > x) ? eo : x;
+                }
+            } else if (row0 + FI == n) {
+#pragma unroll
+                for (int i = 0; i < FI; i++) { const u32 eo = (u32)r[i] & emask; x = eo > x ? eo : x; }
+            }
+            if (row0 + FI == n) {
+                if (cl.run_end) cl.run_end[rid - 1] = (i64)((u64)p.min_e + x);
+                cl.klast[kA] = rid; *d_m = rid;
+            }
+        } else {
+            u64 x = X;
+            u32 kl = 0;                                                   // key of the thread's last row
+#pragma unroll
+            for (int i = 0; i < FI; i++) {
+                if ((u32)i < nv) {
+                    kl = k[i];
+                    if ((hm >> i) & 1u) {
+                        if (prev && cl.run_end) cl.run_end[rid - 1] = (i64)((u64)p.min_e + f_low(x, be));
+                        if (f_shr(x, be) != (u64)k[i] + 1) { cl.kfirst[k[i]] = rid; if (prev) cl.klast[(u32)f_shr(x, be) - 1u] = rid; }
+                        prev = (u32)(row0 + i) + 1; rid++;
+                    }
+                    const u64 v = Vof(i);
+                    x = v > x ? v : x;
+                }
+            }
+            if (nv && row0 + nv == n) {
+                if (cl.run_end) cl.run_end[rid - 1] = (i64)((u64)p.min_e + f_low(x, be));
+                cl.klast[kl] = rid; *d_m = rid;
+            }
+        }
+        // the rows' values leave as the words came: turned through the wavefront's LDS slots into whole-line stores
+        if (cl.rid) {
+            __builtin_amdgcn_wave_barrier();
+            u32 rr = rid0;
+#pragma unroll
+            for (int i = 0; i < FI; i++) { rr += (hm >> i) & 1u; s_x[wv][ln * (FI + 1) + i] = rr - 1; }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < FI; q++) { const u32 e = (u32)q * IVX_WAVE + ln; if (w0 + e < n) cl.rid[w0 + e] = (u32)s_x[wv][e + (e >> 3)]; }
+        }
+        if (cl.cstart) {
+            __builtin_amdgcn_wave_barrier();
+            if (fast) {
+                u32 lin_h = prev0 ? (u32)(w[prev0 - 1] >> be) : 0u;      // (used only when this thread's first row continues that head's run)
+#pragma unroll
+                for (int i = 0; i < FI; i++) {
+                    if ((hm >> i) & 1u) lin_h = (u32)(r[i] >> be);
+                    s_x[wv][ln * (FI + 1) + i] = (u64)koffA + (lin_h - baseA);
+                }
+            } else {
+                i64 cs_h = 0;
+                if (prev0 && nv) {                                       // the head before this thread's rows
+                    const u64 wp = w[prev0 - 1];
+                    if (LIN) { const u64 lin = f_shr(wp, be); const u32 kh = f_key(s_base, p.nkeys, lin); cs_h = (i64)(s_kmin[kh] + (lin - s_base[kh])); }
+                    else cs_h = (i64)((u64)p.min_s + f_low(f_shr(wp, be), bs));
+                }
+#pragma unroll
+                for (int i = 0; i < FI; i++) {
+                    if ((u32)i < nv && ((hm >> i) & 1u)) cs_h = sof(i);
+                    s_x[wv][ln * (FI + 1) + i] = (u64)cs_h;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < FI; q++) { const u32 e = (u32)q * IVX_WAVE + ln; if (w0 + e < n) cl.cstart[w0 + e] = (i64)s_x[wv][e + (e >> 3)]; }
+        }
+        return;
+    }
     // ---- section 3, emit: a head closes the run before it and opens its own
     if (fast) {
         u32 x = x32;
@@ -566,7 +655,7 @@ __global__ __launch_bounds__(FT, 8) void k_pk_runs(const u64 *__restrict__ w, u6
 }
 
 template <bool LIN>
-ivx_status runs_packed(ivx_ctx *ctx, const u64 *w, u64 n, const Pack64 &p, i64 min_dist, int strict, const ivx_runs_out &out)
+ivx_status runs_packed(ivx_ctx *ctx, const u64 *w, u64 n, const Pack64 &p, i64 min_dist, int strict, const ivx_runs_out &out, const PkCluster *cl)
 {
     hipStream_t stq = ctx->stream;
     const u64 ntile = (n + FTILE - 1) / FTILE;
@@ -578,23 +667,41 @@ ivx_status runs_packed(ivx_ctx *ctx, const u64 *w, u64 n, const Pack64 &p, i64 m
     for (u64 x = p.nkeys ? p.nkeys - 1 : 0; x; x >>= 1) bk++;
     const bool narrow = p.small && p.bits_e <= 32 && (LIN ? p.bits_s <= 32 : p.bits_s + bk <= 32) &&
                         min_dist < (1ll << 61) && !getenv("IVX_NO_NARROW_RUNS");
-    hipLaunchKernelGGL((k_pk_max<LIN>), dim3((u32)ntile), dim3(FT), LIN ? ((size_t)p.nkeys + 1) * sizeof(u64) : 0, stq, w, n, p, agg);
+    const PkCluster none{nullptr, nullptr, nullptr, nullptr, nullptr};
+    const dim3 grid((u32)ntile), blk(FT);
+    const u64 *pre1 = agg, *pre2 = agg + ntile;
+    hipLaunchKernelGGL((k_pk_max<LIN>), grid, blk, LIN ? ((size_t)p.nkeys + 1) * sizeof(u64) : 0, stq, w, n, p, agg);
     IVX_TRY((ivxscan::exclusive<MaxPayOp>(ctx, agg, ntile)));
-    if (narrow)
-        hipLaunchKernelGGL((k_pk_runs<LIN, false, true>), dim3((u32)ntile), dim3(FT), tab, stq, w, n, p, min_dist, strict, (const u64 *)agg, agg + ntile,
-                           (const u64 *)nullptr, out, d_m);
-    else
-        hipLaunchKernelGGL((k_pk_runs<LIN, false, false>), dim3((u32)ntile), dim3(FT), tab, stq, w, n, p, min_dist, strict, (const u64 *)agg, agg + ntile,
-                           (const u64 *)nullptr, out, d_m);
+    if (narrow) hipLaunchKernelGGL((k_pk_runs<LIN, 0, true>), grid, blk, tab, stq, w, n, p, min_dist, strict, pre1, agg + ntile, (const u64 *)nullptr, out, none, d_m);
+    else hipLaunchKernelGGL((k_pk_runs<LIN, 0, false>), grid, blk, tab, stq, w, n, p, min_dist, strict, pre1, agg + ntile, (const u64 *)nullptr, out, none, d_m);
     IVX_TRY((ivxscan::exclusive<HeadPayOp>(ctx, agg + ntile, ntile)));
-    if (narrow)
-        hipLaunchKernelGGL((k_pk_runs<LIN, true, true>), dim3((u32)ntile), dim3(FT), tab, stq, w, n, p, min_dist, strict, (const u64 *)agg, (u64 *)nullptr,
-                           (const u64 *)(agg + ntile), out, d_m);
-    else
-        hipLaunchKernelGGL((k_pk_runs<LIN, true, false>), dim3((u32)ntile), dim3(FT), tab, stq, w, n, p, min_dist, strict, (const u64 *)agg, (u64 *)nullptr,
-                           (const u64 *)(agg + ntile), out, d_m);
+    if (cl) {
+        if (narrow) hipLaunchKernelGGL((k_pk_runs<LIN, 2, true>), grid, blk, tab, stq, w, n, p, min_dist, strict, pre1, (u64 *)nullptr, pre2, out, *cl, d_m);
+        else hipLaunchKernelGGL((k_pk_runs<LIN, 2, false>), grid, blk, tab, stq, w, n, p, min_dist, strict, pre1, (u64 *)nullptr, pre2, out, *cl, d_m);
+    } else {
+        if (narrow) hipLaunchKernelGGL((k_pk_runs<LIN, 1, true>), grid, blk, tab, stq, w, n, p, min_dist, strict, pre1, (u64 *)nullptr, pre2, out, none, d_m);
+        else hipLaunchKernelGGL((k_pk_runs<LIN, 1, false>), grid, blk, tab, stq, w, n, p, min_dist, strict, pre1, (u64 *)nullptr, pre2, out, none, d_m);
+    }
     IVX_HIP(ctx, hipGetLastError());
     return IVX_OK;
+}
+
+// cluster(), last pass: the id of every row's run -- global, or counted from the key's base (ClusterIdCoordinator) -- and the
+// run's end, from the run numbers k_pk_runs<2> left.  ks: the (unpacked) key column; rows of one (key, start) may sit in another
+// order there than in the packed words, but they share their run.
+__global__ __launch_bounds__(RT) void k_pk_cluster_fin(const u32 *__restrict__ rid, const u32 *__restrict__ ks, u64 n, u32 nkeys,
+                                                       const u32 *__restrict__ kfirst, const i64 *__restrict__ key_base,
+                                                       const i64 *__restrict__ run_end, i64 *cluster, i64 *cend)
+{
+    const u64 i = (u64)blockIdx.x * RT + threadIdx.x;
+    if (i >= n) return;
+    const u32 r = rid[i];
+    if (cluster) {
+        i64 c = (i64)r;
+        if (key_base) { const u32 k = ks[i]; if (k < nkeys) c = key_base[k] + (i64)(r - kfirst[k]); }
+        cluster[i] = c;
+    }
+    if (cend) cend[i] = run_end[r];
 }
 
 }  // namespace
@@ -613,8 +720,8 @@ ivx_status ivx_merge_runs_packed(ivx_ctx *ctx, const u64 *w, u64 n, const Pack64
 {
     *m = 0;
     if (n == 0) return IVX_OK;
-    if (p.lin) IVX_TRY(runs_packed<true>(ctx, w, n, p, min_dist, strict, out));
-    else IVX_TRY(runs_packed<false>(ctx, w, n, p, min_dist, strict, out));
+    if (p.lin) IVX_TRY(runs_packed<true>(ctx, w, n, p, min_dist, strict, out, nullptr));
+    else IVX_TRY(runs_packed<false>(ctx, w, n, p, min_dist, strict, out, nullptr));
     IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 2, ctx->d_scalars + 2, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
     IVX_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *m = ctx->h_scalars[2];
@@ -676,6 +783,40 @@ __global__ __launch_bounds__(RT) void k_cluster_rows(const u32 *__restrict__ ks,
 }
 
 }  // namespace
+
+// cluster() over the packed words (see ivx_runs.hpp).  Scratch: WS_T5 (tile summaries), WS_T6 (run numbers), WS_T7 (run ends),
+// WS_T8 / WS_T9 (per-key run ranges).
+ivx_status ivx_cluster_rows_packed(ivx_ctx *ctx, const u64 *w, const Pack64 &p, const u32 *ks, u64 n, u32 nkeys,
+                                   i64 min_dist, int strict, const i64 *key_base, const ivx_cluster_out &out, u64 *m)
+{
+    *m = 0;
+    hipStream_t stq = ctx->stream;
+    u32 *kfirst, *klast;
+    IVX_TRY(ctx->get_scratch(WS_T8, (size_t)nkeys * sizeof(u32), (void **)&kfirst));
+    IVX_TRY(ctx->get_scratch(WS_T9, (size_t)nkeys * sizeof(u32), (void **)&klast));
+    IVX_HIP(ctx, hipMemsetAsync(kfirst, 0, (size_t)nkeys * sizeof(u32), stq));
+    IVX_HIP(ctx, hipMemsetAsync(klast, 0, (size_t)nkeys * sizeof(u32), stq));
+    if (n) {
+        const bool rows_out = out.cluster || out.start || out.end;
+        u32 *rid = nullptr; i64 *run_end = nullptr;
+        if (out.cluster || out.end) IVX_TRY(ctx->get_scratch(WS_T6, n * sizeof(u32), (void **)&rid));
+        if (out.end) IVX_TRY(ctx->get_scratch(WS_T7, n * sizeof(i64), (void **)&run_end));
+        const PkCluster cl{rid, out.start, run_end, kfirst, klast};
+        const ivx_runs_out none{nullptr, nullptr, nullptr, nullptr};
+        if (p.lin) IVX_TRY(runs_packed<true>(ctx, w, n, p, min_dist, strict, none, &cl));
+        else IVX_TRY(runs_packed<false>(ctx, w, n, p, min_dist, strict, none, &cl));
+        if (rows_out && (out.cluster || out.end))
+            hipLaunchKernelGGL(k_pk_cluster_fin, dim3((u32)((n + RT - 1) / RT)), dim3(RT), 0, stq, (const u32 *)rid, ks, n, nkeys, (const u32 *)kfirst, key_base,
+                               (const i64 *)run_end, out.cluster, out.end);
+    }
+    if (out.key_clusters)
+        hipLaunchKernelGGL(k_key_clusters, dim3((nkeys + RT - 1) / RT), dim3(RT), 0, stq, (const u32 *)kfirst, (const u32 *)klast, nkeys, out.key_clusters);
+    IVX_HIP(ctx, hipGetLastError());
+    IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 2, ctx->d_scalars + 2, sizeof(u64), hipMemcpyDeviceToHost, stq));
+    IVX_HIP(ctx, hipStreamSynchronize(stq));
+    *m = n ? ctx->h_scalars[2] : 0;
+    return IVX_OK;
+}
 
 ivx_status ivx_cluster_rows(ivx_ctx *ctx, const u32 *ks, const i64 *ss, const i64 *es, u64 n, u32 nkeys,
                             i64 min_dist, int strict, const i64 *key_base, const ivx_cluster_out &out, u64 *m)

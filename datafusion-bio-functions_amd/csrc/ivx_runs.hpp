@@ -70,3 +70,9 @@ ivx_status ivx_merge_runs_packed(ivx_ctx *ctx, const u64 *w, u64 n, const Pack64
 struct ivx_cluster_out { i64 *cluster; i64 *start; i64 *end; u64 *key_clusters; };
 ivx_status ivx_cluster_rows(ivx_ctx *ctx, const u32 *ks, const i64 *ss, const i64 *es, u64 n, u32 nkeys,
                             i64 min_dist, int strict, const i64 *key_base, const ivx_cluster_out &out, u64 *m);
+// ... and over the sort's packed words when ivx_merge_packed_ok allows (w: sorted on the (key, start) bits at least; ks: the
+// unpacked key column, for the per-key id base): tile maxima, run heads, one pass that leaves every row's run number and run
+// start, one that turns the numbers into ids and run ends -- instead of three passes over 20-byte rows, a 16-byte state per
+// row and two per-row passes.
+ivx_status ivx_cluster_rows_packed(ivx_ctx *ctx, const u64 *w, const Pack64 &p, const u32 *ks, u64 n, u32 nkeys,
+                                   i64 min_dist, int strict, const i64 *key_base, const ivx_cluster_out &out, u64 *m);

@@ -287,8 +287,9 @@ u32 bits_of(u64 x) { u32 b = 0; while (x) { b++; x >>= 1; } return b; }
 // sort (key,start,end,row) ascending; rows of equal (key,start,end) keep input order = ascending row
 // sw (nullable; needs rows == nullptr): the caller reads the sorted rows through a SortedRows -- narrow columns (32-bit
 // offsets, stored in ss / es as u32 arrays) whenever the one-word form applies and both ranges fit 32 bits, else the wide ones.
-// pk (nullable; with sw): the caller is the merge sweep with pk->d / pk->strict and takes the PACKED words, sorted on their
-// (key, start) bits only, whenever ivx_merge_packed_ok says the one-pass sweep applies: pk->ok, and nothing is unpacked.
+// pk (nullable): the caller is a merge sweep with pk->d / pk->strict and takes the PACKED words, sorted on their (key, start)
+// bits at least, whenever ivx_merge_packed_ok says the sweep over packed words applies: pk->ok.  With sw (merge, complement)
+// nothing is unpacked then; without (cluster) the rows are unpacked as always and pk->w stays valid beside them.
 struct PackedWant { i64 d; int strict; bool ok; const u64 *w; Pack64 p; };
 ivx_status sort64(ivx_ctx *ctx, int slot_a, int slot_b, const u32 *key, const i64 *s, const i64 *e, u64 n, u32 nkeys,
                   u32 *ks, i64 *ss, i64 *es, u32 *rows, SortedRows *sw = nullptr, PackedWant *pk = nullptr)
@@ -343,10 +344,19 @@ ivx_status sort64(ivx_ctx *ctx, int slot_a, int slot_b, const u32 *key, const i6
     // complement / the right side of subtract do not: equal words are equal rows, and the record is 8 bytes instead of 12)
     const int nw = total <= 64 ? 1 : 3;
     // (the packed sweep takes sorted input as well: one pack pass instead of a 20-byte copy and three passes over wide rows)
-    const bool packed = nw == 1 && pk && !rows && !getenv("IVX_NO_FUSED_SWEEP") &&
+    const bool packed = nw == 1 && pk && sw && !rows && !getenv("IVX_NO_FUSED_SWEEP") &&
                         ivx_merge_packed_ok(p, n, nkeys, pk->d, pk->strict, (r.odd & 1) != 0, (r.odd & 2) != 0);
+    // (a caller that needs the unpacked rows AND sweeps over the packed words -- cluster -- gets both: pk->w stays valid)
+    const bool also = nw == 1 && pk && !sw && !getenv("IVX_NO_FUSED_SWEEP") &&
+                      ivx_merge_packed_ok(p, n, nkeys, pk->d, pk->strict, (r.odd & 1) != 0, (r.odd & 2) != 0);
     if (sorted_in && !packed) {
         hipLaunchKernelGGL(k_copy_sorted, dim3(grid1(n)), dim3(ST), 0, st, key, s, e, n, ks, ss, es, rows);
+        if (also) {
+            u64 *pw;
+            IVX_TRY(ctx->get_scratch(slot_a, n * sizeof(u64), (void **)&pw));
+            hipLaunchKernelGGL(k_pack1, dim3(grid1(n)), dim3(ST), 0, st, key, s, e, n, p, pw, (u32 *)nullptr);
+            pk->ok = true; pk->w = pw; pk->p = p;
+        }
         IVX_HIP(ctx, hipGetLastError());
         return IVX_OK;
     }
@@ -420,6 +430,7 @@ ivx_status sort64(ivx_ctx *ctx, int slot_a, int slot_b, const u32 *key, const i6
             hipLaunchKernelGGL((k_unpack1<false>), dim3((grid1(n) + UNPACK_TILES - 1) / UNPACK_TILES), dim3(ST), 0, st, (const u64 *)o[0], (const u32 *)pay[in_b], n, p, ks, ss, es, rows,
                                0u, (u32 *)nullptr);
         }
+        if (also) { pk->ok = true; pk->w = o[0]; pk->p = p; }
     } else {
         hipLaunchKernelGGL(k_pack64, dim3(grid1(n)), dim3(ST), 0, st, key, s, e, n, nkeys, a[0], a[1], a[2], flags);
         const ivx_sort_field f[3] = {{0, 0, 64}, {1, 0, 64}, {2, 32, 64}};
@@ -991,10 +1002,12 @@ ivx_status ivx_cluster_device(ivx_ctx *ctx, const u32 *key, const i64 *s, const 
         if (!ks) IVX_TRY(ctx->get_scratch(WS_T0, n * sizeof(u32), (void **)&ks));
         if (!ss) IVX_TRY(ctx->get_scratch(WS_T1, n * sizeof(i64), (void **)&ss));
         if (!es) IVX_TRY(ctx->get_scratch(WS_T2, n * sizeof(i64), (void **)&es));
-        IVX_TRY(sort64(ctx, WS_SA0, WS_SB0, key, s, e, n, nkeys, ks, ss, es, rows));
     }
+    PackedWant pk{min_dist, strict, false, nullptr, Pack64{}};
+    if (n) IVX_TRY(sort64(ctx, WS_SA0, WS_SB0, key, s, e, n, nkeys, ks, ss, es, rows, nullptr, &pk));
     const ivx_cluster_out co{oc, ocs, oce, key_clusters};
-    IVX_TRY(ivx_cluster_rows(ctx, ks, ss, es, n, nkeys, min_dist, strict, key_base, co, m));
+    if (pk.ok) IVX_TRY(ivx_cluster_rows_packed(ctx, pk.w, pk.p, ks, n, nkeys, min_dist, strict, key_base, co, m));
+    else IVX_TRY(ivx_cluster_rows(ctx, ks, ss, es, n, nkeys, min_dist, strict, key_base, co, m));
     return keyflag(ctx, "cluster: key id >= n_keys");
 }
 

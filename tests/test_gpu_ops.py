@@ -661,6 +661,44 @@ def test_cluster_random(ctx, seed):
                       orc.cluster(k, s, e, min_dist=md, strict=strict, n_keys=nk + 2))
 
 
+@pytest.mark.parametrize("shape", ["sparse", "dense", "many_keys", "sorted"])
+def test_cluster_over_packed_words(ctx, shape):
+    """Well-formed rows: cluster() sweeps over the sort's packed words (k_pk_runs<2> + k_pk_cluster_fin); IVX_NO_FUSED_SWEEP=1
+    is the scan over unpacked rows.  Several hundred tiles, keys that open inside tiles and wavefronts, equal starts, ids with
+    and without a per-key base, the per-key counts alone."""
+    rng = np.random.default_rng(777)
+    n = 1_200_000
+    nk = {"sparse": 24, "dense": 24, "many_keys": 500, "sorted": 9}[shape]
+    span = {"sparse": 150_000_000, "dense": 200_000, "many_keys": 30_000, "sorted": 5_000_000}[shape]
+    k = rng.integers(0, nk, n).astype(np.uint32)
+    if shape == "many_keys":
+        k[k % 5 == 2] = 7
+    s = rng.integers(0, span, n).astype(np.int64) + rng.integers(-10**6, 10**6, nk)[k]
+    e = s + rng.integers(1, 80, n)
+    s[::19] = s[1::19][: len(s[::19])]; k[::19] = k[1::19][: len(k[::19])]; e[::19] = np.maximum(e[::19], s[::19] + 1)
+    if shape == "sorted":
+        o = np.lexsort((e, s, k)); k, s, e = k[o].copy(), s[o].copy(), e[o].copy()
+    base = (np.arange(nk + 1, dtype=np.int64) * 1_000_003)[: nk + 1]
+    for md, strict in ((0, False), (6, True), (40, False)):
+        want = orc.cluster(k, s, e, min_dist=md, strict=strict, n_keys=nk + 1)
+        for env in ({}, {"IVX_NO_FUSED_SWEEP": "1"}, {"IVX_NO_NARROW_RUNS": "1"}):
+            os.environ.update(env)
+            try:
+                got = ctx.cluster(k, s, e, n_keys=nk + 1, min_dist=md, strict=strict)
+                cnt = ctx.cluster(k, s, e, n_keys=nk + 1, min_dist=md, strict=strict, rows=False)
+                based = ctx.cluster(k, s, e, n_keys=nk + 1, min_dist=md, strict=strict, key_base=base)
+            finally:
+                for v in env:
+                    os.environ.pop(v, None)
+            _same_cluster(got, want)
+            assert (np.asarray(cnt["key_clusters"]).astype(np.int64) == np.asarray(got["key_clusters"]).astype(np.int64)).all()
+            assert cnt["n_clusters"] == got["n_clusters"]
+            kc = np.asarray(got["key_clusters"]).astype(np.int64)
+            first = np.concatenate([[0], np.cumsum(kc)[:-1]])
+            kk = np.asarray(got["key"]).astype(np.int64)
+            assert (np.asarray(based["cluster"]).astype(np.int64) == np.asarray(got["cluster"]).astype(np.int64) - first[kk] + base[kk]).all(), (shape, md, strict, env)
+
+
 def test_cluster_sharded_ids_match_single_run(ctx):
     # two "partitions" holding disjoint contigs: counts first, exclusive scan over the keys in
     # order (what ClusterIdCoordinator does, cluster.rs:396-417), then ids with key_base
