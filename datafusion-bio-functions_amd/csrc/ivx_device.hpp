@@ -11,6 +11,29 @@ __device__ __forceinline__ u32 mask_rank(u64 mask)
     return __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u));
 }
 
+// 32-bit wavefront scans on the DPP path (row shifts, then the row broadcasts of gfx9): no LDS round trip per step as with
+// ds_bpermute.  Lanes without a source take `old` = 0, the identity of both operators used here.
+template <int CTRL, int ROWS>
+__device__ __forceinline__ u32 dpp0(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWS, 0xf, false); }
+__device__ __forceinline__ u32 wave_incl_max32(u32 v)
+{
+    u32 o;
+    o = dpp0<0x111, 0xf>(v); v = o > v ? o : v;                          // row_shr:1, 2, 4, 8
+    o = dpp0<0x112, 0xf>(v); v = o > v ? o : v;
+    o = dpp0<0x114, 0xf>(v); v = o > v ? o : v;
+    o = dpp0<0x118, 0xf>(v); v = o > v ? o : v;
+    o = dpp0<0x142, 0xa>(v); v = o > v ? o : v;                          // row_bcast:15 into rows 1 and 3
+    o = dpp0<0x143, 0xc>(v); v = o > v ? o : v;                          // row_bcast:31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ u32 wave_incl_sum32(u32 v)
+{
+    v += dpp0<0x111, 0xf>(v); v += dpp0<0x112, 0xf>(v); v += dpp0<0x114, 0xf>(v); v += dpp0<0x118, 0xf>(v);
+    v += dpp0<0x142, 0xa>(v); v += dpp0<0x143, 0xc>(v);
+    return v;
+}
+__device__ __forceinline__ u32 wave_prev32(u32 v) { return dpp0<0x138, 0xf>(v); }      // wave_shr:1 (lane 0: 0)
+
 template <typename T>
 __device__ __forceinline__ T wave_incl_scan(T v)
 {

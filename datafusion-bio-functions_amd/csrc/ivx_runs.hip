@@ -324,29 +324,6 @@ __global__ __launch_bounds__(FT) void k_pk_max(const u64 *__restrict__ w, u64 n,
     }
 }
 
-// 32-bit wavefront scans on the DPP path (row shifts, then the row broadcasts of gfx9): no LDS round trip per step as with
-// ds_bpermute.  Lanes without a source take `old` = 0, the identity of both operators used here.
-template <int CTRL, int ROWS>
-__device__ __forceinline__ u32 dpp0(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWS, 0xf, false); }
-__device__ __forceinline__ u32 wave_incl_max32(u32 v)
-{
-    u32 o;
-    o = dpp0<0x111, 0xf>(v); v = o > v ? o : v;                          // row_shr:1, 2, 4, 8
-    o = dpp0<0x112, 0xf>(v); v = o > v ? o : v;
-    o = dpp0<0x114, 0xf>(v); v = o > v ? o : v;
-    o = dpp0<0x118, 0xf>(v); v = o > v ? o : v;
-    o = dpp0<0x142, 0xa>(v); v = o > v ? o : v;                          // row_bcast:15 into rows 1 and 3
-    o = dpp0<0x143, 0xc>(v); v = o > v ? o : v;                          // row_bcast:31 into rows 2 and 3
-    return v;
-}
-__device__ __forceinline__ u32 wave_incl_sum32(u32 v)
-{
-    v += dpp0<0x111, 0xf>(v); v += dpp0<0x112, 0xf>(v); v += dpp0<0x114, 0xf>(v); v += dpp0<0x118, 0xf>(v);
-    v += dpp0<0x142, 0xa>(v); v += dpp0<0x143, 0xc>(v);
-    return v;
-}
-__device__ __forceinline__ u32 wave_prev32(u32 v) { return dpp0<0x138, 0xf>(v); }      // wave_shr:1 (lane 0: 0)
-
 // NARROW (decided on the host: bits_e <= 32, the word's upper part -- `lin` -- fits 32 bits, every coordinate and min_dist within
 // +-2^61 so that differences cannot overflow): a wavefront whose 512 rows share ONE key -- all but a few dozen of a launch --
 // works on 32-bit (lin, end offset) pairs with the key's tables in scalar registers; the run-head test is the sign of

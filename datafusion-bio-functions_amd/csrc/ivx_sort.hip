@@ -120,6 +120,16 @@ __global__ __launch_bounds__(RS_T) void k_scatter(CPtrs<NW> in, Ptrs<NW> out, u6
     constexpr int RS_I = Tile<NW>::I, RS_TILE = Tile<NW>::N, RS_WTILE = Tile<NW>::WT;
     __shared__ u64 rec[NW][RS_TILE];
     __shared__ u32 recp[PAY ? RS_TILE : 1];
+    // 8-byte records: the lanes that share a digit find each other through one 64-bit word per (wavefront, digit) -- every
+    // lane ORs its bit in, reads the word, writes zero back (LDS operations of a wavefront execute in order) -- instead of
+    // eight ballots and sixteen selects per record: the kernel is bound by the instructions it issues (122 VALU per 64
+    // records with the ballots), not by its 3.2 GB.  The wider records' tiles leave no room for the 32 KB.
+#ifdef IVX_SORT_NO_LMATCH
+    constexpr bool LMATCH = false;
+#else
+    constexpr bool LMATCH = NW == 1;
+#endif
+    __shared__ u64 pmask[LMATCH ? RS_WAVES : 1][LMATCH ? 256 : 1];
     __shared__ u32 wcnt[RS_WAVES][256];          // per-wave digit counts -> exclusive offsets across waves
     __shared__ u32 dstart[256];                  // first local slot of the digit in this tile
     __shared__ u32 tcnt[256];                    // records of the digit in this tile
@@ -128,11 +138,14 @@ __global__ __launch_bounds__(RS_T) void k_scatter(CPtrs<NW> in, Ptrs<NW> out, u6
 
     const u32 tid = threadIdx.x, wv = tid / IVX_WAVE, ln = lane_id();
     if (tid < 256) gbase[tid] = offs[(u64)tid * nblk + blockIdx.x];
+    if (LMATCH) for (int i = tid; i < RS_WAVES * 256; i += RS_T) (&pmask[0][0])[i] = 0;     // (the first tile's barrier orders this)
+    const u64 lanebit = 1ull << ln;
     const u64 lo = (u64)blockIdx.x * chunk;
     const u64 hi = lo + chunk < n ? lo + chunk : n;
 
     // 8-byte records: the next tile's records are loaded while this one goes through LDS (registers allow it)
-    constexpr bool PREFETCH = NW == 1;
+    // (not with the 32-bit payload: 24 more registers per thread spilled 156 bytes per lane and bought nothing, 0.85 -> 0.79 ms)
+    constexpr bool PREFETCH = NW == 1 && !PAY;
     u64 nxt[PREFETCH ? RS_I : 1][NW];
     u32 nxp[PREFETCH && PAY ? RS_I : 1];
     auto load_tile = [&](u64 t0, u64 (&dst)[PREFETCH ? RS_I : 1][NW], u32 (&dp)[PREFETCH && PAY ? RS_I : 1]) {
@@ -197,7 +210,15 @@ __global__ __launch_bounds__(RS_T) void k_scatter(CPtrs<NW> in, Ptrs<NW> out, u6
             const u32 j = wv * RS_WTILE + k * IVX_WAVE + ln;        // slot in tile
             const bool valid = j < tile_n;
             const u32 d = valid ? (u32)((pick_word<NW>(r[k], word) >> shift) & 0xFF) : 0u;
-            const u64 peers = match_digit(d, valid);
+            u64 peers;
+            if (LMATCH) {
+                peers = 0;
+                if (valid) {
+                    atomicOr((unsigned long long *)&pmask[LMATCH ? wv : 0][LMATCH ? d : 0], (unsigned long long)lanebit);
+                    peers = pmask[LMATCH ? wv : 0][LMATCH ? d : 0];
+                    pmask[LMATCH ? wv : 0][LMATCH ? d : 0] = 0;
+                }
+            } else peers = match_digit(d, valid);
             u32 base = 0;
             if (valid) base = wcnt[wv][d];
             const u32 rk = mask_rank(peers);

@@ -84,17 +84,26 @@ __global__ __launch_bounds__(ST) void k_range64(const u32 *__restrict__ key, con
     i64 lo_s = INT64_MAX, hi_s = INT64_MIN, lo_e = INT64_MAX, hi_e = INT64_MIN;
     bool bad = false, inv = false, mal = false, emp = false;
     constexpr int U = 4;                                                // rows per thread in flight (their loads depend on nothing)
-    for (u64 i0 = (u64)blockIdx.x * (ST * U) + threadIdx.x; i0 < n; i0 += (u64)gridDim.x * (ST * U)) {
-        i64 a[U], b[U], pa[U], pb[U]; u32 k[U], pk[U];
+    const u32 ln = lane_id();
+    for (u64 i0 = (u64)blockIdx.x * (ST * U) + threadIdx.x; i0 - threadIdx.x < n; i0 += (u64)gridDim.x * (ST * U)) {
+        i64 a[U], b[U]; u32 k[U];
+        // the row before lane 0's (the other lanes take their neighbour's registers: half the loads of reading row i - 1 too)
+        i64 pa0[U], pb0[U]; u32 pk0[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const u64 i = i0 + (u64)u * ST;
-            const bool in = i < n, hp = in && i > 0;
+            const bool in = i < n;
             a[u] = in ? s[i] : 0; b[u] = in ? e[i] : 0; k[u] = in ? (key ? key[i] : 0u) : 0u;
-            pa[u] = hp ? s[i - 1] : INT64_MIN; pb[u] = hp ? e[i - 1] : INT64_MIN; pk[u] = hp ? (key ? key[i - 1] : 0u) : 0u;
+            pa0[u] = INT64_MIN; pb0[u] = INT64_MIN; pk0[u] = 0u;
+            if (ln == 0 && in && i > 0) { pa0[u] = s[i - 1]; pb0[u] = e[i - 1]; pk0[u] = key ? key[i - 1] : 0u; }
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
+            // (every lane takes part in the lane shifts, also the ones past the end)
+            u32 pk = wave_prev32(k[u]);
+            i64 pa = (i64)(((u64)wave_prev32((u32)((u64)a[u] >> 32)) << 32) | wave_prev32((u32)(u64)a[u]));
+            i64 pb = (i64)(((u64)wave_prev32((u32)((u64)b[u] >> 32)) << 32) | wave_prev32((u32)(u64)b[u]));
+            if (ln == 0) { pk = pk0[u]; pa = pa0[u]; pb = pb0[u]; }
             if (i0 + (u64)u * ST >= n) continue;
             lo_s = a[u] < lo_s ? a[u] : lo_s; hi_s = a[u] > hi_s ? a[u] : hi_s;
             lo_e = b[u] < lo_e ? b[u] : lo_e; hi_e = b[u] > hi_e ? b[u] : hi_e;
@@ -104,8 +113,8 @@ __global__ __launch_bounds__(ST) void k_range64(const u32 *__restrict__ key, con
                 if (a[u] < *(volatile long long *)&smin[k[u]]) atomicMin(&smin[k[u]], (long long)a[u]);
                 if (a[u] > *(volatile long long *)&smax[k[u]]) atomicMax(&smax[k[u]], (long long)a[u]);
             }
-            // (key,start,end) below the row before it?
-            inv |= k[u] != pk[u] ? k[u] < pk[u] : (a[u] != pa[u] ? a[u] < pa[u] : b[u] < pb[u]);
+            // (key,start,end) below the row before it?  (row 0 has none: pa = pb = INT64_MIN, pk = 0 compare as "not below")
+            inv |= k[u] != pk ? k[u] < pk : (a[u] != pa ? a[u] < pa : b[u] < pb);
         }
     }
 #pragma unroll
@@ -316,7 +325,7 @@ ivx_status sort64(ivx_ctx *ctx, int slot_a, int slot_b, const u32 *key, const i6
         IVX_TRY(ctx->get_scratch(slot_b + 2, ((size_t)nkeys + 1) * sizeof(u64), (void **)&base));
         hipLaunchKernelGGL(k_init_keyrange64, dim3((nkeys + ST - 1) / ST), dim3(ST), 0, st, (i64 *)kmin, (i64 *)kmax, nkeys);
     }
-    hipLaunchKernelGGL(k_range64, dim3(ivx_stream_grid(n, ST * 16, 4096)), dim3(ST), try_lin ? (size_t)nkeys * 16 : 0, st, key, s, e, n, nkeys, d_rng, flags,
+    hipLaunchKernelGGL(k_range64, dim3(ivx_stream_grid(n, ST * 4, 2048)), dim3(ST), try_lin ? (size_t)nkeys * 16 : 0, st, key, s, e, n, nkeys, d_rng, flags,
                        kmin, kmax);
     if (try_lin) hipLaunchKernelGGL(k_lin_layout64, dim3(1), dim3(1024), 0, st, (const long long *)kmin, (const long long *)kmax, nkeys, base, d_lin);
     IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 24, d_rng, 8 * sizeof(u64), hipMemcpyDeviceToHost, st));   // Range64 (6 words), d_lin (2 words)
