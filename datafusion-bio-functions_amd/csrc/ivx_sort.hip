@@ -273,9 +273,22 @@ __global__ __launch_bounds__(RS_T) void k_scatter(CPtrs<NW> in, Ptrs<NW> out, u6
     }
 }
 
+// records per workgroup: RS_CHUNK for big inputs; smaller ones are spread over ~4 workgroups per CU's worth of chunks
+// (whole tiles), or a 1 M-row sort would run on 16 of the 256 CUs
+template <int NW>
+u64 sort_chunk(u64 n)
+{
+    u64 chunk = RS_CHUNK;
+    const u64 tile = (u64)Tile<NW>::N;
+    const u64 want = (n + 1023) / 1024;                                // ~1024 chunks
+    const u64 c = (want + tile - 1) / tile * tile;
+    if (c < chunk) chunk = c < tile ? tile : c;
+    return chunk;
+}
+
 template <int NW, bool PAY>
 ivx_status sort_impl(ivx_ctx *ctx, u64 *const *a, u64 *const *b, u64 n, const ivx_sort_field *fields, int nfields, int *in_b, bool tight,
-                     u32 *const *pay)
+                     u32 *const *pay, bool first_hist)
 {
     *in_b = 0;
     if (n <= 1) return IVX_OK;
@@ -294,15 +307,7 @@ ivx_status sort_impl(ivx_ctx *ctx, u64 *const *a, u64 *const *b, u64 n, const iv
         IVX_HIP(ctx, hipStreamSynchronize(st));
     }
 
-    // records per workgroup: RS_CHUNK for big inputs; smaller ones are spread over ~4 workgroups per CU's worth of chunks
-    // (whole tiles), or a 1 M-row sort would run on 16 of the 256 CUs
-    u64 chunk = RS_CHUNK;
-    {
-        const u64 tile = (u64)Tile<NW>::N;
-        const u64 want = (n + 1023) / 1024;                            // ~1024 chunks
-        const u64 c = (want + tile - 1) / tile * tile;
-        if (c < chunk) chunk = c < tile ? tile : c;
-    }
+    const u64 chunk = sort_chunk<NW>(n);
     const u32 nblk = (u32)((n + chunk - 1) / chunk);
     u32 *hist;
     IVX_TRY(ctx->get_scratch(WS_SORTHIST, (size_t)256 * nblk * sizeof(u32), (void **)&hist));
@@ -318,7 +323,8 @@ ivx_status sort_impl(ivx_ctx *ctx, u64 *const *a, u64 *const *b, u64 n, const iv
             CPtrs<NW> ci; Ptrs<NW> po;
             for (int q = 0; q < NW; q++) { ci.w[q] = src[q]; po.w[q] = dst[q]; }
             ci.p = PAY ? pay[cur] : nullptr; po.p = PAY ? pay[cur ^ 1] : nullptr;
-            hipLaunchKernelGGL(k_hist, dim3(nblk), dim3(RS_HT), 0, st, (const u64 *)src[fields[f].word], n, sh, nblk, hist, (u32)chunk);
+            if (!first_hist) hipLaunchKernelGGL(k_hist, dim3(nblk), dim3(RS_HT), 0, st, (const u64 *)src[fields[f].word], n, sh, nblk, hist, (u32)chunk);
+            first_hist = false;
             IVX_TRY(ivx_scan_exclusive_u32(ctx, hist, (u64)256 * nblk));
             hipLaunchKernelGGL((k_scatter<NW, PAY>), dim3(nblk), dim3(RS_T), 0, st, ci, po, n, fields[f].word, sh, nblk, (const u32 *)hist, (u32)chunk);
             cur ^= 1;
@@ -331,14 +337,21 @@ ivx_status sort_impl(ivx_ctx *ctx, u64 *const *a, u64 *const *b, u64 n, const iv
 
 }  // namespace
 
+void ivx_sort_geometry1(u64 n, u64 *chunk, u32 *nblk)
+{
+    *chunk = sort_chunk<1>(n);
+    *nblk = (u32)((n + *chunk - 1) / *chunk);
+}
+
 ivx_status ivx_radix_sort(ivx_ctx *ctx, int nw, u64 *const *a, u64 *const *b, u64 n,
-                          const ivx_sort_field *fields, int nfields, int *in_b, bool tight, u32 *const *pay)
+                          const ivx_sort_field *fields, int nfields, int *in_b, bool tight, u32 *const *pay, bool first_hist)
 {
     if (pay && nw != 1) return ctx->fail(IVX_ERR_INVALID, "sort: a 32-bit payload goes with one-word records");
+    if (first_hist && (nw != 1 || !tight)) return ctx->fail(IVX_ERR_INVALID, "sort: a prepared first histogram goes with tight one-word sorts");
     switch (nw) {
-    case 1: return pay ? sort_impl<1, true>(ctx, a, b, n, fields, nfields, in_b, tight, pay) : sort_impl<1, false>(ctx, a, b, n, fields, nfields, in_b, tight, pay);
-    case 2: return sort_impl<2, false>(ctx, a, b, n, fields, nfields, in_b, tight, pay);
-    case 3: return sort_impl<3, false>(ctx, a, b, n, fields, nfields, in_b, tight, pay);
+    case 1: return pay ? sort_impl<1, true>(ctx, a, b, n, fields, nfields, in_b, tight, pay, first_hist) : sort_impl<1, false>(ctx, a, b, n, fields, nfields, in_b, tight, pay, first_hist);
+    case 2: return sort_impl<2, false>(ctx, a, b, n, fields, nfields, in_b, tight, pay, false);
+    case 3: return sort_impl<3, false>(ctx, a, b, n, fields, nfields, in_b, tight, pay, false);
     default: return ctx->fail(IVX_ERR_INVALID, "sort: unsupported record width");
     }
 }

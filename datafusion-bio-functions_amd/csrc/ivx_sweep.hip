@@ -199,6 +199,53 @@ __global__ __launch_bounds__(ST) void k_pack1(const u32 *__restrict__ key, const
     if (w1) w1[i] = (u32)i;                                             // the row id rides along as a 32-bit payload (12-byte records); callers
 }                                                                       // that do not ask for row ids sort the 8-byte words alone
 
+// k_pack1 for a sort that follows at once: one workgroup per sort workgroup (ivx_sort_geometry1), which also counts the digits
+// of the sort's first pass -- bits [shift, shift + 8) -- into hist[digit * nblk + block] as k_hist would: the words are not read
+// a second time for that (1.6 GB of a 200 M-row sort)
+__global__ __launch_bounds__(ST) void k_pack1h(const u32 *__restrict__ key, const i64 *__restrict__ s, const i64 *__restrict__ e,
+                                               u64 n, Pack64 p, u64 *w0, u32 *w1, int shift, u32 nblk, u32 *__restrict__ hist, u32 chunk)
+{
+    __shared__ u32 cnt[ST / IVX_WAVE][256];
+    for (int i = threadIdx.x; i < (ST / IVX_WAVE) * 256; i += ST) (&cnt[0][0])[i] = 0;
+    __syncthreads();
+    const u64 lo = (u64)blockIdx.x * chunk;
+    const u64 hi = lo + chunk < n ? lo + chunk : n;
+    const u32 wv = threadIdx.x / IVX_WAVE;
+    for (u64 i0 = lo; i0 < hi; i0 += ST * 4) {
+        u64 x[4]; bool valid[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const u64 i = i0 + (u64)u * ST + threadIdx.x;
+            valid[u] = i < hi; x[u] = 0;
+            if (valid[u]) {
+                const u64 k = key ? key[i] : 0u;
+                if (p.lin) x[u] = shl64(p.base[k] + ((u64)s[i] - (u64)p.kmin[k]), p.bits_e) | ((u64)e[i] - (u64)p.min_e);
+                else x[u] = shl64(k, p.bits_s + p.bits_e) | shl64((u64)s[i] - (u64)p.min_s, p.bits_e) | ((u64)e[i] - (u64)p.min_e);
+                w0[i] = x[u];
+                if (w1) w1[i] = (u32)i;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {                                   // (as k_hist, ivx_sort.hip)
+            const u32 d = (u32)((x[u] >> shift) & 0xFF);
+            const u64 act = __ballot(valid[u]);
+            if (act == 0) continue;
+            const u32 first = (u32)__builtin_ctzll(act);
+            const u32 d0 = __shfl(d, first, IVX_WAVE);
+            if (__ballot(valid[u] && d == d0) == act) { if (lane_id() == first) cnt[wv][d0] += (u32)__popcll(act); }
+            else if (valid[u]) atomicAdd(&cnt[wv][d], 1u);
+        }
+    }
+    __syncthreads();
+    {
+        const u32 d = threadIdx.x;
+        u32 t = 0;
+#pragma unroll
+        for (int k = 0; k < ST / IVX_WAVE; k++) t += cnt[k][d];
+        hist[(u64)d * nblk + blockIdx.x] = t;
+    }
+}
+
 // FIX: the words were sorted (stably) on their bits above lo_bits only -- (key, start) -- so rows of equal (key, start)
 // sit together in input order and still have to be ordered by their low bits (end), then row.  Such runs are short
 // for genomic data (two or three rows): every row finds its own place inside its run by counting the run's rows that
@@ -383,19 +430,29 @@ ivx_status sort64(ivx_ctx *ctx, int slot_a, int slot_b, const u32 *key, const i6
         IVX_TRY(ctx->get_scratch(slot_b + 1, n * sizeof(u32), (void **)&pay[1]));
     }
     int in_b = 0;
+    // pack for a sort whose first digit starts at bit `shift`: the pack kernel leaves that pass's histograms (k_pack1h)
+    const bool pack_counts = !getenv("IVX_NO_PACK_HIST");
+    auto pack_for_sort = [&](int shift, u32 *payload) -> ivx_status {
+        if (!pack_counts) { hipLaunchKernelGGL(k_pack1, dim3(grid1(n)), dim3(ST), 0, st, key, s, e, n, p, a[0], payload); return IVX_OK; }
+        u64 chunk; u32 nblk; u32 *hist;
+        ivx_sort_geometry1(n, &chunk, &nblk);
+        IVX_TRY(ctx->get_scratch(WS_SORTHIST, (size_t)256 * nblk * sizeof(u32), (void **)&hist));
+        hipLaunchKernelGGL(k_pack1h, dim3(nblk), dim3(ST), 0, st, key, s, e, n, p, a[0], payload, shift, nblk, hist, (u32)chunk);
+        return IVX_OK;
+    };
     if (packed) {
-        hipLaunchKernelGGL(k_pack1, dim3(grid1(n)), dim3(ST), 0, st, key, s, e, n, p, a[0], (u32 *)nullptr);
-        if (!sorted_in) {
+        if (sorted_in) hipLaunchKernelGGL(k_pack1, dim3(grid1(n)), dim3(ST), 0, st, key, s, e, n, p, a[0], (u32 *)nullptr);
+        else {
             const int lo = (int)p.bits_e;
             const ivx_sort_field f[1] = {{0, lo, lo + (int)((total - p.bits_e + 7) / 8 * 8)}};
-            IVX_TRY(ivx_radix_sort(ctx, 1, a, b, n, f, 1, &in_b, true, nullptr));
+            IVX_TRY(pack_for_sort(lo, nullptr));
+            IVX_TRY(ivx_radix_sort(ctx, 1, a, b, n, f, 1, &in_b, true, nullptr, f[0].hi > f[0].lo && pack_counts));
         }
         pk->ok = true; pk->w = in_b ? b[0] : a[0]; pk->p = p;
         IVX_HIP(ctx, hipGetLastError());
         return IVX_OK;
     }
     if (nw == 1) {
-        hipLaunchKernelGGL(k_pack1, dim3(grid1(n)), dim3(ST), 0, st, key, s, e, n, p, a[0], pay[0]);
         // Few rows share a (key,start) when the rows are sparse in the coordinate space: then sort on those bits
         // only -- the end bits would be three or four more digit passes -- and order the short runs of equal
         // (key,start) afterwards (k_fix_runs).
@@ -405,7 +462,8 @@ ivx_status sort64(ivx_ctx *ctx, int slot_a, int slot_b, const u32 *key, const i6
         if (two_step) {
             const int lo = (int)p.bits_e;
             const ivx_sort_field f[1] = {{0, lo, lo + (int)((total - p.bits_e + 7) / 8 * 8)}};
-            IVX_TRY(ivx_radix_sort(ctx, 1, a, b, n, f, 1, &in_b, true, with_rows ? pay : nullptr));
+            IVX_TRY(pack_for_sort(lo, pay[0]));
+            IVX_TRY(ivx_radix_sort(ctx, 1, a, b, n, f, 1, &in_b, true, with_rows ? pay : nullptr, f[0].hi > f[0].lo && pack_counts));
             o = in_b ? b : a;
             u32 *toolong = flags + 1;                                   // (upper half of the key-flag word; zeroed by the caller)
             if (narrow && k8)
@@ -421,13 +479,14 @@ ivx_status sort64(ivx_ctx *ctx, int slot_a, int slot_b, const u32 *key, const i6
             IVX_HIP(ctx, hipStreamSynchronize(st));
             if (((const u32 *)(ctx->h_scalars + 8))[1]) {                // a long run of equal (key,start): the plain way after all
                 IVX_HIP(ctx, hipMemsetAsync(toolong, 0, sizeof(u32), st));
-                hipLaunchKernelGGL(k_pack1, dim3(grid1(n)), dim3(ST), 0, st, key, s, e, n, p, a[0], pay[0]);
+                IVX_TRY(pack_for_sort(0, pay[0]));
                 two_step = false;
             }
         }
+        else IVX_TRY(pack_for_sort(0, pay[0]));
         if (!two_step) {
             const ivx_sort_field f[1] = {{0, 0, (int)((total + 7) / 8 * 8)}};
-            IVX_TRY(ivx_radix_sort(ctx, 1, a, b, n, f, 1, &in_b, true, with_rows ? pay : nullptr));
+            IVX_TRY(ivx_radix_sort(ctx, 1, a, b, n, f, 1, &in_b, true, with_rows ? pay : nullptr, total > 0 && pack_counts));
             o = in_b ? b : a;
             if (narrow && k8)
             hipLaunchKernelGGL((k_unpack1<false, true, true>), dim3((grid1(n) + UNPACK_TILES - 1) / UNPACK_TILES), dim3(ST), 0, st, (const u64 *)o[0], (const u32 *)pay[in_b], n, p, ks, ss, es, rows,
