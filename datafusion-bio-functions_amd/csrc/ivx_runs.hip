@@ -334,7 +334,7 @@ __global__ __launch_bounds__(FT) void k_pk_max(const u64 *__restrict__ w, u64 n,
 // the runs' ends by number, per key the runs before its first and up to its last.
 struct PkCluster { u32 *rid; i64 *cstart; i64 *run_end; u32 *kfirst, *klast; };
 template <bool LIN, int MODE, bool NARROW>
-__global__ __launch_bounds__(FT, MODE == 2 ? 5 : 8) void k_pk_runs(const u64 *__restrict__ w, u64 n, Pack64 p, i64 d, int strict, const u64 *__restrict__ pre1,
+__global__ __launch_bounds__(FT, MODE == 0 ? 8 : 5) void k_pk_runs(const u64 *__restrict__ w, u64 n, Pack64 p, i64 d, int strict, const u64 *__restrict__ pre1,
                                                   u64 *__restrict__ agg2, const u64 *__restrict__ pre2, ivx_runs_out out, PkCluster cl, u64 *d_m)
 {
     constexpr bool EMIT = MODE != 0;
