@@ -636,13 +636,31 @@ struct SubLds {
     __device__ __forceinline__ i64 Pm(u32 i) const { return pm[ri_(i)]; }
 };
 
-template <class A>
+// WF: every right row has start <= end (k_range64 says so).  Then the gap heads are the merged runs of the rights, the right_cursor
+// can never be behind the first head above ls (that head's own row ends beyond ls), and the walk's last right with rs <= le lies in
+// the run of the last head with rs <= le, whose final end is either the cursor or beyond le: TWO searches and one lookup instead of
+// five partition points.
+template <class A, bool WF>
 __device__ __forceinline__ SubPlan plan_row(u32 k, i64 ls, i64 le, int strict, const A &a, u32 nh, u32 nr, u32 ha, u32 hb)
 {
     SubPlan p;
     const bool incl = !strict;
     // heads with rs <= ls never emit
     const u32 h_ls = bisect(ha, hb, [&](u32 i) { const u32 mk = a.Hk(i); if (mk != k) return mk < k; return a.Hrs(i) <= ls; });
+    if (WF) {
+        p.h_lo = h_ls;
+        p.h_hi = rank_near_up(h_ls, nh, [&](u32 i) { const u32 mk = a.Hk(i); if (mk != k) return mk < k; const i64 mv = a.Hrs(i); return incl ? (mv <= le) : (mv < le); });
+        if (p.h_hi < p.h_lo) p.h_hi = p.h_lo;
+        i64 cursor = ls;
+        if (p.h_hi > 0 && a.Hk(p.h_hi - 1) == k) {
+            const u32 jl = (p.h_hi < nh ? a.Hj(p.h_hi) : nr) - 1u;      // the last right of that head's run
+            const i64 pm = a.Pm(jl);
+            if (pm > cursor) cursor = pm;
+        }
+        p.tail_from = cursor;
+        p.has_tail = cursor < le ? 1u : 0u;
+        return p;
+    }
     // right_cursor (subtract.rs:401-412): first right whose running max end reaches ls.  Everything before the
     // last head at or below ls ends below that head's start, so the search starts there; it normally ends
     // before the next head (checked, not assumed: rights with end < start break it)
@@ -688,7 +706,7 @@ __global__ __launch_bounds__(ST) void k_sub_brackets(const u32 *__restrict__ lk,
 __global__ __launch_bounds__(ST) void k_sub_count(const u32 *__restrict__ lk, const i64 *__restrict__ lsv, const i64 *__restrict__ lev, u64 nl,
                                                   int strict, const u32 *hk, const i64 *hrs, const u32 *hj, u32 nh,
                                                   const u32 *rk, const i64 *rs, const SegMax64 *sm, u32 nr, u64 *cnt,
-                                                  u32 *__restrict__ plan_hlo, i64 *__restrict__ plan_tail, const u32 *__restrict__ brk)
+                                                  u32 *__restrict__ plan_hlo, i64 *__restrict__ plan_tail, const u32 *__restrict__ brk, int wf)
 {
     __shared__ u32 s_h[2], s_win[4];
     __shared__ u32 l_hk[SUB_HW], l_hj[SUB_HW], l_rk[SUB_RW];
@@ -723,10 +741,10 @@ __global__ __launch_bounds__(ST) void k_sub_count(const u32 *__restrict__ lk, co
     bool redo = !lds;
     if (lds) {
         SubLds a{l_hk, l_hrs, l_hj, l_rk, l_rs, l_pm, s_win[0], s_win[1], s_win[2], s_win[3], false};
-        p = plan_row(k, ls, le, strict, a, nh, nr, s_h[0], s_h[1]);
+        p = wf ? plan_row<SubLds, true>(k, ls, le, strict, a, nh, nr, s_h[0], s_h[1]) : plan_row<SubLds, false>(k, ls, le, strict, a, nh, nr, s_h[0], s_h[1]);
         redo = a.esc;
     }
-    if (redo) p = plan_row(k, ls, le, strict, g, nh, nr, s_h[0], s_h[1]);
+    if (redo) p = wf ? plan_row<SubGlobal, true>(k, ls, le, strict, g, nh, nr, s_h[0], s_h[1]) : plan_row<SubGlobal, false>(k, ls, le, strict, g, nh, nr, s_h[0], s_h[1]);
     cnt[i] = (u64)(p.h_hi - p.h_lo) + p.has_tail;
     // the row's plan stays for the fill pass (12 bytes per row instead of the five searches again): its first head and
     // where its tail fragment starts; the number of heads follows from the scanned counts, has_tail from tail < end
@@ -992,6 +1010,8 @@ ivx_status ivx_subtract_device(ivx_ctx *ctx, const u32 *lkey, const i64 *ls, con
     IVX_TRY(ctx->get_scratch(WS_T5, nra * sizeof(i64), (void **)&rsv));
     IVX_TRY(ctx->get_scratch(WS_T6, nra * sizeof(i64), (void **)&rev));
     IVX_TRY(sort64(ctx, WS_RA0, WS_RB0, rkey, rs, re, nr, nkeys, rk, rsv, rev, nullptr));
+    // (sort64 left the right side's Range64 in the pinned scalars: odd bit 0 = some right row has end < start)
+    const int wf = (nr == 0 || (ctx->h_scalars[29] & 1ull) == 0) && !getenv("IVX_SUB_GENERAL");
     IVX_TRY(keyflag(ctx, "subtract: key id >= n_keys"));
 
     // right side: running max of ends per key, gap heads
@@ -1026,7 +1046,7 @@ ivx_status ivx_subtract_device(ivx_ctx *ctx, const u32 *lkey, const i64 *ls, con
     hipLaunchKernelGGL(k_sub_brackets, dim3(grid1((u64)nblk_c + 1)), dim3(ST), 0, st, (const u32 *)lk, (const i64 *)lsv, nl, (const u32 *)hk, (const i64 *)hrs, (u32)nh, nblk_c, brk);
     hipLaunchKernelGGL(k_sub_count, dim3(nblk_c), dim3(ST), 0, st, (const u32 *)lk, (const i64 *)lsv, (const i64 *)lev, nl, strict,
                        (const u32 *)hk, (const i64 *)hrs, (const u32 *)hj, (u32)nh, (const u32 *)rk, (const i64 *)rsv, (const SegMax64 *)sm, (u32)nr, cnt,
-                       plan_hlo, plan_tail, (const u32 *)brk);
+                       plan_hlo, plan_tail, (const u32 *)brk, wf);
     IVX_TRY(ivx_scan_exclusive_u64(ctx, cnt, nl + 1));
     IVX_HIP(ctx, hipMemcpyAsync(ctx->h_scalars + 5, cnt + nl, sizeof(u64), hipMemcpyDeviceToHost, st));
     IVX_HIP(ctx, hipStreamSynchronize(st));

@@ -550,6 +550,36 @@ def test_subtract_random(ctx, seed):
             assert len(g) == len(w) and (g == w).all()
 
 
+@pytest.mark.parametrize("shape", ["sparse", "dense", "touching", "many_keys"])
+def test_subtract_well_formed_rights_two_searches(ctx, shape):
+    """Rights with start <= end take the two-search plan (plan_row<WF>: the gap heads are the merged runs); IVX_SUB_GENERAL=1
+    is the five-point plan.  Both against the oracle: empty and duplicate lefts, rights that touch / nest / repeat, lefts
+    that reach across many runs, keys without rights."""
+    rng = np.random.default_rng(9090)
+    nl, nr = 400_000, 150_000
+    nk = {"sparse": 8, "dense": 8, "touching": 3, "many_keys": 300}[shape]
+    span = {"sparse": 40_000_000, "dense": 300_000, "touching": 200_000, "many_keys": 20_000}[shape]
+    lk = rng.integers(0, nk, nl).astype(np.uint32); rk = rng.integers(0, max(nk - 1, 1), nr).astype(np.uint32)
+    ls = rng.integers(0, span, nl).astype(np.int64); le = ls + rng.integers(0, 3000, nl)
+    rs = rng.integers(0, span, nr).astype(np.int64); re = rs + rng.integers(0, 400, nr)
+    if shape == "touching":
+        rs = (rs // 50) * 50; re = rs + 50 * rng.integers(0, 4, nr)      # rights on a lattice: touching, nested, equal, empty
+        ls = (ls // 25) * 25; le = ls + 25 * rng.integers(0, 9, nl)
+    le[::37] = ls[::37]; ls[::11] = ls[1::11][: len(ls[::11])]; le[::11] = np.maximum(le[::11], ls[::11])
+    le[::501] = le[::501] + 10 * span                                     # a few lefts across everything
+    for strict in (False, True):
+        want = orc.subtract(lk, ls, le, rk, rs, re, strict=strict)
+        for env in ({}, {"IVX_SUB_GENERAL": "1"}):
+            os.environ.update(env)
+            try:
+                got = ctx.subtract(lk, ls, le, rk, rs, re, n_keys=nk, strict=strict)
+            finally:
+                for v in env:
+                    os.environ.pop(v, None)
+            for g, w in zip(got, want):
+                assert len(g) == len(w) and (g == w).all(), (shape, strict, env)
+
+
 @pytest.mark.parametrize("device", [False, True])
 def test_subtract_sizing_then_fill_plan(ctx, device):
     """The fill call that follows a sizing call reuses the sizing call's sorted sides; a one-call fill and a
