@@ -1,4 +1,6 @@
-// ivx_runs.hpp -- the interval-merge sweep as parallel scans (shared by merge() and coverage()).
+// ivx_runs.hpp -- the interval-merge sweep as parallel scans (merge, complement, cluster).  Two forms: the general one below
+// over sorted columns (any input), and the sweep over the sort's packed words for well-formed rows (ivx_merge_runs_packed /
+// ivx_cluster_rows_packed; ivx_runs.hip says why that one may ignore the order of equal starts and needs only a maximum).
 //
 // The reference walks the sorted rows of a contig with one running state
 // (cur_start, cur_end, cur_count): merge.rs:286-311 and merge_intervals,
