@@ -257,13 +257,14 @@ namespace {
 // With V = (key + 1) << bits_e | (end - min_e) the segmented running maximum is a plain one (a later key's V beats every
 // earlier one).  Three kernels over tiles of 4096 words with two scans of one word per tile between them:
 //   k_pk_max    the tile's largest V (only rows of the tile's last key can hold it: striped loads, no per-row key lookup)
-//   k_pk_runs<false>  V-maximum before the tile -> run heads -> (heads, latest head) of the tile
-//   k_pk_runs<true>   the same again, and every head closes the run before it (it holds cur_end before itself = that run's
+//   k_pk_runs<0>  V-maximum before the tile -> run heads -> (heads, latest head) of the tile
+//   k_pk_runs<1>  the same again, and every head closes the run before it (it holds cur_end before itself = that run's
 //               end, and the previous head's row number) and opens its own; row n - 1 closes the last run.
+//   k_pk_runs<2>  cluster(): instead of emitting runs, every row's run number and run start (+ k_pk_cluster_fin)
 // A thread takes 8 CONSECUTIVE words (coalesced loads, turned through LDS per wavefront): the key of a word's linearised
 // (key, start) is then a lookup for the first word and a compare for the others.
 // (A single kernel with both scans chained through per-tile status words -- decoupled look-back -- was built first: 1.66 ms
-// for 200 M rows against [see DESIGN.md] for these three; its tiles wait on each other twice and it has to spin.)
+// for 200 M rows against 1.2 ms for these three; its tiles wait on each other twice and it has to spin.  DESIGN.md section 3.)
 constexpr int FT = 512, FI = 8, FTILE = FT * FI, FWV = FT / IVX_WAVE;
 
 struct MaxPayOp {                                  // u64 maximum
