@@ -462,6 +462,14 @@ def main():
                     m = int(out[0].numel()); del out
                     cpu = cpu_fig(lambda: orc.merge(hk, hs, he), ns, f"first {ns} rows (sort + sweep)", 1)
                     entry(f"merge_200M_{tag}", tm, km, ALG["merge"](n, 0, m), n, {"out_rows": m}, cpu)
+                    if tag == "sparse":
+                        # the same rows coordinate-sorted (the usual state of BED / VCF-derived tables): no sort pass at all
+                        o = torch.argsort((k.to(torch.int64) << 40) | s64)
+                        k2, s2, e2 = k[o].contiguous(), s64[o].contiguous(), e64[o].contiguous()
+                        del o
+                        tm, km, out = timed(lambda: ctx.merge(k2, s2, e2, n_keys=24), reps=4)
+                        m2 = int(out[0].numel()); del out, k2, s2, e2
+                        entry("merge_200M_sparse_sorted_input", tm, km, ALG["merge"](n, 0, m2), n, {"out_rows": m2, "what": "the sparse rows in (contig, start) order"})
                 if "subtract" in which and tag == "sparse":
                     nr = n // 10
                     rk, rs64, re64 = half_open64(*synth.gen_torch(nr, 8, 24, 0x5EED0009, dev))

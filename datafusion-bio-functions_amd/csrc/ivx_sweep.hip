@@ -61,7 +61,8 @@ __global__ __launch_bounds__(ST) void k_unpack64(const u64 *__restrict__ w0, con
 // coordinates always do -- the sort key is ONE word and the record 16 bytes instead of 24, with fewer
 // radix digits in total
 struct Range64 { long long min_s, max_s, min_e, max_e; unsigned long long unsorted, odd; };   // unsorted: some row sorts before its predecessor;
-                                                                                                // odd: bit 0 some end < start, bit 1 some end == start
+                                                                                                // odd: bit 0 some end < start, bit 1 some end == start,
+                                                                                                // bit 2 some row's (key, start) below its predecessor's
 
 // kmin / kmax (nullable; nkeys <= LIN_KEYS): also every key's own range of starts, for the linearised sort word below --
 // privatised in LDS, and a bound is touched by an atomic only when a row moves it (a plain read comes first)
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(ST) void k_range64(const u32 *__restrict__ key, con
         __syncthreads();
     }
     i64 lo_s = INT64_MAX, hi_s = INT64_MIN, lo_e = INT64_MAX, hi_e = INT64_MIN;
-    bool bad = false, inv = false, mal = false, emp = false;
+    bool bad = false, inv = false, inv2 = false, mal = false, emp = false;
     constexpr int U = 4;                                                // rows per thread in flight (their loads depend on nothing)
     const u32 ln = lane_id();
     for (u64 i0 = (u64)blockIdx.x * (ST * U) + threadIdx.x; i0 - threadIdx.x < n; i0 += (u64)gridDim.x * (ST * U)) {
@@ -115,6 +116,7 @@ __global__ __launch_bounds__(ST) void k_range64(const u32 *__restrict__ key, con
             }
             // (key,start,end) below the row before it?  (row 0 has none: pa = pb = INT64_MIN, pk = 0 compare as "not below")
             inv |= k[u] != pk ? k[u] < pk : (a[u] != pa ? a[u] < pa : b[u] < pb);
+            inv2 |= k[u] != pk ? k[u] < pk : a[u] < pa;
         }
     }
 #pragma unroll
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(ST) void k_range64(const u32 *__restrict__ key, con
     if (bad) flags[0] = 1;
     if (inv) out->unsorted = 1;
     {
-        const unsigned long long o = (__ballot(mal) ? 1ull : 0ull) | (__ballot(emp) ? 2ull : 0ull);
+        const unsigned long long o = (__ballot(mal) ? 1ull : 0ull) | (__ballot(emp) ? 2ull : 0ull) | (__ballot(inv2) ? 4ull : 0ull);
         if (o && lane_id() == 0) atomicOr(&out->odd, o);
     }
     __syncthreads();
@@ -380,7 +382,8 @@ ivx_status sort64(ivx_ctx *ctx, int slot_a, int slot_b, const u32 *key, const i6
     const Range64 r = *(const Range64 *)(ctx->h_scalars + 24);
     // coordinate-sorted input (the usual state of BED / VCF / BAM-derived tables): nothing to sort, and equal
     // rows already are in ascending row order
-    const bool sorted_in = !r.unsorted && !getenv("IVX_FORCE_SORT");
+    // (the sweep over packed words asks less: (key, start) order -- coordinate-sorted files rarely order the ends of equal starts)
+    bool sorted_in = !r.unsorted && !getenv("IVX_FORCE_SORT");
     Pack64 p;
     p.min_s = r.min_s; p.min_e = r.min_e; p.base = base; p.kmin = kmin; p.lin = 0; p.nkeys = nkeys; p.pad = 0;
     {
@@ -405,6 +408,7 @@ ivx_status sort64(ivx_ctx *ctx, int slot_a, int slot_b, const u32 *key, const i6
     // (a caller that needs the unpacked rows AND sweeps over the packed words -- cluster -- gets both: pk->w stays valid)
     const bool also = nw == 1 && pk && !sw && !getenv("IVX_NO_FUSED_SWEEP") &&
                       ivx_merge_packed_ok(p, n, nkeys, pk->d, pk->strict, (r.odd & 1) != 0, (r.odd & 2) != 0);
+    if (packed && (r.odd & 4) == 0 && !getenv("IVX_FORCE_SORT")) sorted_in = true;
     if (sorted_in && !packed) {
         hipLaunchKernelGGL(k_copy_sorted, dim3(grid1(n)), dim3(ST), 0, st, key, s, e, n, ks, ss, es, rows);
         if (also) {
