@@ -461,13 +461,19 @@ ivx_status sort64(ivx_ctx *ctx, int slot_a, int slot_b, const u32 *key, const i6
         // only -- the end bits would be three or four more digit passes -- and order the short runs of equal
         // (key,start) afterwards (k_fix_runs).
         const double per_pos = (double)n / positions;
-        bool two_step = p.bits_e >= 8 && n >= (1u << 16) && per_pos <= 0.25 && !getenv("IVX_FORCE_SORT");
+        // rows already in (key, start) order -- coordinate-sorted files that do not order the ends of equal starts: the words
+        // need no sort at all, only the repair of their equal-start runs
+        const bool ks_sorted = (r.odd & 4) == 0 && !getenv("IVX_FORCE_SORT");
+        bool two_step = ks_sorted || (p.bits_e >= 8 && n >= (1u << 16) && per_pos <= 0.25 && !getenv("IVX_FORCE_SORT"));
         u64 *const *o = a;
         if (two_step) {
             const int lo = (int)p.bits_e;
             const ivx_sort_field f[1] = {{0, lo, lo + (int)((total - p.bits_e + 7) / 8 * 8)}};
-            IVX_TRY(pack_for_sort(lo, pay[0]));
-            IVX_TRY(ivx_radix_sort(ctx, 1, a, b, n, f, 1, &in_b, true, with_rows ? pay : nullptr, f[0].hi > f[0].lo && pack_counts));
+            if (ks_sorted) hipLaunchKernelGGL(k_pack1, dim3(grid1(n)), dim3(ST), 0, st, key, s, e, n, p, a[0], pay[0]);
+            else {
+                IVX_TRY(pack_for_sort(lo, pay[0]));
+                IVX_TRY(ivx_radix_sort(ctx, 1, a, b, n, f, 1, &in_b, true, with_rows ? pay : nullptr, f[0].hi > f[0].lo && pack_counts));
+            }
             o = in_b ? b : a;
             u32 *toolong = flags + 1;                                   // (upper half of the key-flag word; zeroed by the caller)
             if (narrow && k8)

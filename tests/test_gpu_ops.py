@@ -460,7 +460,7 @@ def test_sweeps_on_coordinate_sorted_input(ctx, variant):
             os.environ.pop("IVX_FORCE_SORT", None)
 
 
-@pytest.mark.parametrize("dups", ["few", "long_runs"])
+@pytest.mark.parametrize("dups", ["few", "long_runs", "long_runs_in_start_order"])
 def test_sweeps_sort_on_key_start_then_fix_runs(ctx, dups):
     """Unsorted sparse input is radix-sorted on (key,start) only and runs of equal (key,start) are ordered by
     (end,row) afterwards; runs longer than 64 rows send the call back to the full-width sort."""
@@ -474,6 +474,8 @@ def test_sweeps_sort_on_key_start_then_fix_runs(ctx, dups):
         s = rng.choice(rng.integers(0, 2_000_000_000, 40), n).astype(np.int64)   # 40 distinct starts: runs of thousands
     e = s + rng.integers(1, 5000, n)
     e[::11] = e[1::11][: len(e[::11])]                                  # equal (start,end) too: the row index decides
+    if dups == "long_runs_in_start_order":                              # (key, start) order, ends unordered: no radix pass, the repair
+        o = np.lexsort((s, k)); k, s, e = k[o].copy(), s[o].copy(), e[o].copy()   # of the runs gives up on their length, then the full sort
     rk, rs, re = synth(30_000, 413, nkeys=6, mean_len=150, span=3_000_000, dtype=np.int64)
     re += 1
     for strict in (False, True):
