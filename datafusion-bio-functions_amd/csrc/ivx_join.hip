@@ -567,7 +567,6 @@ ivx_status ivx_join_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32
     errflag = (u32 *)(ctx->d_scalars + 8);
     u32 *lenhist = (u32 *)(ctx->d_scalars + 32);                        // 33 counters
 
-    IVX_HIP(ctx, hipMemsetAsync(binstart, 0, (maxcells + 1) * sizeof(u32), st));
     const ivx_zero_ranges zr{{errflag, lenhist, hdr}, {1u, 34u, (u32)HDR_WORDS}};     // cleared by the key-statistics' first kernel
     // IVX_FILTER=0: no occupancy bitmap; =force: whenever it fits (tests); default: when it would reject most probe rows
     const char *fenv = getenv("IVX_FILTER");
@@ -592,6 +591,7 @@ ivx_status ivx_join_build(ivx_ctx *ctx, ivx_index *ix, const u32 *key, const i32
         IVX_HIP(ctx, hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
         tail_st = ctx->aux;
     }
+    IVX_HIP(ctx, hipMemsetAsync(binstart, 0, (maxcells + 1) * sizeof(u32), tail_st));    // (8 MB per million rows: part of the tail, not of what the caller waits for)
     hipLaunchKernelGGL(k_join_count, dim3(grid), dim3(BT), 0, tail_st, key, s, e, n, nkeys, origin, lbase, hdr, binstart, cellid, rank);
     {
         const hipStream_t keep = ctx->stream;
