@@ -416,7 +416,9 @@ __global__ __launch_bounds__(PT) void k_overlap_rowval_routed(JoinIndexView ix, 
     }
 }
 
-template <int MODE>
+// PI_: probe rows per thread per tile.  A thread walks its rows one after the other (each walk is a chain of dependent index
+// reads), so a DataFusion-sized batch takes ONE row per thread -- 8192 rows are 32 workgroups and one walk of latency, not 8 and four
+template <int MODE, int PI_>
 __global__ __launch_bounds__(PT) void k_probe_overlap(JoinIndexView ix, const u32 *__restrict__ pkey,
                                                       const i32 *__restrict__ ps, const i32 *__restrict__ pe, u64 n,
                                                       u32 *__restrict__ per_row, u8 *__restrict__ exists,
@@ -427,14 +429,15 @@ __global__ __launch_bounds__(PT) void k_probe_overlap(JoinIndexView ix, const u3
     __shared__ unsigned long long s_base;
     if (gate && *gate != 0) return;                        // (routed callers: only when the probe rows were left in place)
     const u32 sh0 = ix.hdr[HDR_SH0], nlev = ix.hdr[HDR_NLEV];
-    const u64 ntiles = (n + PTILE - 1) / PTILE;
+    constexpr int PTILE_ = PT * PI_;
+    const u64 ntiles = (n + PTILE_ - 1) / PTILE_;
     u64 acc = 0;                                           // MODE COUNT / PER_ROW: pairs seen by this thread
     for (u64 tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        u32 cnt[PI], st0[PI], st1[PI];
+        u32 cnt[PI_], st0[PI_], st1[PI_];
         u32 tsum = 0;
 #pragma unroll
-        for (int it = 0; it < PI; it++) {
-            const u64 i = tile * PTILE + (u64)it * PT + threadIdx.x;
+        for (int it = 0; it < PI_; it++) {
+            const u64 i = tile * PTILE_ + (u64)it * PT + threadIdx.x;
             u32 m = 0, a0 = 0, a1 = 0;
             if (i < n) {
                 const u32 k = pkey ? pkey[i] : 0u;
@@ -459,10 +462,10 @@ __global__ __launch_bounds__(PT) void k_probe_overlap(JoinIndexView ix, const u3
         if (total && base + total <= cap) {
             u64 at = base + ex;
 #pragma unroll
-            for (int it = 0; it < PI; it++) {
+            for (int it = 0; it < PI_; it++) {
                 const u32 m = cnt[it];
                 if (m == 0) continue;
-                const u64 i = tile * PTILE + (u64)it * PT + threadIdx.x;
+                const u64 i = tile * PTILE_ + (u64)it * PT + threadIdx.x;
                 if (m <= 2) {
                     ob[at] = st0[it]; op[at] = (u32)i;
                     if (m == 2) { ob[at + 1] = st1[it]; op[at + 1] = (u32)i; }
@@ -525,8 +528,8 @@ ivx_status ivx_join_rowval_routed(ivx_ctx *ctx, const ivx_index *ix, int mode, c
     IVX_TRY(ivx_unroute_u32(ctx, R, n, vb, per_row, exists));
     // rows that came in region order were not moved: the plain kernel answers them in place (gated on the flag)
     const u32 g2 = ivx_stream_grid(n, PTILE, 256 * 8);
-    if (mode == JP_PER_ROW) hipLaunchKernelGGL(k_probe_overlap<JP_PER_ROW>, dim3(g2), dim3(PT), 0, st, ix->jv, key, s, e, n, per_row, exists, (u32 *)nullptr, (u32 *)nullptr, (u64)0, (unsigned long long *)d_total, R.unsorted);
-    else hipLaunchKernelGGL(k_probe_overlap<JP_EXISTS>, dim3(g2), dim3(PT), 0, st, ix->jv, key, s, e, n, per_row, exists, (u32 *)nullptr, (u32 *)nullptr, (u64)0, (unsigned long long *)d_total, R.unsorted);
+    if (mode == JP_PER_ROW) hipLaunchKernelGGL((k_probe_overlap<JP_PER_ROW, PI>), dim3(g2), dim3(PT), 0, st, ix->jv, key, s, e, n, per_row, exists, (u32 *)nullptr, (u32 *)nullptr, (u64)0, (unsigned long long *)d_total, R.unsorted);
+    else hipLaunchKernelGGL((k_probe_overlap<JP_EXISTS, PI>), dim3(g2), dim3(PT), 0, st, ix->jv, key, s, e, n, per_row, exists, (u32 *)nullptr, (u32 *)nullptr, (u64)0, (unsigned long long *)d_total, R.unsorted);
     IVX_HIP(ctx, hipGetLastError());
     return IVX_OK;
 }
@@ -636,22 +639,20 @@ ivx_status ivx_join_probe(ivx_ctx *ctx, const JoinIndexView &jv, int mode,
                           u32 *per_row, u8 *exists, u32 *ob, u32 *op, u64 cap, u64 *d_cursor)
 {
     if (n == 0) return IVX_OK;
-    const u32 grid = ivx_stream_grid(n, PTILE, 256 * 8);
     unsigned long long *cur = (unsigned long long *)d_cursor;
+    const bool small = n <= (1u << 18);                                // one row per thread: latency, not throughput, is what a small batch costs
+    const u32 grid = small ? (u32)((n + PT - 1) / PT) : ivx_stream_grid(n, PTILE, 256 * 8);
+#define IVX_PROBE_LAUNCH(M_) do { \
+        if (small) hipLaunchKernelGGL((k_probe_overlap<M_, 1>), dim3(grid), dim3(PT), 0, ctx->stream, jv, key, s, e, n, per_row, exists, ob, op, cap, cur, (const u32 *)nullptr); \
+        else hipLaunchKernelGGL((k_probe_overlap<M_, PI>), dim3(grid), dim3(PT), 0, ctx->stream, jv, key, s, e, n, per_row, exists, ob, op, cap, cur, (const u32 *)nullptr); \
+    } while (0)
     switch (mode) {
-    case JP_COUNT:
-        hipLaunchKernelGGL(k_probe_overlap<JP_COUNT>, dim3(grid), dim3(PT), 0, ctx->stream, jv, key, s, e, n, per_row, exists, ob, op, cap, cur, (const u32 *)nullptr);
-        break;
-    case JP_PER_ROW:
-        hipLaunchKernelGGL(k_probe_overlap<JP_PER_ROW>, dim3(grid), dim3(PT), 0, ctx->stream, jv, key, s, e, n, per_row, exists, ob, op, cap, cur, (const u32 *)nullptr);
-        break;
-    case JP_EXISTS:
-        hipLaunchKernelGGL(k_probe_overlap<JP_EXISTS>, dim3(grid), dim3(PT), 0, ctx->stream, jv, key, s, e, n, per_row, exists, ob, op, cap, cur, (const u32 *)nullptr);
-        break;
-    default:
-        hipLaunchKernelGGL(k_probe_overlap<JP_FILL>, dim3(grid), dim3(PT), 0, ctx->stream, jv, key, s, e, n, per_row, exists, ob, op, cap, cur, (const u32 *)nullptr);
-        break;
+    case JP_COUNT: IVX_PROBE_LAUNCH(JP_COUNT); break;
+    case JP_PER_ROW: IVX_PROBE_LAUNCH(JP_PER_ROW); break;
+    case JP_EXISTS: IVX_PROBE_LAUNCH(JP_EXISTS); break;
+    default: IVX_PROBE_LAUNCH(JP_FILL); break;
     }
+#undef IVX_PROBE_LAUNCH
     IVX_HIP(ctx, hipGetLastError());
     return IVX_OK;
 }

@@ -896,7 +896,7 @@ ivx_status ivx_count_probe(ivx_ctx *ctx, const ivx_index *ix, const u32 *key, co
     if (n == 0) return IVX_OK;
     if (rowval_regions_wanted(ix, n)) return ivx_rowval_probe_regions(ctx, ix->jv, ix->jv_nreg, IVX_RV_COUNT, key, s, e, n, strict, out, nullptr, ix->jv_filter, ix->jv_pk24, ix->jv_fast);
     if (rowval_routed_wanted(ix, n)) return rowval_routed(ctx, ix, false, key, s, e, n, strict, out);
-    hipLaunchKernelGGL(k_probe_count, dim3(ivx_stream_grid(n, OT * 4)), dim3(OT), 0, ctx->stream, ix->gs, ix->ge, key, s, e, n, strict, out, (const u32 *)nullptr);
+    hipLaunchKernelGGL(k_probe_count, dim3(ivx_stream_grid(n, OT)), dim3(OT), 0, ctx->stream, ix->gs, ix->ge, key, s, e, n, strict, out, (const u32 *)nullptr);
     IVX_HIP(ctx, hipGetLastError());
     return IVX_OK;
 }
@@ -906,7 +906,7 @@ ivx_status ivx_coverage_probe(ivx_ctx *ctx, const ivx_index *ix, const u32 *key,
     if (n == 0) return IVX_OK;
     if (rowval_regions_wanted(ix, n)) return ivx_rowval_probe_regions(ctx, ix->jv, ix->jv_nreg, IVX_RV_COVERAGE, key, s, e, n, strict, out, nullptr, ix->jv_filter, ix->jv_pk24, ix->jv_fast);
     if (rowval_routed_wanted(ix, n)) return rowval_routed(ctx, ix, true, key, s, e, n, strict, out);
-    hipLaunchKernelGGL(k_probe_coverage, dim3(ivx_stream_grid(n, OT * 4)), dim3(OT), 0, ctx->stream, ix->cv, key, s, e, n, strict, out, (const u32 *)nullptr);
+    hipLaunchKernelGGL(k_probe_coverage, dim3(ivx_stream_grid(n, OT)), dim3(OT), 0, ctx->stream, ix->cv, key, s, e, n, strict, out, (const u32 *)nullptr);
     IVX_HIP(ctx, hipGetLastError());
     return IVX_OK;
 }
@@ -938,7 +938,7 @@ ivx_status ivx_nearest_probe(ivx_ctx *ctx, const ivx_index *ix, const u32 *key, 
             // rows that came in region order were not moved: the plain kernel answers them in place
             hipLaunchKernelGGL(k_probe_nearest1, dim3(ivx_stream_grid(n, OT * 4)), dim3(OT), 0, st, ix->nv, key, s, e, n, strict, include_overlaps, ob, op, od, R.unsorted);
         } else if (k == 1) {
-            hipLaunchKernelGGL(k_probe_nearest1, dim3(ivx_stream_grid(n, OT * 4)), dim3(OT), 0, st, ix->nv, key, s, e, n, strict, include_overlaps, ob, op, od, (const u32 *)nullptr);
+            hipLaunchKernelGGL(k_probe_nearest1, dim3(ivx_stream_grid(n, OT)), dim3(OT), 0, st, ix->nv, key, s, e, n, strict, include_overlaps, ob, op, od, (const u32 *)nullptr);
         } else {
             u32 *cnt; u64 *offs;
             IVX_TRY(ctx->get_scratch(WS_T3, n * sizeof(u32), (void **)&cnt));
@@ -946,7 +946,7 @@ ivx_status ivx_nearest_probe(ivx_ctx *ctx, const ivx_index *ix, const u32 *key, 
             IVX_HIP(ctx, hipMemsetAsync(cnt, 0, n * sizeof(u32), st));
             hipLaunchKernelGGL(k_rows_of, dim3(grid1(n + 1)), dim3(OT), 0, st, (const u32 *)cnt, n, offs);
             IVX_TRY(ivx_scan_exclusive_u64(ctx, offs, n + 1));
-            hipLaunchKernelGGL(k_nearest_emit, dim3(ivx_stream_grid(n, OT * 4)), dim3(OT), 0, st, n, 1u, (const u32 *)cnt, (const i64 *)nullptr, (const u32 *)cnt, (const u64 *)offs, cap, ob, op, od);
+            hipLaunchKernelGGL(k_nearest_emit, dim3(ivx_stream_grid(n, OT)), dim3(OT), 0, st, n, 1u, (const u32 *)cnt, (const i64 *)nullptr, (const u32 *)cnt, (const u64 *)offs, cap, ob, op, od);
         }
         IVX_HIP(ctx, hipGetLastError());
         *rows = n;
