@@ -144,7 +144,7 @@ __global__ __launch_bounds__(RS_T) void k_scatter(CPtrs<NW> in, Ptrs<NW> out, u6
     const u64 hi = lo + chunk < n ? lo + chunk : n;
 
     // 8-byte records: the next tile's records are loaded while this one goes through LDS (registers allow it)
-    // (not with the 32-bit payload: 24 more registers per thread spilled 156 bytes per lane and bought nothing, 0.85 -> 0.79 ms)
+    // (not with the 32-bit payload: 24 more registers per thread spilled 156 bytes per lane and cost 7 %)
     constexpr bool PREFETCH = NW == 1 && !PAY;
     u64 nxt[PREFETCH ? RS_I : 1][NW];
     u32 nxp[PREFETCH && PAY ? RS_I : 1];
