@@ -33,6 +33,7 @@ __device__ __forceinline__ u32 wave_incl_sum32(u32 v)
     return v;
 }
 __device__ __forceinline__ u32 wave_prev32(u32 v) { return dpp0<0x138, 0xf>(v); }      // wave_shr:1 (lane 0: 0)
+__device__ __forceinline__ u32 wave_next32(u32 v) { return dpp0<0x130, 0xf>(v); }      // wave_shl:1 (lane 63: 0)
 
 template <typename T>
 __device__ __forceinline__ T wave_incl_scan(T v)

@@ -170,13 +170,19 @@ __global__ __launch_bounds__(GT) void k_grid_bounds(const u32 *__restrict__ key,
     for (u64 i = (u64)blockIdx.x * GT + threadIdx.x; i < nround; i += (u64)gridDim.x * GT) {
         u32 lo = 1, hi = 0, val = 0;                                    // cells [lo, hi] <- val
         const u32 k = i < n ? (key ? key[i] : 0u) : 0xFFFFFFFFu;
-        if (k < nkeys) {
-            const u32 c = kbase[k] + ((u32)((i64)v[i * vs] - (i64)origin[k]) >> sh);
-            u32 cn = ncells;
+        // the row's own cell; the NEXT row's cell comes from the lane above (every lane of the wavefront is in the loop),
+        // only the last lane looks its successor up itself: half the loads and cell computations
+        const u32 myc = k < nkeys ? kbase[k] + ((u32)((i64)v[i * vs] - (i64)origin[k]) >> sh) : ncells;
+        u32 cn = wave_next32(myc);
+        if (lane_id() == IVX_WAVE - 1) {
+            cn = ncells;
             if (i + 1 < n) {
                 const u32 k2 = key ? key[i + 1] : 0u;
                 if (k2 < nkeys) cn = kbase[k2] + ((u32)((i64)v[(i + 1) * vs] - (i64)origin[k2]) >> sh);
             }
+        }
+        if (k < nkeys) {
+            const u32 c = myc;
             if (i == 0) { for (u32 x = 0; x <= c; x++) binstart[x] = 0; }       // (a key's first cell holds its first row: c is small)
             lo = c + 1; hi = cn; val = (u32)(i + 1);
         }
