@@ -486,7 +486,7 @@ def test_sweeps_sort_on_key_start_then_fix_runs(ctx, dups):
             assert len(g) == len(w) and (g == w).all()
 
 
-@pytest.mark.parametrize("shape", ["sparse", "dense", "one_key", "many_keys", "empties"])
+@pytest.mark.parametrize("shape", ["sparse", "dense", "one_key", "many_keys", "empties", "scaffolds"])
 def test_merge_one_pass_sweep(ctx, shape):
     """Well-formed rows go through the one-pass sweep over the sort's packed words (ivx_runs.hip k_merge_fused: several
     hundred tiles, look-back windows beyond 64 tiles, runs and keys that straddle tiles); IVX_NO_FUSED_SWEEP=1 is the
@@ -494,8 +494,9 @@ def test_merge_one_pass_sweep(ctx, shape):
     order inside a start matters) must fall back by itself."""
     rng = np.random.default_rng(4242)
     n = 1_500_000
-    nk = {"sparse": 24, "dense": 24, "one_key": 1, "many_keys": 700, "empties": 5}[shape]
-    span = {"sparse": 200_000_000, "dense": 300_000, "one_key": 50_000_000, "many_keys": 40_000, "empties": 3_000_000}[shape]
+    # (scaffolds: more keys than the linearised sort word's table takes -- the key keeps its own bits in the word)
+    nk = {"sparse": 24, "dense": 24, "one_key": 1, "many_keys": 700, "empties": 5, "scaffolds": 5000}[shape]
+    span = {"sparse": 200_000_000, "dense": 300_000, "one_key": 50_000_000, "many_keys": 40_000, "empties": 3_000_000, "scaffolds": 150_000}[shape]
     k = rng.integers(0, nk, n).astype(np.uint32)
     if shape == "many_keys":
         k[k % 7 == 3] = 5                                              # keys without rows, one heavy key
