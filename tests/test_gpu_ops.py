@@ -694,15 +694,15 @@ def test_cluster_random(ctx, seed):
                       orc.cluster(k, s, e, min_dist=md, strict=strict, n_keys=nk + 2))
 
 
-@pytest.mark.parametrize("shape", ["sparse", "dense", "many_keys", "sorted"])
+@pytest.mark.parametrize("shape", ["sparse", "dense", "many_keys", "sorted", "scaffolds"])
 def test_cluster_over_packed_words(ctx, shape):
     """Well-formed rows: cluster() sweeps over the sort's packed words (k_pk_runs<2> + k_pk_cluster_fin); IVX_NO_FUSED_SWEEP=1
     is the scan over unpacked rows.  Several hundred tiles, keys that open inside tiles and wavefronts, equal starts, ids with
     and without a per-key base, the per-key counts alone."""
     rng = np.random.default_rng(777)
     n = 1_200_000
-    nk = {"sparse": 24, "dense": 24, "many_keys": 500, "sorted": 9}[shape]
-    span = {"sparse": 150_000_000, "dense": 200_000, "many_keys": 30_000, "sorted": 5_000_000}[shape]
+    nk = {"sparse": 24, "dense": 24, "many_keys": 500, "sorted": 9, "scaffolds": 4000}[shape]
+    span = {"sparse": 150_000_000, "dense": 200_000, "many_keys": 30_000, "sorted": 5_000_000, "scaffolds": 100_000}[shape]
     k = rng.integers(0, nk, n).astype(np.uint32)
     if shape == "many_keys":
         k[k % 5 == 2] = 7
