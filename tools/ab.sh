@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B two builds of libivx_hip.so inside ONE gpurun call (boxes differ by >10 %): tools/ab.sh libA.so libB.so [env...]
-R=$GRAFT_REPO_ROOT; L=$R/datafusion-bio-functions_amd/lib
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; L=$R/datafusion-bio-functions_amd/lib
 A=$1; B=$2; shift 2
 cp $L/libivx_hip.so $L/.orig.so
 for round in 1 2; do

@@ -1,6 +1,6 @@
 #!/bin/bash
 # count-probe skeleton vs batch size inside one session: tools/ab_count.sh "libs" "dbg bits"
-R=$GRAFT_REPO_ROOT; L=$R/datafusion-bio-functions_amd/lib
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; L=$R/datafusion-bio-functions_amd/lib
 cp $L/libivx_hip.so $L/.orig.so
 for v in $1; do
   cp $L/$v $L/libivx_hip.so

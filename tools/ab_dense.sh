@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B library builds across build-side shapes inside one session: tools/ab_dense.sh "libs"
-R=$GRAFT_REPO_ROOT; L=$R/datafusion-bio-functions_amd/lib
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; L=$R/datafusion-bio-functions_amd/lib
 cp $L/libivx_hip.so $L/.orig.so
 for v in $1; do
   cp $L/$v $L/libivx_hip.so

@@ -1,6 +1,6 @@
 #!/bin/bash
 # headline probe, libs alternated: tools/ab_head.sh "libA.so libB.so"
-R=$GRAFT_REPO_ROOT; L=$R/datafusion-bio-functions_amd/lib
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; L=$R/datafusion-bio-functions_amd/lib
 cp $L/libivx_hip.so $L/.orig.so
 for round in 1 2 3; do
   for v in $1; do

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B library builds over several build-side shapes (kernel_ms of count and fill): tools/ab_layout.sh "libA.so libB.so" [configs...]
-R=$GRAFT_REPO_ROOT; L=$R/datafusion-bio-functions_amd/lib
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; L=$R/datafusion-bio-functions_amd/lib
 LIBS=$1; shift
 CFGS=("$@")
 if [ ${#CFGS[@]} -eq 0 ]; then CFGS=("NP=100000000 NB=1000000 BMEAN=1000" "NP=100000000 NB=10000000 BMEAN=1000" "NP=50000000 NB=50000000 BMEAN=1000" "NP=100000000 NB=1000000 BMEAN=20000" "NP=100000000 NB=200000 BMEAN=200000" "NP=20000000 NB=5000000 BMEAN=300"); fi

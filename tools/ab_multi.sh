@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B several library builds in one session: tools/ab_multi.sh "lib1.so lib2.so ..." env...
-R=$GRAFT_REPO_ROOT; L=$R/datafusion-bio-functions_amd/lib
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; L=$R/datafusion-bio-functions_amd/lib
 LIBS=$1; shift
 cp $L/libivx_hip.so $L/.orig.so
 for round in 1 2; do

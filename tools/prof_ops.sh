@@ -1,7 +1,7 @@
 #!/bin/bash
 # kernel-trace stats of tools/ops_perf.py: tools/prof_ops.sh <tag> OPS=merge [env...]
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; TAG=$1; shift
 export "$@"
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/po_$TAG -- python3 $R/tools/ops_perf.py > $R/gpurun_out/po_$TAG.log 2>&1
 python3 - <<PY

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools/prof_stats.sh <tag> <env assignments...> ; kernel-trace stats of tools/probe_only.py
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; TAG=$1; shift
 export "$@"
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/st_$TAG -- python3 $R/tools/probe_only.py > $R/gpurun_out/st_$TAG.log 2>&1
 python3 - <<PY
