@@ -5,6 +5,12 @@
 
 __device__ __forceinline__ u32 lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
+// base + number of set bits of a 64-bit ballot below this lane (the bit counter takes an addend: no separate add)
+__device__ __forceinline__ u32 mask_rank_from(u64 mask, u32 base)
+{
+    return __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, base));
+}
+
 // number of set bits of a 64-bit ballot below this lane
 __device__ __forceinline__ u32 mask_rank(u64 mask)
 {

@@ -1370,9 +1370,12 @@ __global__ __launch_bounds__(RP_T) void k_fill_fast(JoinIndexView ix, const u64 
             //  measured: no change.  The walk is bound by the instructions it issues, not by those waits.)
             // One backward branch per step; the match block sits on the fall-through path (a taken branch empties the
             // wavefront's instruction buffer, and the kernel retired 31 branches per 64 rows).
-            if (__builtin_amdgcn_ballot_w64(j < jend) != 0) {
+            // (lane masks straight from the compares -- uicmp / sicmp -- and back into a predicate -- inverse_ballot: the
+            //  bool-to-ballot round trip of `ballot(act && ...)` cost two VALU instructions per step, the recomputed loop
+            //  test one more: 13 -> 10 per step, and the walk is what the kernel's time goes into)
+            u64 actm = __builtin_amdgcn_uicmp(j, jend, 36 /* ULT */);   // lanes whose list is not done
+            if (actm != 0) {
                 do {
-                    const bool act = j < jend;
 #if defined(IVX_FP_BCAST)
                     const u64 x = L.s_ent[__builtin_amdgcn_readfirstlane(j) & 4095u];                  // (profiling: one address per wavefront, no bank conflicts)
 #else
@@ -1381,14 +1384,14 @@ __global__ __launch_bounds__(RP_T) void k_fill_fast(JoinIndexView ix, const u64 
 #if defined(IVX_FP_DUP)
                     { u64 y = *(const volatile u64 *)(L.s_ent + j + 1); asm volatile("" :: "v"(y)); }  // (profiling: every slice read twice)
 #endif
-                    const bool hit = act && (i32)(u32)x <= qe && (i32)(u32)(x >> 32) >= qs;
-                    const u64 mm = __builtin_amdgcn_ballot_w64(hit);
+                    const u64 mm = actm & __builtin_amdgcn_sicmp((i32)(u32)x, qe, 41 /* SLE */) & __builtin_amdgcn_sicmp((i32)(u32)(x >> 32), qs, 39 /* SGE */);
 #if !(defined(IVX_FP_ABL) && IVX_FP_ABL == 1)
-                    if (__builtin_expect(hit, 1)) half[(wpos + mask_rank(mm)) & (HALF - 1)] = make_uint2(j, roww[q]);
+                    if (__builtin_amdgcn_inverse_ballot_w64(mm)) half[mask_rank_from(mm, wpos) & (HALF - 1)] = make_uint2(j, roww[q]);      // (the counter's addend carries the position)
 #endif
                     wpos += (u32)__popcll(mm);
                     j++;
-                } while (__builtin_amdgcn_ballot_w64(j < jend) != 0);
+                    actm = __builtin_amdgcn_uicmp(j, jend, 36);
+                } while (actm != 0);
             }
         }
         u32 got = wpos;
